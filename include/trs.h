@@ -1,0 +1,182 @@
+/*
+ * trs.h — C-ABI of libtrs_hip.so: the MI355X (gfx950) hot path of the torchrecsys training loop.
+ *
+ * The reference (FrancescoI/torchrecsys) has no FFI; the seams this library sits behind are Python call
+ * contracts.  Every entry point below names the reference interface it replaces
+ * (file:line relative to the reference tree).  INTEGRATION.md shows the ctypes stub a maintainer of the
+ * reference would add to bind them.
+ *
+ * Conventions
+ *  - every pointer named *_dev / inside trs_tables / trs_batch is a DEVICE pointer owned by the caller
+ *    (PyTorch-ROCm allocates; the library never allocates, frees or synchronises);
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the null stream) and is
+ *    safe to capture into a hipGraph;
+ *  - return value: 0 = OK, negative = TRS_E_* ; trs_last_error() gives the message of the calling thread's
+ *    last failure.  No C++ exception crosses the boundary;
+ *  - ids are int32 or int64 (`idx_bytes` = 4 or 8): the reference uses int64 everywhere
+ *    (dataset/dataset.py:268-269), the device-resident interaction stream uses int32;
+ *  - an id outside its table is never dereferenced: the triple is skipped and bit 0 of *err_flag_dev is set
+ *    (the reference raises IndexError from aten::embedding; the host mirror raises it at the next sync);
+ *  - "field" order of every per-triple staging array: 0 = user, 1 = pos item, 2 = neg item,
+ *    3+2m = pos metadata column m, 4+2m = neg metadata column m  (R = 3 + 2M fields).
+ */
+#ifndef TRS_H
+#define TRS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRS_MAX_META 8
+#define TRS_MAX_LAYERS 8
+
+#define TRS_OK 0
+#define TRS_E_ARG (-1)     /* bad argument (shape, NULL, unsupported size) */
+#define TRS_E_LAUNCH (-2)  /* HIP launch / runtime error */
+#define TRS_E_DEVICE (-3)  /* no gfx950 device / wrong architecture */
+
+#define TRS_NET_LINEAR 0
+#define TRS_NET_FM 1
+
+/* Embedding tables of one scorer.  Row-major (n_rows, D) fp32, as nn.Embedding.weight
+ * (embeddings/init_embeddings.py:5-50,53-97).
+ *   Linear (collaborative/linear.py:43-51): user,item = self.user,self.item; user_lin,item_lin = user_bias,item_bias
+ *                                           (n,1); meta[m] = self.metadata[m]; meta_lin unused (NULL).
+ *   FM     (collaborative/fm.py:42-56):     user,item; user_lin,item_lin = linear_user,linear_item (n,1);
+ *                                           meta[m] = metadata[m]; meta_lin[m] = linear_metadata[m] (n,1).
+ *   MLP    (collaborative/mlp.py:66-71):    user,item; meta[m] = metadata_embeddings[m]; *_lin unused. */
+typedef struct trs_tables {
+  float* user;
+  float* item;
+  float* user_lin;
+  float* item_lin;
+  float* meta[TRS_MAX_META];
+  float* meta_lin[TRS_MAX_META];
+  int64_t n_users;
+  int64_t n_items;
+  int64_t n_meta[TRS_MAX_META];
+  int32_t D; /* n_factors */
+  int32_t M; /* metadata columns, 0..TRS_MAX_META */
+} trs_tables;
+
+/* One mini-batch as FastDataLoader.__next__ yields it (dataset/dataset.py:414-458):
+ * keys user_id, pos_item_id, neg_item_id (B,), pos_metadata_id, neg_metadata_id (B,M) row-major. */
+typedef struct trs_batch {
+  const void* user;
+  const void* pos;
+  const void* neg;      /* NULL: score the positive pass only (predict, model.py:436-439) */
+  const void* pos_meta; /* (B,M) or NULL when M == 0 */
+  const void* neg_meta;
+  int64_t B;
+  int32_t idx_bytes;     /* 4 or 8 */
+  int32_t* err_flag_dev; /* optional; bit 0 set on an out-of-range id */
+} trs_batch;
+
+/* ---------------------------------------------------------------------------------------------- misc */
+const char* trs_last_error(void);
+/* ABI version of this header; bump on any signature change. */
+int trs_abi_version(void);
+/* 0 if the current HIP device is gfx950, TRS_E_DEVICE otherwise. */
+int trs_check_device(void);
+
+/* ------------------------------------------------------------------------- loader / sampler (a9, a10) */
+/* Counter-based dynamic negative sampler: neg[t] uniform over {0..n_items-1} \ {pos[t]} — the distribution of the
+ * rejection loop at dataset/dataset.py:440-445 (reject only the row's own positive).  Stream: Philox4x32-10,
+ * key = seed, counter = offset + t; r = mulhi64(x, n_items-1); neg = r + (r >= pos).  Not the numpy legacy
+ * stream (that one is replayed on the host by FastDataLoader for bit-exact reference batches). */
+int trs_sample_neg(const void* pos_dev, int idx_bytes, int64_t B, int64_t n_items, uint64_t seed,
+                   uint64_t offset, void* neg_out_dev, void* stream);
+
+/* Epoch shuffle + batch slice + negative sampling in one pass over a device-resident interaction stream
+ * (replaces torch.randperm + tensor[perm[i:i+B]] at dataset/dataset.py:364-373,420-422 and the sampler loop
+ * :435-447).  Row p of the stream is (stream_user[p], stream_item[p]), int32.  Position q = t0 + t of the epoch maps
+ * to row perm(q) where perm is a keyed bijection of [0,N) (4-round Feistel network over ceil(log2 N) bits with
+ * cycle walking, round function Philox-mix keyed by shuffle_key; shuffle_key = 0 means identity = shuffle=False).
+ * Writes user/pos/neg int32 (B,) and, when M > 0, pos_meta/neg_meta (B,M) looked up through item_meta (n_items,M)
+ * (the device form of item_to_metadata_map, dataset/dataset.py:375-411).  neg_static (N,) int32 non-NULL selects the
+ * static negatives of dataset/dataset.py:56-64 instead of sampling. */
+int trs_batch_prepare(const int32_t* stream_user_dev, const int32_t* stream_item_dev,
+                      const int32_t* neg_static_dev, int64_t N, uint64_t shuffle_key, int64_t t0, int64_t B,
+                      int64_t n_items, uint64_t sample_seed, uint64_t sample_offset,
+                      const int32_t* item_meta_dev, int32_t M, int32_t* user_out, int32_t* pos_out,
+                      int32_t* neg_out, int32_t* pos_meta_out, int32_t* neg_meta_out, void* stream);
+
+/* ------------------------------------------------------------------ scorers: forward only (a2, a3, a6) */
+/* Fused positive+negative scoring pass; the user row is gathered once for both passes.
+ * net = TRS_NET_LINEAR: Linear.forward (collaborative/linear.py:54-80), score (B,1);
+ * net = TRS_NET_FM:     FM.forward     (collaborative/fm.py:60-101),   score (B,) after sigmoid.
+ * Replaces the two net.forward calls of TorchRecSys.forward (model.py:171-185).  neg_score may be NULL iff
+ * batch->neg is NULL. */
+int trs_score_forward(int net, const trs_tables* tables, const trs_batch* batch, float* pos_score_dev,
+                      float* neg_score_dev, void* stream);
+
+/* ------------------------------------------------- scorers: forward + hinge + backward (a2,a3,a5,a6,a7) */
+/* One training pass over a batch with all rows read from the PRE-update tables (the semantics of
+ * loss.backward() before optimizer.step(), model.py:188-200):
+ *   scores as trs_score_forward; h = neg - pos + 1; loss_sum += sum max(h,0) (helper/loss.py:5-9; the caller divides
+ *   by B); auc_count += #(pos > neg) (evaluate/metrics.py:23-31); per-triple gradient rows of d(mean hinge)/d(row)
+ *   staged field-major into grad_rows (R,B,D) and the 1-wide terms into grad_lin (R,B) — i.e. exactly the
+ *   uncoalesced values of the sparse COO gradients autograd builds (EmbeddingBackward), zero rows kept.
+ * inv_B = 1/B of the mean.  pos_score/neg_score/auc_count may be NULL.  loss_sum/auc_count are ACCUMULATED
+ * (atomic float / int adds): zero them before the first call. */
+int trs_score_fwd_bwd(int net, const trs_tables* tables, const trs_batch* batch, float inv_B,
+                      float* pos_score_dev, float* neg_score_dev, float* loss_sum_dev,
+                      int32_t* auc_count_dev, float* grad_rows_dev, float* grad_lin_dev, void* stream);
+
+/* Backward only, from upstream d(loss)/d(score) (B,) per pass — the autograd.Function backward used when a caller
+ * drives net.forward + its own loss (any objective), same staging as above. */
+int trs_score_backward(int net, const trs_tables* tables, const trs_batch* batch, const float* gpos_dev,
+                       const float* gneg_dev, float* grad_rows_dev, float* grad_lin_dev, void* stream);
+
+/* ---------------------------------------------------------------- sparse row optimisers (a7, App. A.5) */
+/* table[idx[t]] += alpha * vals[t]  for t < n, rows of D floats, vals row t at vals + t*ld.  Float atomics, one
+ * 256-B segment per wave-instruction.  alpha = -lr is torch.optim.SGD's sparse param.add_(grad, alpha=-lr)
+ * (third-party torch/optim/sgd.py, called from model.py:198).  Duplicate ids accumulate (uncoalesced COO). */
+int trs_rows_scatter_add(float* table_dev, int64_t n_rows, int32_t D, const void* idx_dev, int32_t idx_bytes,
+                         const float* vals_dev, int64_t ld, int64_t n, float alpha, int32_t* err_flag_dev,
+                         void* stream);
+
+/* Fused SGD update of every table of a scorer from the staging arrays of trs_score_fwd_bwd:
+ * table_f[idx_f[t]] -= lr * grad_rows[f][t]  and the 1-wide tables likewise from grad_lin. */
+int trs_score_sgd_update(int net, const trs_tables* tables, const trs_batch* batch, const float* grad_rows_dev,
+                         const float* grad_lin_dev, float lr, void* stream);
+
+/* Coalescing optimisers (SparseAdam / Adagrad / SGD-momentum need the per-row SUM of duplicates):
+ *   1. trs_rows_scatter_add into `acc` (same shape as the table, all-zero between steps);
+ *   2. trs_rows_apply_*: for every id in idx, the first arrival per distinct row (elected with atomicExch on
+ *      stamp[row] == step_id) applies the update from acc[row] and clears acc[row].  Rows present in the batch are
+ *      "touched" even when their gradient is zero.
+ * step_id must be unique per (table, step) and never 0 after the stamps were zero-initialised. */
+int trs_rows_apply_sparse_adam(float* table_dev, float* acc_dev, float* exp_avg_dev, float* exp_avg_sq_dev,
+                               int32_t* stamp_dev, int64_t n_rows, int32_t D, const void* idx_dev,
+                               int32_t idx_bytes, int64_t n, int32_t step_id, float lr, float beta1, float beta2,
+                               float eps, int64_t step_count, void* stream);
+int trs_rows_apply_adagrad(float* table_dev, float* acc_dev, float* state_sum_dev, int32_t* stamp_dev,
+                           int64_t n_rows, int32_t D, const void* idx_dev, int32_t idx_bytes, int64_t n,
+                           int32_t step_id, float clr, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------ hinge / AUC (a5, a12) */
+/* loss_sum += sum_t max(neg-pos+1, 0); auc_count += #(pos > neg).  (helper/loss.py:5-9, evaluate/metrics.py:23-31) */
+int trs_hinge_auc(const float* pos_dev, const float* neg_dev, int64_t B, float* loss_sum_dev,
+                  int32_t* auc_count_dev, void* stream);
+/* d(mean hinge)/d(pos), d(.)/d(neg): -a/B, +a/B with a = [neg-pos+1 >= 0] (torch clamp subgradient). */
+int trs_hinge_backward(const float* pos_dev, const float* neg_dev, int64_t B, float inv_B, float* gpos_dev,
+                       float* gneg_dev, void* stream);
+
+/* ---------------------------------------------------------------------------------- predict (a13) */
+/* Scores of ONE user against items [item0, item0+n) (model.py:341-452: net.forward over item chunks, pos keys
+ * only).  item_meta (n_items,M) int32 gives each item's metadata ids (NULL when M == 0). */
+int trs_score_all_items(int net, const trs_tables* tables, int64_t user_id, int64_t item0, int64_t n,
+                        const int32_t* item_meta_dev, float* score_out_dev, void* stream);
+/* Top-k of scores (n,) by (score descending, index ascending) -> idx_out (k,) int64.  workspace: at least
+ * trs_topk_workspace_bytes(n, k) bytes.  (torch.sort(descending=True)[:top_k], model.py:447-450) */
+int64_t trs_topk_workspace_bytes(int64_t n, int32_t k);
+int trs_topk(const float* scores_dev, int64_t n, int32_t k, int64_t* idx_out_dev, void* workspace_dev,
+             int64_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRS_H */

@@ -1,0 +1,264 @@
+# -*- coding: utf-8 -*-
+"""Generates tests/golden/*.npz by RUNNING THE REAL REFERENCE (FrancescoI/torchrecsys @ /root/reference).
+
+Run only in the build container (the reference never travels to the GPU box):
+
+    cd /root/repo && PYTHONPATH=/root/reference PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The committed .npz files hold DATA only: inputs (seeds, id tensors, initial parameters) and the reference's outputs
+(scores, losses, gradients, updated parameters, index streams, top-k, printed metrics).  No reference source is stored.
+Determinism: torch.set_num_threads(1); np.random.seed + torch.manual_seed before every case.
+"""
+import builtins
+import contextlib
+import io
+import os
+import re
+import sys
+import typing
+
+builtins.List = typing.List  # the reference's collaborative/mlp.py:16 uses List without importing it
+
+import numpy as np  # noqa: E402
+import pandas as pd  # noqa: E402
+import torch  # noqa: E402
+
+torch.set_num_threads(1)
+
+from torchrecsys.collaborative.fm import FM  # noqa: E402
+from torchrecsys.collaborative.linear import Linear  # noqa: E402
+from torchrecsys.collaborative.mlp import MLP  # noqa: E402
+from torchrecsys.dataset.dataset import FastDataLoader, ProcessData  # noqa: E402
+from torchrecsys.evaluate.metrics import Metrics  # noqa: E402
+from torchrecsys.helper.loss import hinge_loss  # noqa: E402
+from torchrecsys.model import TorchRecSys  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+NU, NI, D, B = 40, 30, 8, 64
+META_SIZES = [5, 7, 4]
+
+
+def seed(s):
+    np.random.seed(s)
+    torch.manual_seed(s)
+
+
+def make_net(net_type, M, **kw):
+    n_meta = {f"m{m}": META_SIZES[m] for m in range(M)}
+    cls = {"linear": Linear, "fm": FM, "mlp": MLP}[net_type]
+    return cls(n_users=NU, n_items=NI, n_metadata=n_meta, n_factors=D, use_metadata=M > 0, **kw)
+
+
+def make_batch(M, rs):
+    """Explicit id tensors with duplicate users/items and some pos == neg rows."""
+    u = rs.randint(0, NU, size=B)
+    p = rs.randint(0, NI, size=B)
+    n = rs.randint(0, NI, size=B)
+    u[5] = u[6] = u[40]          # duplicate users
+    p[7] = p[8] = n[9]           # duplicates across pos/neg
+    n[10] = p[10]                # pos == neg rows (cancelling gradients on the item row)
+    n[11] = p[11]
+    batch = {"user_id": torch.from_numpy(u).long(), "pos_item_id": torch.from_numpy(p).long(),
+             "neg_item_id": torch.from_numpy(n).long()}
+    if M > 0:
+        item_meta = np.stack([rs.randint(0, META_SIZES[m], size=NI) for m in range(M)], axis=1)
+        batch["pos_metadata_id"] = torch.from_numpy(item_meta[p]).long()
+        batch["neg_metadata_id"] = torch.from_numpy(item_meta[n]).long()
+    return batch
+
+
+def sd_np(module, prefix):
+    return {f"{prefix}/{k}": v.detach().cpu().numpy().copy() for k, v in module.state_dict().items()}
+
+
+def fwd_both(net, batch, M):
+    mk = ("pos_metadata_id", "neg_metadata_id") if M > 0 else (None, None)
+    pos = net.forward(batch, "user_id", "pos_item_id", mk[0])
+    neg = net.forward(batch, "user_id", "neg_item_id", mk[1])
+    return pos, neg
+
+
+def dense_grads(net, prefix):
+    out = {}
+    for k, p in net.named_parameters():
+        g = p.grad
+        if g is None:
+            continue
+        out[f"{prefix}/{k}"] = (g.to_dense() if g.is_sparse else g).detach().numpy().copy()
+    return out
+
+
+class PairOpt:
+    """SparseAdam(embeddings) + Adam(dense): the only 'Adam' the reference can run on the MLP."""
+
+    def __init__(self, net, lr):
+        emb = [p for k, p in net.named_parameters() if k.split(".")[0] in ("user", "item", "metadata_embeddings")]
+        dense = [p for k, p in net.named_parameters() if k.split(".")[0] not in ("user", "item", "metadata_embeddings")]
+        self.a = torch.optim.SparseAdam(emb, lr=lr)
+        self.b = torch.optim.Adam(dense, lr=lr)
+
+    def zero_grad(self):
+        self.a.zero_grad()
+        self.b.zero_grad()
+
+    def step(self):
+        self.a.step()
+        self.b.step()
+
+
+def g1_g2():
+    """G1 forward/backward of one batch; G2 three optimiser steps per optimiser; G6 eval-mode scores."""
+    cases = [("linear", {}), ("fm", {}), ("mlp", {"hidden_layers": [32, 16]}),
+             ("mlp_nobn", {"hidden_layers": [32, 16], "use_batch_norm": False})]
+    for name, kw in cases:
+        net_type = name.split("_")[0]
+        for M in (0, 1, 3):
+            rs = np.random.RandomState(100 + M)
+            batch = make_batch(M, rs)
+            seed(11)
+            net = make_net(net_type, M, **kw)
+            net.train()
+            out = {f"batch/{k}": v.numpy() for k, v in batch.items()}
+            out.update(sd_np(net, "init"))
+            pos, neg = fwd_both(net, batch, M)
+            loss = hinge_loss(pos, neg)
+            loss.backward()
+            out["pos"] = pos.detach().numpy()
+            out["neg"] = neg.detach().numpy()
+            out["loss"] = np.float32(loss.item())
+            out["auc"] = np.float64(Metrics().auc_score(pos.detach().float(), neg.detach().float()).item())
+            out.update(dense_grads(net, "grad"))
+            out.update(sd_np(net, "after_fwd"))  # BN running stats after the two training passes
+            # G6: eval-mode scores with the updated running stats
+            net.eval()
+            with torch.no_grad():
+                pe, ne = fwd_both(net, batch, M)
+            out["pos_eval"], out["neg_eval"] = pe.numpy(), ne.numpy()
+            np.savez_compressed(os.path.join(OUT, f"g1_{name}_M{M}.npz"), **out)
+
+            # G2 optimiser trajectories (3 steps on the same batch, fresh net each time)
+            opts = {
+                "sgd": lambda ps, n_: torch.optim.SGD(ps, lr=0.05),
+                "sgdm": lambda ps, n_: torch.optim.SGD(ps, lr=0.05, momentum=0.9),
+                "adagrad": lambda ps, n_: torch.optim.Adagrad(ps, lr=0.05),
+            }
+            if net_type == "mlp":
+                opts["adam"] = lambda ps, n_: PairOpt(n_, lr=0.01)
+            else:
+                opts["sparseadam"] = lambda ps, n_: torch.optim.SparseAdam(ps, lr=0.01)
+            for oname, mk in opts.items():
+                seed(11)
+                net = make_net(net_type, M, **kw)
+                net.train()
+                opt = mk(list(net.parameters()), net)
+                traj = {f"batch/{k}": v.numpy() for k, v in batch.items()}
+                traj.update(sd_np(net, "init"))
+                losses = []
+                for step in range(3):
+                    opt.zero_grad()
+                    pos, neg = fwd_both(net, batch, M)
+                    loss = hinge_loss(pos, neg)
+                    loss.backward()
+                    opt.step()
+                    losses.append(loss.item())
+                    traj.update(sd_np(net, f"step{step}"))
+                traj["losses"] = np.asarray(losses, dtype=np.float32)
+                np.savez_compressed(os.path.join(OUT, f"g2_{name}_M{M}_{oname}.npz"), **traj)
+
+
+def g3():
+    """Index streams: split, static negatives, dynamic sampler (incl. forced collisions), loader batches."""
+    out = {}
+    for N in (7, 1000):
+        df = pd.DataFrame({"u": np.arange(N) % 5, "i": np.arange(N) % 3})
+        seed(3)
+        dp = ProcessData(df.copy(), "u", "i", split_ratio=0.8, dynamic_neg_sampling=True)
+        # recover the split row order through a marker column: use pos ids of a frame whose item column is arange
+        df2 = pd.DataFrame({"u": np.zeros(N, dtype=np.int64), "i": np.arange(N)})
+        dp2 = ProcessData(df2, "u", "i", split_ratio=0.8, dynamic_neg_sampling=True)
+        dp2.prepare_data()
+        out[f"split_train_N{N}"] = dp2.train_data["pos_item_id"].numpy()
+        out[f"split_test_N{N}"] = dp2.test_data["pos_item_id"].numpy()
+    # static negatives: drawn before the split from the global legacy stream
+    N = 1000
+    rs = np.random.RandomState(0)
+    df = pd.DataFrame({"u": rs.randint(0, 50, N), "i": np.concatenate([np.arange(20), rs.randint(0, 20, N - 20)])})
+    seed(5)
+    dp = ProcessData(df.copy(), "u", "i", split_ratio=0.8, dynamic_neg_sampling=False)
+    dp.prepare_data()
+    out["static_df_u"], out["static_df_i"] = df["u"].values, df["i"].values
+    out["static_train_user"] = dp.train_data["user_id"].numpy()
+    out["static_train_pos"] = dp.train_data["pos_item_id"].numpy()
+    out["static_train_neg"] = dp.train_data["neg_item_id"].numpy()
+    out["static_test_neg"] = dp.test_data["neg_item_id"].numpy()
+    # dynamic sampler through FastDataLoader: n_items = 3 forces collisions; also n_items = 20
+    for n_items in (3, 20):
+        pos = np.random.RandomState(7).randint(0, n_items, size=257)
+        data = {"user_id": torch.zeros(257, dtype=torch.long), "pos_item_id": torch.from_numpy(pos).long()}
+        seed(9)
+        loader = FastDataLoader(data, batch_size=100, shuffle=False, dynamic_neg_sampling=True, n_items=n_items)
+        negs = [b["neg_item_id"].numpy() for b in loader]
+        out[f"dyn_pos_n{n_items}"] = pos
+        out[f"dyn_neg_n{n_items}"] = np.concatenate(negs)
+        out[f"dyn_next_draw_n{n_items}"] = np.int64(np.random.randint(0, 1000))  # stream position afterwards
+    # shuffled loader: which rows each batch holds (randperm in ctor + one per __iter__)
+    data = {"user_id": torch.arange(23), "pos_item_id": torch.arange(23) % 4, "neg_item_id": torch.arange(23) % 3}
+    seed(13)
+    loader = FastDataLoader(data, batch_size=5, shuffle=True)
+    out["shuffle_epoch0"] = np.concatenate([b["user_id"].numpy() for b in loader])
+    out["shuffle_epoch1"] = np.concatenate([b["user_id"].numpy() for b in loader])
+    np.savez_compressed(os.path.join(OUT, "g3_index_streams.npz"), **out)
+
+
+def synth_df(n_users, n_items, N, rs):
+    """Dense id coverage."""
+    users = np.concatenate([np.arange(n_users), rs.randint(0, n_users, N - n_users)])
+    items = np.concatenate([np.tile(np.arange(n_items), -(-n_users // n_items))[:n_users],
+                            rs.randint(0, n_items, N - n_users)])
+    perm = rs.permutation(N)
+    return pd.DataFrame({"user": users[perm], "item": items[perm]})
+
+
+def g4_g5():
+    """End-to-end TorchRecSys runs: epoch losses, final weights, predict top-k, evaluate() metrics."""
+    n_users, n_items, N = 300, 100, 10000
+    df = synth_df(n_users, n_items, N, np.random.RandomState(0))
+    for net_type in ("linear", "fm", "mlp"):
+        for dyn in (False, True):
+            seed(7)
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                model = TorchRecSys(dataset=df.copy(), user_id_col="user", item_id_col="item", n_factors=16,
+                                    net_type=net_type, dynamic_neg_sampling=dyn)
+                init = sd_np(model, "init")
+                opt = torch.optim.SGD(model.parameters(), lr=0.05)
+                model.fit(optimizer=opt, epochs=2, batch_size=256)
+                final = sd_np(model, "final")
+                if not dyn:
+                    model.evaluate(batch_size=256)
+                top = model.predict(user_id=3, top_k=10, prediction_batch_size=37)
+            txt = buf.getvalue()
+            out = {"df_user": df["user"].values, "df_item": df["item"].values, "top10_user3": top.numpy()}
+            out["epoch_losses"] = np.asarray([float(x) for x in re.findall(r"Training Loss: ([0-9.]+)", txt)])
+            if not dyn:
+                out["eval_loss"] = np.float64(re.findall(r"Testing loss: ([0-9.]+)", txt)[0])
+                out["eval_auc"] = np.float64(re.findall(r"Testing auc: ([0-9.]+)", txt)[0])
+            out["stdout"] = np.asarray(txt)
+            out.update(init)
+            out.update(final)
+            # all-item scores of user 3 in eval mode (tie check for the top-k fixture)
+            model.net.eval()
+            with torch.no_grad():
+                sc = model.net.forward({"user_id": torch.full((n_items,), 3, dtype=torch.long),
+                                        "pos_item_id": torch.arange(n_items)}, "user_id", "pos_item_id", None)
+            out["scores_user3"] = sc.reshape(-1).numpy()
+            np.savez_compressed(os.path.join(OUT, f"g4_{net_type}_{'dyn' if dyn else 'static'}.npz"), **out)
+
+
+if __name__ == "__main__":
+    assert os.path.isdir("/root/reference"), "run in the build container"
+    g1_g2()
+    g3()
+    g4_g5()
+    tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))
+    print("golden vectors written:", len([f for f in os.listdir(OUT) if f.endswith('.npz')]), "files,", tot, "bytes")

@@ -1,0 +1,117 @@
+# -*- coding: utf-8 -*-
+"""ctypes binding of libtrs_hip.so — the C-ABI declared in include/trs.h.
+
+There is NO CPU fallback: a missing library, a missing symbol or a non-gfx950 device raises.  PyTorch-ROCm is used
+only as the owner of device memory and of the HIP stream the kernels are enqueued on.
+"""
+import ctypes as C
+import os
+
+TRS_MAX_META = 8
+TRS_NET_LINEAR = 0
+TRS_NET_FM = 1
+ABI_VERSION = 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtrs_hip.so")
+
+c_float_p = C.POINTER(C.c_float)
+c_int32_p = C.POINTER(C.c_int32)
+c_int64_p = C.POINTER(C.c_int64)
+
+
+class TrsTables(C.Structure):
+    """struct trs_tables (include/trs.h)."""
+    _fields_ = [
+        ("user", C.c_void_p),
+        ("item", C.c_void_p),
+        ("user_lin", C.c_void_p),
+        ("item_lin", C.c_void_p),
+        ("meta", C.c_void_p * TRS_MAX_META),
+        ("meta_lin", C.c_void_p * TRS_MAX_META),
+        ("n_users", C.c_int64),
+        ("n_items", C.c_int64),
+        ("n_meta", C.c_int64 * TRS_MAX_META),
+        ("D", C.c_int32),
+        ("M", C.c_int32),
+    ]
+
+
+class TrsBatch(C.Structure):
+    """struct trs_batch (include/trs.h)."""
+    _fields_ = [
+        ("user", C.c_void_p),
+        ("pos", C.c_void_p),
+        ("neg", C.c_void_p),
+        ("pos_meta", C.c_void_p),
+        ("neg_meta", C.c_void_p),
+        ("B", C.c_int64),
+        ("idx_bytes", C.c_int32),
+        ("err_flag_dev", C.c_void_p),
+    ]
+
+
+_vp, _i32, _i64, _u64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
+_T, _Bp = C.POINTER(TrsTables), C.POINTER(TrsBatch)
+
+# name -> (restype, argtypes); must list every function include/trs.h declares (tests/test_abi.py checks both ways)
+PROTOTYPES = {
+    "trs_last_error": (C.c_char_p, []),
+    "trs_abi_version": (C.c_int, []),
+    "trs_check_device": (C.c_int, []),
+    "trs_sample_neg": (C.c_int, [_vp, C.c_int, _i64, _i64, _u64, _u64, _vp, _vp]),
+    "trs_batch_prepare": (C.c_int, [_vp, _vp, _vp, _i64, _u64, _i64, _i64, _i64, _u64, _u64, _vp, _i32,
+                                    _vp, _vp, _vp, _vp, _vp, _vp]),
+    "trs_score_forward": (C.c_int, [C.c_int, _T, _Bp, _vp, _vp, _vp]),
+    "trs_score_fwd_bwd": (C.c_int, [C.c_int, _T, _Bp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "trs_score_backward": (C.c_int, [C.c_int, _T, _Bp, _vp, _vp, _vp, _vp, _vp]),
+    "trs_rows_scatter_add": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _i64, _i64, _f, _vp, _vp]),
+    "trs_score_sgd_update": (C.c_int, [C.c_int, _T, _Bp, _vp, _vp, _f, _vp]),
+    "trs_rows_apply_sparse_adam": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _i64, _i32,
+                                             _f, _f, _f, _f, _i64, _vp]),
+    "trs_rows_apply_adagrad": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _i64, _i32, _f, _f, _vp]),
+    "trs_hinge_auc": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "trs_hinge_backward": (C.c_int, [_vp, _vp, _i64, _f, _vp, _vp, _vp]),
+    "trs_score_all_items": (C.c_int, [C.c_int, _T, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "trs_topk_workspace_bytes": (C.c_int64, [_i64, _i32]),
+    "trs_topk": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _i64, _vp]),
+}
+
+
+class TrsError(RuntimeError):
+    """A negative return code from libtrs_hip.so."""
+
+
+_lib = None
+
+
+def load():
+    """Load libtrs_hip.so and bind every prototype.  Raises if the library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+            f"`make -C torchrecsys_amd/csrc`.  torchrecsys_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.trs_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"libtrs_hip.so ABI version {got} != binding version {ABI_VERSION}; rebuild the library")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().trs_last_error()
+        raise TrsError(f"{what or 'libtrs_hip'} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()

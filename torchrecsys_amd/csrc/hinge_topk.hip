@@ -1,0 +1,177 @@
+// hinge_topk.hip — hinge loss / pairwise AUC reductions (reference helper/loss.py:5-9, evaluate/metrics.py:23-31)
+// and the predict() top-k (reference model.py:447-450: torch.sort(descending=True)[:top_k]).
+#include "trs_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(TRS_BLOCK) void hinge_auc_kernel(const float* __restrict__ pos,
+                                                             const float* __restrict__ neg, int64_t B,
+                                                             float* loss_sum, int32_t* auc_count) {
+  float L = 0.f;
+  int A = 0;
+  const int64_t stride = (int64_t)gridDim.x * TRS_BLOCK;
+  for (int64_t t = (int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x; t < B; t += stride) {
+    const float p = pos[t], n = neg[t];
+    L += fmaxf(n - p + 1.0f, 0.f);
+    A += (p > n) ? 1 : 0;
+  }
+  __shared__ float s_l[TRS_BLOCK / TRS_WAVE];
+  __shared__ int s_a[TRS_BLOCK / TRS_WAVE];
+  L = trs_wave_sum(L);
+  A = trs_wave_sum_i(A);
+  if ((threadIdx.x & 63) == 0) {
+    s_l[threadIdx.x >> 6] = L;
+    s_a[threadIdx.x >> 6] = A;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float l = 0.f;
+    int a = 0;
+    for (int w = 0; w < TRS_BLOCK / TRS_WAVE; ++w) {
+      l += s_l[w];
+      a += s_a[w];
+    }
+    if (loss_sum && l != 0.f) atomicAdd(loss_sum, l);
+    if (auc_count && a != 0) atomicAdd(auc_count, a);
+  }
+}
+
+__global__ __launch_bounds__(TRS_BLOCK) void hinge_backward_kernel(const float* __restrict__ pos,
+                                                                  const float* __restrict__ neg, int64_t B,
+                                                                  float inv_B, float* __restrict__ gpos,
+                                                                  float* __restrict__ gneg) {
+  const int64_t stride = (int64_t)gridDim.x * TRS_BLOCK;
+  for (int64_t t = (int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x; t < B; t += stride) {
+    const float act = (neg[t] - pos[t] + 1.0f >= 0.f) ? inv_B : 0.f;
+    gpos[t] = -act;
+    gneg[t] = act;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ top-k
+// key = (orderable(score) << 32) | (0xFFFFFFFF - index): descending key order == (score desc, index asc).
+// NaN sorts first (torch.sort(descending=True) treats NaN as the largest value); -0.0 ties with +0.0.
+constexpr int TOPK_CHUNK = 4096;
+constexpr int TOPK_MAXK = TOPK_CHUNK / 2;
+
+__device__ __forceinline__ uint64_t topk_key(float s, uint32_t idx) {
+  uint32_t o;
+  if (s != s) {
+    o = 0xFFFFFFFFu;
+  } else {
+    if (s == 0.f) s = 0.f;
+    const uint32_t b = __float_as_uint(s);
+    o = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+  }
+  return ((uint64_t)o << 32) | (uint64_t)(0xFFFFFFFFu - idx);
+}
+
+// Each block sorts one chunk of TOPK_CHUNK keys (descending, bitonic in LDS) and emits its first k.
+// FROM_SCORES: read fp32 scores and build keys; otherwise read keys.  FINAL: write int64 indices instead of keys.
+template <bool FROM_SCORES, bool FINAL>
+__global__ __launch_bounds__(TRS_BLOCK) void topk_chunk_kernel(const float* __restrict__ scores,
+                                                              const uint64_t* __restrict__ keys_in, int64_t n, int k,
+                                                              uint64_t* __restrict__ keys_out,
+                                                              int64_t* __restrict__ idx_out) {
+  __shared__ uint64_t s[TOPK_CHUNK];
+  const int64_t base = (int64_t)blockIdx.x * TOPK_CHUNK;
+  for (int i = threadIdx.x; i < TOPK_CHUNK; i += TRS_BLOCK) {
+    const int64_t g = base + i;
+    uint64_t key = 0;  // below every real key
+    if (g < n) key = FROM_SCORES ? topk_key(scores[g], (uint32_t)g) : keys_in[g];
+    s[i] = key;
+  }
+  __syncthreads();
+  for (int size = 2; size <= TOPK_CHUNK; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = threadIdx.x; i < TOPK_CHUNK / 2; i += TRS_BLOCK) {
+        const int lo = 2 * i - (i & (stride - 1));
+        const int hi = lo + stride;
+        const bool desc = (lo & size) == 0;  // descending blocks first -> whole array descending at the end
+        const uint64_t a = s[lo], b = s[hi];
+        if ((a < b) == desc) {
+          s[lo] = b;
+          s[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < k; i += TRS_BLOCK) {
+    if (FINAL)
+      idx_out[i] = (int64_t)(0xFFFFFFFFu - (uint32_t)(s[i] & 0xFFFFFFFFu));
+    else
+      keys_out[(int64_t)blockIdx.x * k + i] = s[i];
+  }
+}
+
+}  // namespace
+
+extern "C" int trs_hinge_auc(const float* pos_dev, const float* neg_dev, int64_t B, float* loss_sum_dev,
+                             int32_t* auc_count_dev, void* stream) {
+  TRS_REQUIRE(B >= 0, "trs_hinge_auc: negative B");
+  if (B == 0) return TRS_OK;
+  TRS_REQUIRE(pos_dev && neg_dev, "trs_hinge_auc: scores are NULL");
+  hipLaunchKernelGGL(hinge_auc_kernel, dim3(trs_grid(B, TRS_BLOCK * 4)), dim3(TRS_BLOCK), 0, (hipStream_t)stream,
+                     pos_dev, neg_dev, B, loss_sum_dev, auc_count_dev);
+  TRS_CHECK_LAUNCH("hinge_auc_kernel");
+  return TRS_OK;
+}
+
+extern "C" int trs_hinge_backward(const float* pos_dev, const float* neg_dev, int64_t B, float inv_B,
+                                  float* gpos_dev, float* gneg_dev, void* stream) {
+  TRS_REQUIRE(B >= 0, "trs_hinge_backward: negative B");
+  if (B == 0) return TRS_OK;
+  TRS_REQUIRE(pos_dev && neg_dev && gpos_dev && gneg_dev, "trs_hinge_backward: NULL argument");
+  hipLaunchKernelGGL(hinge_backward_kernel, dim3(trs_grid(B, TRS_BLOCK)), dim3(TRS_BLOCK), 0, (hipStream_t)stream,
+                     pos_dev, neg_dev, B, inv_B, gpos_dev, gneg_dev);
+  TRS_CHECK_LAUNCH("hinge_backward_kernel");
+  return TRS_OK;
+}
+
+extern "C" int64_t trs_topk_workspace_bytes(int64_t n, int32_t k) {
+  if (n <= 0 || k <= 0) return 0;
+  const int64_t nb0 = (n + TOPK_CHUNK - 1) / TOPK_CHUNK;
+  const int64_t nb1 = (nb0 * k + TOPK_CHUNK - 1) / TOPK_CHUNK;
+  return 8 * (int64_t)k * (nb0 + nb1);
+}
+
+extern "C" int trs_topk(const float* scores_dev, int64_t n, int32_t k, int64_t* idx_out_dev, void* workspace_dev,
+                        int64_t workspace_bytes, void* stream) {
+  TRS_REQUIRE(n > 0 && n < ((int64_t)1 << 32), "trs_topk: n=%lld outside 1..2^32-1", (long long)n);
+  TRS_REQUIRE(k >= 1 && k <= n, "trs_topk: need 1 <= k <= n (k=%d, n=%lld)", k, (long long)n);
+  TRS_REQUIRE(k <= TOPK_MAXK, "trs_topk: k=%d exceeds the supported maximum %d", k, TOPK_MAXK);
+  TRS_REQUIRE(scores_dev && idx_out_dev, "trs_topk: scores/idx_out is NULL");
+  TRS_REQUIRE(workspace_bytes >= trs_topk_workspace_bytes(n, k) && (workspace_dev || n <= TOPK_CHUNK),
+              "trs_topk: workspace too small (%lld < %lld)", (long long)workspace_bytes,
+              (long long)trs_topk_workspace_bytes(n, k));
+  hipStream_t s = (hipStream_t)stream;
+  if (n <= TOPK_CHUNK) {
+    hipLaunchKernelGGL((topk_chunk_kernel<true, true>), dim3(1), dim3(TRS_BLOCK), 0, s, scores_dev, nullptr, n, k,
+                       nullptr, idx_out_dev);
+    TRS_CHECK_LAUNCH("topk_chunk_kernel");
+    return TRS_OK;
+  }
+  const int64_t nb0 = (n + TOPK_CHUNK - 1) / TOPK_CHUNK;
+  uint64_t* bufA = (uint64_t*)workspace_dev;
+  uint64_t* bufB = bufA + nb0 * k;
+  hipLaunchKernelGGL((topk_chunk_kernel<true, false>), dim3((unsigned)nb0), dim3(TRS_BLOCK), 0, s, scores_dev,
+                     nullptr, n, k, bufA, nullptr);
+  TRS_CHECK_LAUNCH("topk_chunk_kernel");
+  int64_t cnt = nb0 * k;
+  uint64_t *in = bufA, *out = bufB;
+  while (cnt > TOPK_CHUNK) {
+    const int64_t nb = (cnt + TOPK_CHUNK - 1) / TOPK_CHUNK;
+    hipLaunchKernelGGL((topk_chunk_kernel<false, false>), dim3((unsigned)nb), dim3(TRS_BLOCK), 0, s, nullptr, in,
+                       cnt, k, out, nullptr);
+    TRS_CHECK_LAUNCH("topk_chunk_kernel");
+    cnt = nb * k;
+    uint64_t* tmp = in;
+    in = out;
+    out = tmp;
+  }
+  hipLaunchKernelGGL((topk_chunk_kernel<false, true>), dim3(1), dim3(TRS_BLOCK), 0, s, nullptr, in, cnt, k, nullptr,
+                     idx_out_dev);
+  TRS_CHECK_LAUNCH("topk_chunk_kernel");
+  return TRS_OK;
+}

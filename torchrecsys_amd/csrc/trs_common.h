@@ -1,0 +1,145 @@
+// trs_common.h — shared host/device helpers of libtrs_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/trs.h"
+
+#define TRS_WAVE 64
+#define TRS_BLOCK 256
+
+// ------------------------------------------------------------------------------------------ errors
+void trs_set_error(const char* fmt, ...);
+
+#define TRS_REQUIRE(cond, ...)        \
+  do {                                \
+    if (!(cond)) {                    \
+      trs_set_error(__VA_ARGS__);     \
+      return TRS_E_ARG;               \
+    }                                 \
+  } while (0)
+
+#define TRS_CHECK_LAUNCH(name)                                             \
+  do {                                                                     \
+    hipError_t e__ = hipGetLastError();                                    \
+    if (e__ != hipSuccess) {                                               \
+      trs_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return TRS_E_LAUNCH;                                                 \
+    }                                                                      \
+  } while (0)
+
+// grid for a memory-bound grid-stride kernel: enough workgroups to fill 256 CUs x 8 blocks, no more.
+static inline int trs_grid(int64_t work_items, int items_per_block) {
+  int64_t g = (work_items + items_per_block - 1) / items_per_block;
+  if (g < 1) g = 1;
+  if (g > 256 * 8) g = 256 * 8;
+  return (int)g;
+}
+
+// ------------------------------------------------------------------------------------------ ids
+__device__ __forceinline__ int64_t trs_ld_idx(const void* p, int idx_bytes, int64_t t) {
+  return idx_bytes == 8 ? ((const int64_t*)p)[t] : (int64_t)((const int32_t*)p)[t];
+}
+__device__ __forceinline__ void trs_st_idx(void* p, int idx_bytes, int64_t t, int64_t v) {
+  if (idx_bytes == 8)
+    ((int64_t*)p)[t] = v;
+  else
+    ((int32_t*)p)[t] = (int32_t)v;
+}
+
+// ------------------------------------------------------------------------------------------ Philox4x32-10
+// Counter-based generator (Salmon et al., SC'11).  Restated bit-for-bit in oracle/philox.py.
+struct trs_u4 {
+  uint32_t x, y, z, w;
+};
+__host__ __device__ __forceinline__ trs_u4 trs_philox4x32_10(uint64_t counter, uint64_t key) {
+  uint32_t c0 = (uint32_t)counter, c1 = (uint32_t)(counter >> 32), c2 = 0u, c3 = 0u;
+  uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  trs_u4 o = {c0, c1, c2, c3};
+  return o;
+}
+
+// 64x64 -> high 64 bits
+__host__ __device__ __forceinline__ uint64_t trs_mulhi64(uint64_t a, uint64_t b) {
+#ifdef __HIP_DEVICE_COMPILE__
+  return __umul64hi(a, b);
+#else
+  return (uint64_t)(((unsigned __int128)a * (unsigned __int128)b) >> 64);
+#endif
+}
+
+// neg uniform over {0..n_items-1} \ {pos}: r uniform over n_items-1 values, shifted past pos.
+__host__ __device__ __forceinline__ int64_t trs_sample_one_neg(uint64_t seed, uint64_t ctr, int64_t pos,
+                                                               int64_t n_items) {
+  trs_u4 r = trs_philox4x32_10(ctr, seed);
+  uint64_t x = ((uint64_t)r.y << 32) | (uint64_t)r.x;
+  if (n_items <= 1) return 0;  // degenerate: the reference would loop forever (dataset/dataset.py:443)
+  int64_t v = (int64_t)trs_mulhi64(x, (uint64_t)(n_items - 1));
+  return v + (v >= pos ? 1 : 0);
+}
+
+// ------------------------------------------------------------------------------------------ Feistel shuffle
+// Keyed bijection of [0,N): 4-round balanced Feistel network on 2*hb bits (2*hb >= ceil(log2 N)), cycle-walked back
+// into range.  Restated in oracle/philox.py::feistel_perm.
+__host__ __device__ __forceinline__ uint32_t trs_mix32(uint32_t x, uint32_t k) {
+  x ^= k;
+  x *= 0x9E3779B1u;
+  x ^= x >> 15;
+  x *= 0x85EBCA77u;
+  x ^= x >> 13;
+  x *= 0xC2B2AE3Du;
+  x ^= x >> 16;
+  return x;
+}
+__host__ __device__ __forceinline__ int trs_feistel_half_bits(int64_t N) {
+  int bits = 1;
+  while (bits < 63 && ((int64_t)1 << bits) < N) ++bits;
+  return (bits + 1) / 2;
+}
+__host__ __device__ __forceinline__ int64_t trs_feistel_perm(int64_t q, int64_t N, uint64_t key, int hb) {
+  if (key == 0) return q;
+  const uint64_t mask = ((uint64_t)1 << hb) - 1;
+  uint64_t x = (uint64_t)q;
+  do {
+    uint32_t L = (uint32_t)(x >> hb), R = (uint32_t)(x & mask);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      uint32_t rk = (uint32_t)(key >> (16 * (r & 3))) ^ (uint32_t)(key >> 32) ^ (0xA511E9B3u * (uint32_t)(r + 1));
+      uint32_t F = trs_mix32(R, rk) & (uint32_t)mask;
+      uint32_t nL = R;
+      R = L ^ F;
+      L = nL;
+    }
+    x = ((uint64_t)L << hb) | (uint64_t)R;
+  } while (x >= (uint64_t)N);
+  return (int64_t)x;
+}
+
+// ------------------------------------------------------------------------------------------ reductions
+// sum over the G lanes of an aligned lane group (G power of two <= 64); every lane of the group gets the sum.
+template <int G>
+__device__ __forceinline__ float trs_group_sum(float v) {
+#pragma unroll
+  for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float trs_wave_sum(float v) { return trs_group_sum<64>(v); }
+__device__ __forceinline__ int trs_wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
