@@ -1,0 +1,274 @@
+# -*- coding: utf-8 -*-
+"""Kernel-level parity: libtrs_hip.so (through the C-ABI) against oracle/ on the same seeded inputs.  GPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import loader as oloader
+from oracle import nets as onets
+from oracle import optim as ooptim
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5  # north_star tolerance for fp32 scores / gradients (norm-wise relative, see conftest.rel_err)
+DEV = "cuda:0"
+
+
+def _ops():
+    from torchrecsys_amd import ops
+    return ops
+
+
+def make_case(net, D, M, B, NU=50, NI=37, seed=0, idx_dtype=np.int64):
+    rs = np.random.RandomState(seed)
+    sizes = [5, 7, 4, 9, 3, 6, 8, 2][:M]
+    p = {"user.weight": rs.normal(0, 0.3, (NU, D)), "item.weight": rs.normal(0, 0.3, (NI, D))}
+    if net == "linear":
+        p["user_bias.weight"] = rs.normal(0, 0.3, (NU, 1))
+        p["item_bias.weight"] = rs.normal(0, 0.3, (NI, 1))
+    else:
+        p["linear_user.weight"] = rs.normal(0, 0.3, (NU, 1))
+        p["linear_item.weight"] = rs.normal(0, 0.3, (NI, 1))
+    for m in range(M):
+        p[f"metadata.{m}.weight"] = rs.normal(0, 0.3, (sizes[m], D))
+        if net == "fm":
+            p[f"linear_metadata.{m}.weight"] = rs.normal(0, 0.3, (sizes[m], 1))
+    p = {k: v.astype(np.float32) for k, v in p.items()}
+    u, i, j = rs.randint(0, NU, B), rs.randint(0, NI, B), rs.randint(0, NI, B)
+    if B > 12:
+        u[1] = u[2] = u[3]
+        i[4] = j[5] = i[6]
+        j[7] = i[7]
+    batch = {"user_id": u, "pos_item_id": i, "neg_item_id": j}
+    if M:
+        item_meta = np.stack([rs.randint(0, sizes[m], NI) for m in range(M)], axis=1)
+        batch["pos_metadata_id"], batch["neg_metadata_id"] = item_meta[i], item_meta[j]
+    batch = {k: v.astype(np.int64) for k, v in batch.items()}
+    return p, batch, idx_dtype
+
+
+def to_dev(net, p, batch, idx_dtype):
+    ops = _ops()
+    t = {k: torch.from_numpy(v).to(DEV) for k, v in p.items()}
+    M = sum(1 for k in p if k.startswith("metadata."))
+    lin = ("user_bias.weight", "item_bias.weight") if net == "linear" else ("linear_user.weight", "linear_item.weight")
+    metas = [t[f"metadata.{m}.weight"] for m in range(M)]
+    meta_lins = [t[f"linear_metadata.{m}.weight"] for m in range(M)] if net == "fm" else []
+    T, keepT = ops.make_tables(t["user.weight"], t["item.weight"], t[lin[0]], t[lin[1]], metas, meta_lins)
+    tdt = torch.int32 if idx_dtype == np.int32 else torch.int64
+    ids = {k: torch.from_numpy(v).to(DEV).to(tdt).contiguous() for k, v in batch.items()}
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    Bt, keepB = ops.make_batch(ids["user_id"], ids["pos_item_id"], ids["neg_item_id"], ids.get("pos_metadata_id"),
+                               ids.get("neg_metadata_id"), err)
+    return t, T, Bt, ids, err, (keepT, keepB)
+
+
+def dense_from_staging(net, p, batch, grad_rows, grad_lin):
+    """Scatter the staged per-triple rows into dense-equivalent gradients (what p.grad.to_dense() is)."""
+    M = sum(1 for k in p if k.startswith("metadata."))
+    gr, gl = grad_rows.cpu().numpy().astype(np.float64), grad_lin.cpu().numpy().astype(np.float64)
+    out = {k: np.zeros(v.shape, np.float64) for k, v in p.items()}
+    lin = ("user_bias", "item_bias") if net == "linear" else ("linear_user", "linear_item")
+    fields = [("user", lin[0], batch["user_id"]), ("item", lin[1], batch["pos_item_id"]),
+              ("item", lin[1], batch["neg_item_id"])]
+    for m in range(M):
+        lm = f"linear_metadata.{m}" if net == "fm" else None
+        fields.append((f"metadata.{m}", lm, batch["pos_metadata_id"][:, m]))
+        fields.append((f"metadata.{m}", lm, batch["neg_metadata_id"][:, m]))
+    for f, (name, lname, idx) in enumerate(fields):
+        np.add.at(out[f"{name}.weight"], idx, gr[f])
+        if lname:
+            np.add.at(out[f"{lname}.weight"], idx, gl[f][:, None])
+    return out
+
+
+CASES = [("fm", 64, 0), ("fm", 8, 0), ("fm", 16, 1), ("fm", 128, 3), ("fm", 80, 0), ("fm", 10, 1), ("fm", 256, 0),
+         ("fm", 512, 1), ("fm", 4, 0), ("fm", 1, 0), ("fm", 100, 2), ("fm", 33, 0),
+         ("linear", 32, 0), ("linear", 8, 1), ("linear", 64, 3), ("linear", 80, 0), ("linear", 7, 2),
+         ("linear", 1024, 0)]
+
+
+@pytest.mark.parametrize("net,D,M", CASES)
+@pytest.mark.parametrize("idx_dtype", [np.int64, np.int32])
+def test_forward_and_fwd_bwd(net, D, M, idx_dtype):
+    ops = _ops()
+    B = 203
+    p, batch, _ = make_case(net, D, M, B, seed=D + M)
+    t, T, Bt, ids, err, keep = to_dev(net, p, batch, idx_dtype)
+    pos, neg = ops.score_forward(net, T, Bt, B, DEV)
+    sp, sn, loss, grads = onets.train_forward_backward(net, {k: v.copy() for k, v in p.items()}, batch)
+    assert rel_err(pos.cpu().numpy(), sp.reshape(-1)) < TOL
+    assert rel_err(neg.cpu().numpy(), sn.reshape(-1)) < TOL
+    loss_sum = torch.zeros(1, dtype=torch.float32, device=DEV)
+    auc = torch.zeros(1, dtype=torch.int32, device=DEV)
+    pos2, neg2, gr, gl = ops.score_fwd_bwd(net, T, Bt, B, D, M, DEV, loss_sum, auc)
+    torch.cuda.synchronize()
+    assert torch.equal(pos2, pos) and torch.equal(neg2, neg)
+    assert abs(loss_sum.item() / B - float(loss)) <= TOL * max(abs(float(loss)), 1e-3)
+    # counted on the kernel's own scores (saturated sigmoids tie at 1.0 and flip on the last bit)
+    assert auc.item() == int((pos > neg).sum().item())
+    dense = dense_from_staging(net, p, batch, gr, gl)
+    for k, v in grads.items():
+        assert rel_err(dense[k], v) < TOL, k
+    assert err.item() == 0
+    # backward from explicit upstream gradients == hinge path
+    gp, gn = ops.hinge_backward(pos, neg)
+    ogp, ogn = onets.hinge_grad(sp.reshape(-1), sn.reshape(-1))
+    assert np.array_equal(gp.cpu().numpy(), ogp) and np.array_equal(gn.cpu().numpy(), ogn)
+    gr2, gl2 = ops.score_backward(net, T, Bt, B, D, M, DEV, gp, gn)
+    assert torch.equal(gr2, gr) and torch.equal(gl2, gl)
+
+
+@pytest.mark.parametrize("net,D,M", [("fm", 64, 0), ("fm", 16, 2), ("linear", 32, 1), ("linear", 80, 0)])
+def test_sgd_update_three_steps(net, D, M):
+    ops = _ops()
+    B, lr = 300, 0.05
+    p, batch, _ = make_case(net, D, M, B, seed=3)
+    t, T, Bt, ids, err, keep = to_dev(net, p, batch, np.int64)
+    ref = {k: v.copy() for k, v in p.items()}
+    for step in range(3):
+        loss_sum = torch.zeros(1, dtype=torch.float32, device=DEV)
+        _, _, gr, gl = ops.score_fwd_bwd(net, T, Bt, B, D, M, DEV, loss_sum, want_scores=False)
+        ops.score_sgd_update(net, T, Bt, gr, gl, lr)
+        _, _, loss, grads = onets.train_forward_backward(net, ref, batch)
+        ooptim.sgd_step(ref, grads, lr)
+        assert abs(loss_sum.item() / B - float(loss)) <= TOL * max(abs(float(loss)), 1e-3)
+    for k, v in ref.items():
+        assert rel_err(t[k].cpu().numpy(), v) < TOL, k
+
+
+@pytest.mark.parametrize("D", [1, 16, 64, 80, 200])
+@pytest.mark.parametrize("kind", ["adam", "adagrad"])
+def test_coalescing_row_optimisers(D, kind):
+    ops = _ops()
+    rs = np.random.RandomState(D)
+    n_rows, n = 40, 150
+    W = rs.normal(0, 1, (n_rows, D)).astype(np.float32)
+    idx = rs.randint(0, n_rows // 2, n).astype(np.int64)  # rows >= n_rows/2 stay untouched
+    tW = torch.from_numpy(W.copy()).to(DEV)
+    acc = torch.zeros_like(tW)
+    s1 = torch.zeros_like(tW)
+    s2 = torch.zeros_like(tW)
+    stamp = torch.zeros(n_rows, dtype=torch.int32, device=DEV)
+    tidx = torch.from_numpy(idx).to(DEV)
+    ref, m, v = W.copy(), np.zeros_like(W), np.zeros_like(W)
+    for step in range(1, 4):
+        vals = rs.normal(0, 1, (n, D)).astype(np.float32)
+        vals[idx == 3] = 0.0  # a touched row with an all-zero gradient must still decay its moments
+        tv = torch.from_numpy(vals).to(DEV)
+        ops.rows_scatter_add(acc, tidx, tv, 1.0)
+        G = np.zeros_like(W)
+        np.add.at(G, idx, vals)
+        rows = np.unique(idx)
+        if kind == "adam":
+            ops.rows_apply_sparse_adam(tW, acc, s1, s2, stamp, tidx, step, 0.01, 0.9, 0.999, 1e-8, step)
+            ooptim.sparse_adam_rows(ref, G, rows, m, v, step, 0.01)
+        else:
+            ops.rows_apply_adagrad(tW, acc, s1, stamp, tidx, step, 0.05, 1e-10)
+            ooptim.adagrad_rows(ref, G, rows, m, step, 0.05)
+        torch.cuda.synchronize()
+        assert float(acc.abs().max()) == 0.0  # accumulator cleared by the owners
+    assert rel_err(tW.cpu().numpy(), ref) < 5e-5
+    assert np.array_equal(tW.cpu().numpy()[n_rows // 2:], W[n_rows // 2:])  # lazy: untouched rows bit-identical
+    assert rel_err(s1.cpu().numpy(), m) < 5e-5
+
+
+def test_out_of_range_ids_are_flagged_not_dereferenced():
+    ops = _ops()
+    p, batch, _ = make_case("fm", 16, 0, 64, seed=1)
+    batch["pos_item_id"][5] = 10_000_000
+    batch["user_id"][9] = -3
+    t, T, Bt, ids, err, keep = to_dev("fm", p, batch, np.int64)
+    pos, neg = ops.score_forward("fm", T, Bt, 64, DEV)
+    loss_sum = torch.zeros(1, dtype=torch.float32, device=DEV)
+    _, _, gr, gl = ops.score_fwd_bwd("fm", T, Bt, 64, 16, 0, DEV, loss_sum)
+    ops.score_sgd_update("fm", T, Bt, gr, gl, 0.1)
+    torch.cuda.synchronize()
+    assert err.item() == 1
+    assert pos[5].item() == 0.0 and pos[9].item() == 0.0
+    assert float(gr[:, 5].abs().max()) == 0.0 and float(gr[:, 9].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("idx_dtype", [torch.int64, torch.int32])
+def test_sample_neg_bit_exact(idx_dtype):
+    ops = _ops()
+    for n_items, B in ((2, 1000), (3, 1000), (100_000, 65_536), (7, 1)):
+        pos = np.random.RandomState(B).randint(0, n_items, B)
+        tpos = torch.from_numpy(pos).to(DEV).to(idx_dtype)
+        neg = ops.sample_neg(tpos, n_items, seed=0x1234_5678_9ABC, offset=77)
+        ref = oloader.device_negatives(pos, n_items, 0x1234_5678_9ABC, 77)
+        assert np.array_equal(neg.cpu().numpy().astype(np.int64), ref)
+        assert (ref != pos).all() and ref.min() >= 0 and ref.max() < n_items
+
+
+@pytest.mark.parametrize("M", [0, 2])
+@pytest.mark.parametrize("static", [False, True])
+def test_batch_prepare_bit_exact(M, static):
+    ops = _ops()
+    rs = np.random.RandomState(5)
+    N, NU, NI = 1000, 60, 41
+    su, si = rs.randint(0, NU, N).astype(np.int32), rs.randint(0, NI, N).astype(np.int32)
+    ns = rs.randint(0, NI, N).astype(np.int32) if static else None
+    im = np.stack([rs.randint(0, 5 + m, NI) for m in range(M)], axis=1).astype(np.int32) if M else None
+    d = lambda a: None if a is None else torch.from_numpy(a).to(DEV)
+    seen = []
+    for key in (0, 0xABCDEF0123):
+        for t0, B in ((0, 256), (256, 256), (768, 232)):
+            out = ops.batch_prepare(d(su), d(si), d(ns), key, t0, B, NI, 99, 1000 + t0, d(im))
+            ref = oloader.device_batch(su, si, ns, key, t0, B, NI, 99, 1000 + t0, im)
+            for k in ref:
+                assert np.array_equal(out[k].cpu().numpy().astype(np.int64), np.asarray(ref[k]).astype(np.int64)), k
+            if key:
+                seen.append(out["user"].cpu().numpy())
+    # identity key = shuffle=False: rows in stream order
+    out = ops.batch_prepare(d(su), d(si), d(ns), 0, 10, 20, NI, 1, 0, d(im))
+    assert np.array_equal(out["user"].cpu().numpy(), su[10:30])
+
+
+def test_hinge_auc():
+    ops = _ops()
+    rs = np.random.RandomState(0)
+    for B in (1, 63, 1000, 70_001):
+        pos, neg = rs.normal(0, 1, B).astype(np.float32), rs.normal(0, 1, B).astype(np.float32)
+        neg[::7] = pos[::7] + 1.0  # h == 2, and ties pos == neg - 1
+        ls = torch.zeros(1, dtype=torch.float32, device=DEV)
+        ac = torch.zeros(1, dtype=torch.int32, device=DEV)
+        ops.hinge_auc(torch.from_numpy(pos).to(DEV), torch.from_numpy(neg).to(DEV), ls, ac)
+        assert abs(ls.item() / B - float(onets.hinge_loss(pos, neg))) < 1e-5 * max(1.0, float(onets.hinge_loss(pos, neg)))
+        assert ac.item() == int((pos > neg).sum())
+
+
+@pytest.mark.parametrize("n,k", [(1, 1), (37, 10), (4096, 10), (4097, 5), (100_000, 10), (100_000, 2048),
+                                 (1_000_003, 100)])
+def test_topk_bit_exact(n, k):
+    ops = _ops()
+    rs = np.random.RandomState(n % 1000)
+    sc = rs.normal(0, 1, n).astype(np.float32)
+    if n > 100:
+        sc[rs.randint(0, n, 50)] = sc.max()  # ties at the top: index-ascending order must hold
+        sc[5] = -0.0
+        sc[6] = 0.0
+    out = ops.topk(torch.from_numpy(sc).to(DEV), k)
+    assert np.array_equal(out.cpu().numpy(), onets.topk(sc, k))
+
+
+@pytest.mark.parametrize("net,D,M", [("fm", 64, 0), ("fm", 16, 2), ("linear", 32, 0), ("linear", 8, 1)])
+def test_score_all_items(net, D, M):
+    ops = _ops()
+    NI = 777
+    p, batch, _ = make_case(net, D, M, 16, NU=20, NI=NI, seed=2)
+    sizes = [p[f"metadata.{m}.weight"].shape[0] for m in range(M)]
+    rs = np.random.RandomState(1)
+    im = np.stack([rs.randint(0, sizes[m], NI) for m in range(M)], axis=1).astype(np.int32) if M else None
+    t, T, Bt, ids, err, keep = to_dev(net, p, batch, np.int64)
+    tim = None if im is None else torch.from_numpy(im).to(DEV)
+    sc = ops.score_all_items(net, T, 3, NI, DEV, tim)
+    items = np.arange(NI)
+    fwd = onets.fm_forward if net == "fm" else onets.linear_forward
+    ref = fwd(p, np.full(NI, 3), items, None if im is None else im.astype(np.int64)).reshape(-1)
+    assert rel_err(sc.cpu().numpy(), ref) < TOL
+    # chunked == unchunked (reference tests/test_model_and_features.py:203-215)
+    parts = [ops.score_all_items(net, T, 3, NI, DEV, tim, item0=a, n=min(100, NI - a)) for a in range(0, NI, 100)]
+    assert torch.equal(torch.cat(parts), sc)
+    assert np.array_equal(ops.topk(sc, 10).cpu().numpy(), onets.topk(ref, 10)) or rel_err(sc.cpu().numpy(), ref) > 0

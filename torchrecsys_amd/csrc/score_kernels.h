@@ -274,11 +274,10 @@ __global__ __launch_bounds__(TRS_BLOCK) void score_kernel(const ScoreArgs a) {
           gl[0 * B + t] = gp + gn;
           gl[1 * B + t] = gp;
           gl[2 * B + t] = gn;
-          if (NET == TRS_NET_FM)
-            for (int m = 0; m < M; ++m) {
-              gl[(int64_t)(3 + 2 * m) * B + t] = gp;
-              gl[(int64_t)(4 + 2 * m) * B + t] = gn;
-            }
+          for (int m = 0; m < M; ++m) {  // Linear has no 1-wide metadata tables: those fields stay 0
+            gl[(int64_t)(3 + 2 * m) * B + t] = NET == TRS_NET_FM ? gp : 0.f;
+            gl[(int64_t)(4 + 2 * m) * B + t] = NET == TRS_NET_FM ? gn : 0.f;
+          }
         }
       }
     }

@@ -1,0 +1,197 @@
+# -*- coding: utf-8 -*-
+"""Thin torch-tensor front of the C-ABI (include/trs.h).  Every function enqueues HIP kernels of libtrs_hip.so on
+torch's current stream; torch only owns the memory.  No CPU path: tensors must live on the GPU."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import TRS_MAX_META, TRS_NET_FM, TRS_NET_LINEAR, TrsBatch, TrsTables, check, ptr
+
+NET_ID = {"linear": TRS_NET_LINEAR, "fm": TRS_NET_FM}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t, name, dtype=None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a GPU tensor: torchrecsys_amd computes on the MI355X only "
+                           f"(no CPU fallback); got device {t.device}")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t
+
+
+def make_tables(user, item, user_lin=None, item_lin=None, metas=(), meta_lins=()):
+    """Build a trs_tables struct from fp32 GPU tensors.  Returns (struct, keepalive list)."""
+    T = TrsTables()
+    keep = [user, item, user_lin, item_lin, list(metas), list(meta_lins)]
+    _dev(user, "user table", torch.float32)
+    _dev(item, "item table", torch.float32)
+    if user.dim() != 2 or item.dim() != 2 or user.shape[1] != item.shape[1]:
+        raise ValueError("user/item tables must be (n, D) with the same D")
+    M = len(metas)
+    if M > TRS_MAX_META:
+        raise ValueError(f"at most {TRS_MAX_META} metadata columns are supported, got {M}")
+    T.user, T.item = ptr(user), ptr(item)
+    T.user_lin = ptr(_dev(user_lin, "user 1-wide table", torch.float32))
+    T.item_lin = ptr(_dev(item_lin, "item 1-wide table", torch.float32))
+    T.n_users, T.n_items = user.shape[0], item.shape[0]
+    T.D, T.M = user.shape[1], M
+    for m in range(M):
+        _dev(metas[m], f"metadata table {m}", torch.float32)
+        if metas[m].shape[1] != user.shape[1]:
+            raise ValueError("metadata tables must have the same D as user/item")
+        T.meta[m] = ptr(metas[m])
+        T.n_meta[m] = metas[m].shape[0]
+        if meta_lins:
+            T.meta_lin[m] = ptr(_dev(meta_lins[m], f"metadata 1-wide table {m}", torch.float32))
+    return T, keep
+
+
+def make_batch(user, pos, neg=None, pos_meta=None, neg_meta=None, err_flag=None):
+    """Build a trs_batch struct from int32/int64 GPU id tensors (all the same dtype)."""
+    Bt = TrsBatch()
+    ids = [t for t in (user, pos, neg, pos_meta, neg_meta) if t is not None]
+    dt = user.dtype
+    if dt not in (torch.int32, torch.int64):
+        raise TypeError(f"ids must be int32 or int64, got {dt}")
+    for t in ids:
+        _dev(t, "id tensor", dt)
+    B = user.shape[0]
+    if pos.shape[0] != B or (neg is not None and neg.shape[0] != B):
+        raise ValueError("user/pos/neg id tensors must have the same length")
+    Bt.user, Bt.pos, Bt.neg = ptr(user), ptr(pos), ptr(neg)
+    Bt.pos_meta, Bt.neg_meta = ptr(pos_meta), ptr(neg_meta)
+    Bt.B = B
+    Bt.idx_bytes = 4 if dt == torch.int32 else 8
+    Bt.err_flag_dev = ptr(err_flag)
+    return Bt, ids + [err_flag]
+
+
+def score_forward(net, T, Bt, B, device, want_neg=True):
+    lib = _lib.load()
+    pos = torch.empty(B, dtype=torch.float32, device=device)
+    neg = torch.empty(B, dtype=torch.float32, device=device) if want_neg else None
+    check(lib.trs_score_forward(NET_ID[net], C.byref(T), C.byref(Bt), ptr(pos), ptr(neg), _stream()),
+          "trs_score_forward")
+    return pos, neg
+
+
+def score_fwd_bwd(net, T, Bt, B, D, M, device, loss_sum, auc_count=None, want_scores=True, grad_rows=None,
+                  grad_lin=None):
+    """Returns (pos, neg, grad_rows (R,B,D), grad_lin (R,B)); loss_sum/auc_count are accumulated in place."""
+    lib = _lib.load()
+    R = 3 + 2 * M
+    pos = torch.empty(B, dtype=torch.float32, device=device) if want_scores else None
+    neg = torch.empty(B, dtype=torch.float32, device=device) if want_scores else None
+    if grad_rows is None:
+        grad_rows = torch.empty((R, B, D), dtype=torch.float32, device=device)
+    if grad_lin is None:
+        grad_lin = torch.empty((R, B), dtype=torch.float32, device=device)
+    inv_B = 1.0 / B if B > 0 else 0.0
+    check(lib.trs_score_fwd_bwd(NET_ID[net], C.byref(T), C.byref(Bt), inv_B, ptr(pos), ptr(neg), ptr(loss_sum),
+                                ptr(auc_count), ptr(grad_rows), ptr(grad_lin), _stream()), "trs_score_fwd_bwd")
+    return pos, neg, grad_rows, grad_lin
+
+
+def score_backward(net, T, Bt, B, D, M, device, gpos, gneg):
+    lib = _lib.load()
+    R = 3 + 2 * M
+    grad_rows = torch.empty((R, B, D), dtype=torch.float32, device=device)
+    grad_lin = torch.empty((R, B), dtype=torch.float32, device=device)
+    check(lib.trs_score_backward(NET_ID[net], C.byref(T), C.byref(Bt), ptr(gpos), ptr(gneg), ptr(grad_rows),
+                                 ptr(grad_lin), _stream()), "trs_score_backward")
+    return grad_rows, grad_lin
+
+
+def score_sgd_update(net, T, Bt, grad_rows, grad_lin, lr):
+    check(_lib.load().trs_score_sgd_update(NET_ID[net], C.byref(T), C.byref(Bt), ptr(grad_rows), ptr(grad_lin),
+                                           float(lr), _stream()), "trs_score_sgd_update")
+
+
+def rows_scatter_add(table, idx, vals, alpha, ld=None, err_flag=None):
+    n_rows, D = table.shape
+    n = idx.shape[0]
+    ld = vals.stride(0) if ld is None else ld
+    check(_lib.load().trs_rows_scatter_add(ptr(table), n_rows, D, ptr(idx), 4 if idx.dtype == torch.int32 else 8,
+                                           ptr(vals), ld, n, float(alpha), ptr(err_flag), _stream()),
+          "trs_rows_scatter_add")
+
+
+def rows_apply_sparse_adam(table, acc, exp_avg, exp_avg_sq, stamp, idx, step_id, lr, beta1, beta2, eps, step_count):
+    n_rows, D = table.shape
+    check(_lib.load().trs_rows_apply_sparse_adam(ptr(table), ptr(acc), ptr(exp_avg), ptr(exp_avg_sq), ptr(stamp),
+                                                 n_rows, D, ptr(idx), 4 if idx.dtype == torch.int32 else 8,
+                                                 idx.shape[0], int(step_id), float(lr), float(beta1), float(beta2),
+                                                 float(eps), int(step_count), _stream()),
+          "trs_rows_apply_sparse_adam")
+
+
+def rows_apply_adagrad(table, acc, state_sum, stamp, idx, step_id, clr, eps):
+    n_rows, D = table.shape
+    check(_lib.load().trs_rows_apply_adagrad(ptr(table), ptr(acc), ptr(state_sum), ptr(stamp), n_rows, D, ptr(idx),
+                                             4 if idx.dtype == torch.int32 else 8, idx.shape[0], int(step_id),
+                                             float(clr), float(eps), _stream()), "trs_rows_apply_adagrad")
+
+
+def hinge_auc(pos, neg, loss_sum, auc_count):
+    check(_lib.load().trs_hinge_auc(ptr(pos), ptr(neg), pos.numel(), ptr(loss_sum), ptr(auc_count), _stream()),
+          "trs_hinge_auc")
+
+
+def hinge_backward(pos, neg):
+    B = pos.numel()
+    gp, gn = torch.empty_like(pos), torch.empty_like(neg)
+    check(_lib.load().trs_hinge_backward(ptr(pos), ptr(neg), B, 1.0 / B if B else 0.0, ptr(gp), ptr(gn), _stream()),
+          "trs_hinge_backward")
+    return gp, gn
+
+
+def sample_neg(pos, n_items, seed, offset):
+    neg = torch.empty_like(pos)
+    check(_lib.load().trs_sample_neg(ptr(pos), 4 if pos.dtype == torch.int32 else 8, pos.numel(), int(n_items),
+                                     int(seed), int(offset), ptr(neg), _stream()), "trs_sample_neg")
+    return neg
+
+
+def batch_prepare(stream_user, stream_item, neg_static, shuffle_key, t0, B, n_items, seed, offset, item_meta=None,
+                  out=None):
+    """Returns dict of int32 GPU tensors user/pos/neg[/pos_meta/neg_meta] for epoch positions [t0, t0+B)."""
+    dev = stream_user.device
+    M = 0 if item_meta is None else item_meta.shape[1]
+    if out is None:
+        out = {k: torch.empty(B, dtype=torch.int32, device=dev) for k in ("user", "pos", "neg")}
+        if M:
+            out["pos_meta"] = torch.empty((B, M), dtype=torch.int32, device=dev)
+            out["neg_meta"] = torch.empty((B, M), dtype=torch.int32, device=dev)
+    check(_lib.load().trs_batch_prepare(ptr(stream_user), ptr(stream_item), ptr(neg_static), stream_user.numel(),
+                                        int(shuffle_key), int(t0), int(B), int(n_items), int(seed), int(offset),
+                                        ptr(item_meta), M, ptr(out["user"]), ptr(out["pos"]), ptr(out["neg"]),
+                                        ptr(out.get("pos_meta")), ptr(out.get("neg_meta")), _stream()),
+          "trs_batch_prepare")
+    return out
+
+
+def score_all_items(net, T, user_id, n_items, device, item_meta=None, item0=0, n=None):
+    n = n_items - item0 if n is None else n
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    check(_lib.load().trs_score_all_items(NET_ID[net], C.byref(T), int(user_id), int(item0), int(n), ptr(item_meta),
+                                          ptr(out), _stream()), "trs_score_all_items")
+    return out
+
+
+def topk(scores, k):
+    lib = _lib.load()
+    n = scores.numel()
+    ws_bytes = lib.trs_topk_workspace_bytes(n, k)
+    ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=scores.device)
+    out = torch.empty(k, dtype=torch.int64, device=scores.device)
+    check(lib.trs_topk(ptr(scores), n, k, ptr(out), ptr(ws), ws_bytes, _stream()), "trs_topk")
+    return out
