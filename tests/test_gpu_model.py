@@ -1,0 +1,205 @@
+# -*- coding: utf-8 -*-
+"""API-level parity on the GPU: torchrecsys_amd.TorchRecSys / nets / engine against golden vectors recorded from the
+real reference (tests/golden/make_golden.py).  GPU only."""
+import contextlib
+import io
+import re
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from conftest import load_golden, rel_err, sub
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+DEV = "cuda:0"
+META_SIZES = [5, 7, 4]
+
+
+def seed(s):
+    np.random.seed(s)
+    torch.manual_seed(s)
+
+
+def build_net(name, M, g, prefix="init"):
+    """Our module with the reference's initial weights loaded through state_dict (same parameter names)."""
+    from torchrecsys_amd.collaborative.fm import FM
+    from torchrecsys_amd.collaborative.linear import Linear
+    net_type = name.split("_")[0]
+    n_meta = {f"m{m}": META_SIZES[m] for m in range(M)}
+    kw = {}
+    if net_type == "mlp":
+        from torchrecsys_amd.collaborative.mlp import MLP
+        cls = MLP
+        kw = {"hidden_layers": [32, 16], "use_batch_norm": name == "mlp"}
+    else:
+        cls = {"linear": Linear, "fm": FM}[net_type]
+    net = cls(n_users=40, n_items=30, n_metadata=n_meta, n_factors=8, use_metadata=M > 0, **kw)
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in sub(g, prefix).items()}
+    net.load_state_dict(sd)
+    return net.to(DEV)
+
+
+def golden_batch(g):
+    b = {k: torch.from_numpy(v).long() for k, v in sub(g, "batch").items()}
+    for k in ("pos_metadata_id", "neg_metadata_id"):
+        if k in b and b[k].dim() == 1:
+            b[k] = b[k].reshape(-1, 1)
+    return b
+
+
+def dev_ids(net, b):
+    ids = {"user": b["user_id"], "pos": b["pos_item_id"], "neg": b["neg_item_id"]}
+    if "pos_metadata_id" in b:
+        ids["pos_meta"], ids["neg_meta"] = b["pos_metadata_id"], b["neg_metadata_id"]
+    return {k: v.to(DEV).contiguous() for k, v in ids.items()}
+
+
+SPARSE_NETS = ["linear", "fm"]
+
+
+@pytest.mark.parametrize("name", SPARSE_NETS)
+@pytest.mark.parametrize("M", [0, 1, 3])
+def test_g1_autograd_bridge(name, M):
+    """net.forward x2 + hinge_loss + loss.backward() through the HIP autograd Functions == reference autograd."""
+    from torchrecsys_amd.helper.loss import hinge_loss
+    from torchrecsys_amd.evaluate.metrics import Metrics
+    g = load_golden(f"g1_{name}_M{M}.npz")
+    net, b = build_net(name, M, g), golden_batch(g)
+    mk = ("pos_metadata_id", "neg_metadata_id") if M else (None, None)
+    pos = net.forward(b, "user_id", "pos_item_id", mk[0])
+    neg = net.forward(b, "user_id", "neg_item_id", mk[1])
+    assert pos.shape == g["pos"].shape and neg.shape == g["neg"].shape
+    loss = hinge_loss(pos, neg)
+    loss.backward()
+    assert rel_err(pos.detach().cpu().numpy(), g["pos"]) < TOL
+    assert rel_err(neg.detach().cpu().numpy(), g["neg"]) < TOL
+    assert abs(loss.item() - float(g["loss"])) <= TOL * abs(float(g["loss"]))
+    assert float(Metrics().auc_score(pos, neg).item()) == pytest.approx(float(g["auc"]), abs=1e-6)
+    ref = sub(g, "grad")
+    for k, p in net.named_parameters():
+        assert p.grad is not None and p.grad.is_sparse, k
+        assert rel_err(p.grad.to_dense().cpu().numpy(), ref[k]) < TOL, k
+    # fused pair forward gives the same scores
+    p2, n2 = net.forward_pair(b)
+    assert torch.equal(p2, pos.detach()) and torch.equal(n2, neg.detach())  # both passes run the same code: bitwise
+
+
+@pytest.mark.parametrize("name", SPARSE_NETS)
+@pytest.mark.parametrize("M", [0, 1, 3])
+@pytest.mark.parametrize("oname", ["sgd", "sgdm", "adagrad", "sparseadam"])
+def test_g2_engine_optimizer_trajectories(name, M, oname):
+    """Three fused training steps honouring a user-built torch optimiser == the reference's trajectories."""
+    from torchrecsys_amd.engine import SparseScorerTrainer
+    g = load_golden(f"g2_{name}_M{M}_{oname}.npz")
+    net, b = build_net(name, M, g), golden_batch(g)
+    ps = list(net.parameters())
+    opt = {"sgd": lambda: torch.optim.SGD(ps, lr=0.05), "sgdm": lambda: torch.optim.SGD(ps, lr=0.05, momentum=0.9),
+           "adagrad": lambda: torch.optim.Adagrad(ps, lr=0.05),
+           "sparseadam": lambda: torch.optim.SparseAdam(ps, lr=0.01)}[oname]()
+    tr = SparseScorerTrainer(net, opt, 64)
+    assert tr.kind == {"sgd": "sgd", "sgdm": "generic", "adagrad": "adagrad", "sparseadam": "sparse_adam"}[oname]
+    ids = dev_ids(net, b)
+    losses = torch.zeros(3, dtype=torch.float32, device=DEV)
+    for t in range(3):
+        tr.step(ids, losses[t:t + 1])
+        ref = sub(g, f"step{t}")
+        sd = net.state_dict()
+        for k, v in ref.items():
+            assert rel_err(sd[k].cpu().numpy(), v) < 5 * TOL, (k, t)
+    tr.check_errors()
+    assert np.allclose(losses.cpu().numpy() / 64, g["losses"], rtol=2e-5, atol=1e-7)
+    if oname == "sparseadam":  # optimizer.state stays truthful
+        st = opt.state[net.user.weight]
+        assert st["step"] == 3 and st["exp_avg"].shape == net.user.weight.shape
+
+
+@pytest.mark.parametrize("name", SPARSE_NETS)
+def test_generic_backward_path_with_any_optimizer(name):
+    """TorchRecSys.forward + hinge_loss + TorchRecSys.backward (reference model.py:171-200) with SparseAdam."""
+    from torchrecsys_amd.helper.loss import hinge_loss
+    from torchrecsys_amd.model import TorchRecSys
+    g = load_golden(f"g2_{name}_M1_sparseadam.npz")
+    net, b = build_net(name, 1, g), golden_batch(g)
+    opt = torch.optim.SparseAdam(list(net.parameters()), lr=0.01)
+    for t in range(3):
+        pos, neg = TorchRecSys.forward(None, net, b)
+        loss = hinge_loss(pos, neg)
+        val = TorchRecSys.backward(None, loss, opt)
+        assert abs(val - float(g["losses"][t])) <= 2e-5 * max(abs(float(g["losses"][t])), 1e-3)
+        for k, v in sub(g, f"step{t}").items():
+            assert rel_err(net.state_dict()[k].cpu().numpy(), v) < 5 * TOL, (k, t)
+
+
+def run_model(net_type, dyn, g, rng="reference", **kw):
+    from torchrecsys_amd.model import TorchRecSys
+    df = pd.DataFrame({"user": g["df_user"], "item": g["df_item"]})
+    seed(7)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        model = TorchRecSys(dataset=df, user_id_col="user", item_id_col="item", n_factors=16, net_type=net_type,
+                            dynamic_neg_sampling=dyn, rng=rng, **kw)
+        init = {k: v.cpu().numpy().copy() for k, v in model.state_dict().items()}
+        opt = torch.optim.SGD(model.parameters(), lr=0.05)
+        model.fit(optimizer=opt, epochs=2, batch_size=256)
+        final = {k: v.cpu().numpy().copy() for k, v in model.state_dict().items()}
+        if not dyn:
+            model.evaluate(batch_size=256)
+        top = model.predict(user_id=3, top_k=10, prediction_batch_size=37)
+    return model, init, final, top, buf.getvalue()
+
+
+@pytest.mark.parametrize("net_type", SPARSE_NETS)
+@pytest.mark.parametrize("dyn", [False, True])
+def test_g4_end_to_end_fit_evaluate_predict(net_type, dyn):
+    g = load_golden(f"g4_{net_type}_{'dyn' if dyn else 'static'}.npz")
+    model, init, final, top, txt = run_model(net_type, dyn, g)
+    for k, v in sub(g, "init").items():  # seeded construction: bit-identical initial weights
+        assert np.array_equal(init[k], v), k
+    losses = [float(x) for x in re.findall(r"Training Loss: ([0-9.]+)", txt)]
+    assert losses == pytest.approx(list(g["epoch_losses"]), abs=1.01e-4)  # printed with 4 decimals
+    for k, v in sub(g, "final").items():
+        assert rel_err(final[k], v) < 2e-5, k  # 78 SGD steps of accumulated fp32 rounding
+    assert isinstance(top, torch.Tensor) and top.dtype == torch.int64 and top.device.type == "cpu"
+    assert np.array_equal(top.numpy(), g["top10_user3"])  # bit-exact top-k (tie-free fixture)
+    if not dyn:
+        assert float(re.findall(r"Testing loss: ([0-9.]+)", txt)[0]) == pytest.approx(float(g["eval_loss"]), abs=1.01e-4)
+        assert float(re.findall(r"Testing auc: ([0-9.]+)", txt)[0]) == pytest.approx(float(g["eval_auc"]), abs=1.01e-4)
+    # same banner / line formats as the reference
+    ref_lines = [l for l in str(g["stdout"]).splitlines() if l.strip()]
+    got_lines = [l for l in txt.splitlines() if l.strip()]
+    assert [re.sub(r"[0-9.]+$", "", l) for l in got_lines] == [re.sub(r"[0-9.]+$", "", l) for l in ref_lines]
+
+
+@pytest.mark.parametrize("net_type", SPARSE_NETS)
+def test_device_rng_mode_trains(net_type):
+    """rng='device': on-GPU shuffle + sampler; not the reference's stream, but it must learn the same problem."""
+    g = load_golden(f"g4_{net_type}_dyn.npz")
+    model, init, final, top, txt = run_model(net_type, True, g, rng="device", seed=3)
+    losses = [float(x) for x in re.findall(r"Training Loss: ([0-9.]+)", txt)]
+    assert len(losses) == 2 and abs(losses[0] - g["epoch_losses"][0]) < 0.02 and losses[1] <= losses[0] + 1e-3
+    assert top.shape == (10,) and len(set(top.tolist())) == 10 and max(top.tolist()) < 100
+
+
+def test_reference_api_invariants():
+    """The structural invariants the reference's own tests assert (tests/test_model_and_features.py)."""
+    from torchrecsys_amd.dataset.dataset import FastDataLoader, ProcessData
+    from torchrecsys_amd.model import TorchRecSys
+    rs = np.random.RandomState(0)
+    n_u, n_i, n = 100, 50, 1000
+    df = pd.DataFrame({"user_id": np.concatenate([np.arange(n_u), rs.randint(0, n_u, n - n_u)]),
+                       "item_id": np.concatenate([np.arange(n_i), rs.randint(0, n_i, n - n_i)])})
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = TorchRecSys(df, "user_id", "item_id", n_factors=16, net_type="linear")
+        # test_batched_prediction / _consistency (:189-215)
+        a = model.predict(user_id=0, top_k=5, prediction_batch_size=7)
+        b = model.predict(user_id=0, top_k=5, prediction_batch_size=n_i + 1)
+    assert a.shape == (5,) and (a < n_i).all() and torch.equal(a, b)
+    with pytest.raises(IndexError):
+        model.predict(user_id=n_u + 5)
+    # ids outside the tables raise IndexError like aten::embedding does
+    bad = {"user_id": torch.tensor([0, n_u + 3]), "pos_item_id": torch.tensor([1, 2])}
+    with pytest.raises(IndexError):
+        model.net.forward(bad, "user_id", "pos_item_id")

@@ -1,0 +1,230 @@
+# -*- coding: utf-8 -*-
+"""Data pipeline of the path (reference dataset/dataset.py): DataFrame -> id tensors, train/test split, static
+negatives, and the batch iterator with the dynamic negative sampler.
+
+Index streams are in the bit-exact parity class: the same global RNG streams are consumed in the same order as the
+reference (numpy legacy `np.random` for negatives, RandomState(42) for the split, torch's CPU generator for the
+shuffle), so a seeded run yields the very same batches.  The per-row Python sampler loop of the reference
+(dataset.py:435-447) is replaced by a vectorised walk over the same stream.
+"""
+import ast
+import json
+import math
+from typing import List
+
+import numpy as np
+import pandas as pd
+import torch
+
+
+def _scalar_meta(x):
+    """One categorical id per row: ints, 1-element lists, or their string encodings ('3', '[3]')."""
+    if isinstance(x, str):
+        x = ast.literal_eval(x)
+    if isinstance(x, (list, tuple, np.ndarray)):
+        if len(x) != 1:
+            raise NotImplementedError(
+                "multi-valued metadata lists are not supported: the scorers index one embedding row per metadata "
+                "column ((B, M) id contract, reference collaborative/linear.py:72-75); pass one categorical id per row")
+        x = x[0]
+    return int(x)
+
+
+class Data:
+    """reference dataset/dataset.py:15-118."""
+
+    def __init__(self, dataset: pd.DataFrame, user_id_col: str, item_id_col: str, metadata_id_col: List[str] = None,
+                 split_ratio: float = 0.8, dynamic_neg_sampling: bool = False):
+        self.dataset = dataset
+        self.user_id = user_id_col
+        self.item_id = item_id_col
+        self._users = np.asarray(dataset[user_id_col].values)
+        self._items = np.asarray(dataset[item_id_col].values)
+        self.num_items = len(np.unique(self._items))   # dataset.py:30
+        self.num_users = len(np.unique(self._users))   # dataset.py:31
+        self.dynamic_neg_sampling = dynamic_neg_sampling
+        self._neg_items = None
+        if not self.dynamic_neg_sampling:
+            self._neg_items = self._get_negative_items()
+        self.split_ratio = split_ratio
+        if metadata_id_col:
+            self.metadata_id = list(metadata_id_col)
+            self._meta = np.stack([np.asarray([_scalar_meta(v) for v in dataset[c].values], dtype=np.int64)
+                                   for c in self.metadata_id], axis=1)
+            self.negative_metadata_id = self._get_negative_metadata_column_names()
+            self.metadata_size = {c: len(np.unique(self._meta[:, k])) for k, c in enumerate(self.metadata_id)}
+
+    def _get_negative_items(self):
+        """Static negatives: ONE np.random.randint(0, num_items, size=N) from the global legacy stream, no rejection of
+        neg == pos, drawn before the split (dataset.py:56-64).  The caller's DataFrame is not mutated."""
+        return np.random.randint(low=0, high=self.num_items, size=len(self._items))
+
+    def _get_negative_metadata_column_names(self):
+        return ["neg_" + c for c in self.metadata_id]
+
+
+class ProcessData(Data):
+    """reference dataset/dataset.py:121-316.  `train_data` / `test_data` are dicts of int64 CPU tensors with keys
+    user_id, pos_item_id[, neg_item_id][, pos_metadata_id (N,M)][, neg_metadata_id (N,M)]."""
+
+    def __init__(self, dataset: pd.DataFrame, user_id_col: str, item_id_col: str, metadata_id_col: List[str] = None,
+                 split_ratio: float = 0.9, dynamic_neg_sampling: bool = False):
+        super().__init__(dataset, user_id_col, item_id_col, metadata_id_col, split_ratio, dynamic_neg_sampling)
+        self.user_id_col = user_id_col
+        self.item_id_col = item_id_col
+        if metadata_id_col:
+            self.metadata_id_col = list(metadata_id_col)
+
+    def prepare_data(self):
+        N = len(self._users)
+        has_meta = hasattr(self, "metadata_id_col") and bool(self.metadata_id_col)
+        self.config = {"num_users": self.num_users, "num_items": self.num_items,
+                       "num_metadata": self.metadata_size if has_meta else {}}
+        for name, ids, n in (("user", self._users, self.num_users), ("item", self._items, self.num_items)):
+            if N and (ids.min() < 0 or ids.max() >= n):
+                raise IndexError(f"{name} ids must be dense 0..{n - 1} (the tables are sized by the number of unique "
+                                 f"ids, dataset.py:30-31, and indexed by the raw values, :268-269); found "
+                                 f"[{ids.min()}, {ids.max()}]")
+        self.item_to_metadata_map = None
+        self.item_meta_table = None
+        self.meta_data_df = None
+        if has_meta:
+            # item -> its metadata ids (first occurrence wins), the device-friendly form of item_to_metadata_map
+            table = np.zeros((self.num_items, len(self.metadata_id_col)), dtype=np.int64)
+            first = np.unique(self._items, return_index=True)[1]
+            table[self._items[first]] = self._meta[first]
+            self.item_meta_table = table
+            self.meta_data_df = pd.DataFrame({"pos_item_id": np.arange(self.num_items),
+                                              **{c: table[:, k] for k, c in enumerate(self.metadata_id_col)}})
+            self.item_to_metadata_map = {int(i): {c: [int(table[i, k])] for k, c in enumerate(self.metadata_id_col)}
+                                         for i in range(self.num_items)}
+        # split: sklearn.train_test_split(test_size=1-split_ratio, random_state=42) restated (dataset.py:239-240)
+        if self.split_ratio < 1:
+            n_test = int(math.ceil((1 - self.split_ratio) * N))
+            perm = np.random.RandomState(42).permutation(N)
+            tr, te = perm[n_test:], perm[:n_test]
+        else:
+            tr, te = np.arange(N), np.arange(0)
+        self.train_data = self._rows_to_tensor_dict(tr, has_meta)
+        self.test_data = self._rows_to_tensor_dict(te, has_meta)
+
+    def _rows_to_tensor_dict(self, rows, has_meta):
+        d = {"user_id": torch.from_numpy(self._users[rows]).long(),
+             "pos_item_id": torch.from_numpy(self._items[rows]).long()}
+        if not self.dynamic_neg_sampling:
+            d["neg_item_id"] = torch.from_numpy(self._neg_items[rows]).long()
+        if has_meta:
+            d["pos_metadata_id"] = torch.from_numpy(self._meta[rows]).long()
+            if not self.dynamic_neg_sampling:
+                d["neg_metadata_id"] = torch.from_numpy(self.item_meta_table[self._neg_items[rows]]).long()
+        return d
+
+    def write_data(self, path: str):
+        with open(f"{path}/config.json", "w") as file:
+            json.dump(self.config, file)
+        if self.meta_data_df is not None:
+            self.meta_data_df.to_csv(f"{path}/meta.csv", index=False)
+
+
+def sample_negatives_reference_stream(pos_item_ids: np.ndarray, n_items: int) -> np.ndarray:
+    """The dynamic sampler of dataset.py:435-447 as a vectorised walk over the SAME global legacy numpy stream: row k
+    takes the next stream value that differs from its own positive.  Scalar `np.random.randint(0, n)` calls consume the
+    stream exactly like `randint(0, n, size=k)`, so the output and the number of draws equal the reference's."""
+    pos = np.asarray(pos_item_ids, dtype=np.int64)
+    B = pos.size
+    out = np.empty(B, dtype=np.int64)
+    k = 0
+    while k < B:
+        draws = np.random.randint(0, n_items, size=B - k)
+        # without collisions row k+i takes draws[i]; the first collision shifts everything behind it by one
+        start = 0
+        while start < draws.size and k < B:
+            m = min(draws.size - start, B - k)
+            hit = np.nonzero(draws[start:start + m] == pos[k:k + m])[0]
+            if hit.size == 0:
+                out[k:k + m] = draws[start:start + m]
+                k += m
+                start += m
+            else:
+                h = int(hit[0])
+                out[k:k + h] = draws[start:start + h]
+                k += h
+                start += h + 1  # the colliding draw is consumed, its row is not finished
+    return out
+
+
+class FastDataLoader:
+    """Batch iterator of the reference (dataset/dataset.py:319-458): randperm shuffle (once in the constructor, once
+    per __iter__), contiguous slices, last batch partial, optional dynamic negatives."""
+
+    def __init__(self, data: dict, batch_size: int = 32, shuffle: bool = False, dynamic_neg_sampling: bool = False,
+                 n_items: int = None, item_to_metadata_map=None, metadata_id_cols: List[str] = None):
+        self.data = data
+        self.batch_size = batch_size
+        self.shuffle = shuffle
+        self.dynamic_neg_sampling = dynamic_neg_sampling
+        self.n_items = n_items
+        self.item_to_metadata_map = item_to_metadata_map
+        self.metadata_id_cols = metadata_id_cols
+        if self.dynamic_neg_sampling and self.n_items is None:
+            raise ValueError("n_items must be provided for dynamic negative sampling.")
+        if self.dynamic_neg_sampling and self.metadata_id_cols and self.item_to_metadata_map is None:
+            raise ValueError("item_to_metadata_map must be provided for dynamic negative sampling with metadata.")
+        self._meta_table = self._as_meta_table(item_to_metadata_map, metadata_id_cols)
+        self.dataset_len = 0
+        if "user_id" in self.data and isinstance(self.data["user_id"], torch.Tensor):
+            self.dataset_len = self.data["user_id"].shape[0]
+        if self.shuffle and self.dataset_len > 0:
+            self.shuffle_indices()
+        self.num_batches = int(np.ceil(self.dataset_len / self.batch_size)) if self.dataset_len > 0 else 0
+
+    def _as_meta_table(self, mapping, cols):
+        """(n_items, M) int64 lookup from either an array/tensor or the reference's {item: {col: [id]}} dict."""
+        if mapping is None or not cols:
+            return None
+        if isinstance(mapping, dict):
+            n = max(mapping.keys()) + 1 if mapping else 0
+            n = max(n, self.n_items or 0)
+            table = np.zeros((n, len(cols)), dtype=np.int64)
+            for item, meta in mapping.items():
+                for k, c in enumerate(cols):
+                    v = meta.get(c, [])
+                    table[item, k] = _scalar_meta(v) if (not isinstance(v, list) or len(v)) else 0
+            return table
+        return np.asarray(mapping, dtype=np.int64)
+
+    def shuffle_indices(self):
+        if self.dataset_len == 0:
+            return
+        self.indices = torch.randperm(self.dataset_len)
+
+    def __len__(self):
+        return self.num_batches
+
+    def __iter__(self):
+        self.i = 0
+        if self.shuffle and self.dataset_len > 0:
+            self.shuffle_indices()
+        return self
+
+    def epoch_order(self):
+        """Row positions in the order this epoch visits them (after __iter__)."""
+        return self.indices if (self.shuffle and self.dataset_len > 0) else torch.arange(self.dataset_len)
+
+    def __next__(self):
+        if self.i >= self.dataset_len:
+            raise StopIteration
+        end = min(self.i + self.batch_size, self.dataset_len)
+        sel = self.indices[self.i:end] if (self.shuffle and self.dataset_len > 0) else slice(self.i, end)
+        batch = {k: t[sel] for k, t in self.data.items() if k in ("user_id", "pos_item_id", "pos_metadata_id")}
+        if not self.dynamic_neg_sampling:
+            for k in ("neg_item_id", "neg_metadata_id"):
+                if k in self.data:
+                    batch[k] = self.data[k][sel]
+        else:
+            neg = sample_negatives_reference_stream(batch["pos_item_id"].numpy(), self.n_items)
+            batch["neg_item_id"] = torch.from_numpy(neg)
+            if self._meta_table is not None and "pos_metadata_id" in batch:
+                batch["neg_metadata_id"] = torch.from_numpy(self._meta_table[neg])
+        self.i += self.batch_size
+        return batch

@@ -1,0 +1,168 @@
+# -*- coding: utf-8 -*-
+"""Training-step engine behind TorchRecSys.fit(): drives the fused HIP kernels for one optimiser step and honours the
+user-supplied torch optimiser object (reference model.py:188-200 only ever calls zero_grad() and step() on it).
+
+Optimiser dispatch:
+  torch.optim.SGD (momentum=0, weight_decay=0)  -> fused row scatter  W[r] += -lr * g        (trs_score_sgd_update)
+  torch.optim.SparseAdam                        -> accumulate + elected-owner lazy Adam rows  (trs_rows_apply_sparse_adam)
+  torch.optim.Adagrad (weight_decay=0)          -> accumulate + elected-owner Adagrad rows    (trs_rows_apply_adagrad)
+  anything else                                 -> the staged rows are handed to the optimiser as the sparse COO
+                                                   gradients autograd would have produced, then optimizer.step().
+Moments live in optimizer.state[p] under torch's own key names, so optimizer.state_dict() stays truthful.
+"""
+import torch
+
+from . import ops
+
+
+def _group_of(optimizer, p):
+    for g in optimizer.param_groups:
+        for q in g["params"]:
+            if q is p:
+                return g
+    return None
+
+
+def classify_optimizer(optimizer, params):
+    """'sgd' | 'sparse_adam' | 'adagrad' | 'generic' for the given embedding parameters."""
+    groups = [_group_of(optimizer, p) for p in params]
+    if any(g is None for g in groups):
+        return "generic"
+    t = type(optimizer)
+    if t is torch.optim.SGD:
+        ok = all(g["momentum"] == 0 and g["dampening"] == 0 and g["weight_decay"] == 0 and not g["nesterov"]
+                 and not g.get("maximize", False) for g in groups)
+        return "sgd" if ok else "generic"
+    if t is torch.optim.SparseAdam:
+        return "sparse_adam" if all(not g.get("maximize", False) for g in groups) else "generic"
+    if t is torch.optim.Adagrad:
+        ok = all(g["weight_decay"] == 0 and not g.get("maximize", False) for g in groups)
+        return "adagrad" if ok else "generic"
+    return "generic"
+
+
+class RowState:
+    """Per-table scratch of the coalescing optimisers: gradient accumulator + owner-election stamps."""
+
+    def __init__(self, p):
+        self.acc = torch.zeros_like(p.data)
+        self.stamp = torch.zeros(p.shape[0], dtype=torch.int32, device=p.device)
+        self.step_id = 0
+
+    def next_id(self):
+        self.step_id += 1
+        if self.step_id >= 2 ** 31 - 1:
+            self.stamp.zero_()
+            self.step_id = 1
+        return self.step_id
+
+
+def apply_rows(kind, optimizer, p, rs, idx, vals, ld=None):
+    """One coalescing-optimiser update of table `p` from uncoalesced (idx, vals) entries."""
+    g = _group_of(optimizer, p)
+    st = optimizer.state[p]
+    ops.rows_scatter_add(rs.acc, idx, vals, 1.0, ld=ld)
+    if kind == "sparse_adam":
+        if len(st) == 0:
+            st["step"] = 0
+            st["exp_avg"] = torch.zeros_like(p.data)
+            st["exp_avg_sq"] = torch.zeros_like(p.data)
+        st["step"] += 1
+        b1, b2 = g["betas"]
+        ops.rows_apply_sparse_adam(p.data, rs.acc, st["exp_avg"], st["exp_avg_sq"], rs.stamp, idx, rs.next_id(),
+                                   g["lr"], b1, b2, g["eps"], int(st["step"]))
+    elif kind == "adagrad":
+        if "sum" not in st:  # torch.optim.Adagrad creates its state in __init__; be safe for foreign objects
+            st["step"] = torch.tensor(0.0)
+            st["sum"] = torch.full_like(p.data, g.get("initial_accumulator_value", 0.0))
+        st["step"] += 1
+        step = float(st["step"])
+        clr = g["lr"] / (1 + (step - 1) * g["lr_decay"])
+        ops.rows_apply_adagrad(p.data, rs.acc, st["sum"], rs.stamp, idx, rs.next_id(), clr, g["eps"])
+    else:
+        raise ValueError(kind)
+
+
+class SparseScorerTrainer:
+    """One training step of a Linear / FM scorer on a device-resident batch."""
+
+    def __init__(self, net, optimizer, batch_capacity):
+        self.net, self.opt = net, optimizer
+        self.params = net.table_params()
+        self.kind = classify_optimizer(optimizer, self.params)
+        dev = self.params[0].device
+        self.dev = dev
+        self.D = self.params[0].shape[1]
+        self.M = net.n_meta_tables()
+        self.R = 3 + 2 * self.M
+        self.cap = batch_capacity
+        self.grad_rows = torch.empty((self.R, batch_capacity, self.D), dtype=torch.float32, device=dev)
+        self.grad_lin = torch.empty((self.R, batch_capacity), dtype=torch.float32, device=dev)
+        self.err = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.row_state = {}
+        if self.kind in ("sparse_adam", "adagrad"):
+            self.row_state = {id(p): RowState(p) for p in self.params}
+
+    def _views(self, B):
+        """Staging views for a batch of B <= capacity rows (contiguous (R,B,D) / (R,B) prefixes)."""
+        if B == self.cap:
+            return self.grad_rows, self.grad_lin
+        gr = self.grad_rows.view(-1)[: self.R * B * self.D].view(self.R, B, self.D)
+        gl = self.grad_lin.view(-1)[: self.R * B].view(self.R, B)
+        return gr, gl
+
+    def step(self, ids, loss_slot, auc_slot=None):
+        """ids: dict user/pos/neg[/pos_meta/neg_meta] of GPU id tensors.  loss_slot: 1-element fp32 view that receives
+        the SUM of the batch's hinge terms (caller divides by B)."""
+        B = ids["user"].shape[0]
+        net = self.net
+        T = net.tables()
+        Bt, keep = ops.make_batch(ids["user"], ids["pos"], ids["neg"], ids.get("pos_meta"), ids.get("neg_meta"),
+                                  self.err)
+        gr, gl = self._views(B)
+        ops.score_fwd_bwd(net.NET, T, Bt, B, self.D, self.M, self.dev, loss_slot, auc_slot, want_scores=False,
+                          grad_rows=gr, grad_lin=gl)
+        if self.kind == "sgd":
+            groups = [_group_of(self.opt, p) for p in self.params]
+            lrs = {g["lr"] for g in groups}
+            if len(lrs) == 1:
+                ops.score_sgd_update(net.NET, T, Bt, gr, gl, lrs.pop())
+            else:
+                self._per_table(ids, gr, gl, lambda p, idx, vals, ld: ops.rows_scatter_add(
+                    p.data, idx, vals, -_group_of(self.opt, p)["lr"], ld=ld))
+        elif self.kind in ("sparse_adam", "adagrad"):
+            self._per_table(ids, gr, gl, lambda p, idx, vals, ld: apply_rows(
+                self.kind, self.opt, p, self.row_state[id(p)], idx, vals, ld))
+        else:
+            self.opt.zero_grad()
+            self._per_table(ids, gr, gl, self._set_sparse_grad)
+            self.opt.step()
+
+    @staticmethod
+    def _set_sparse_grad(p, idx, vals, ld):
+        g = torch.sparse_coo_tensor(idx.reshape(1, -1).long(), vals, size=p.shape)
+        p.grad = g if p.grad is None else p.grad + g
+
+    def _per_table(self, ids, gr, gl, fn):
+        """Call fn(param, idx (n,), vals (n, width), ld) once per embedding table with that table's COO entries."""
+        B, D, M = ids["user"].shape[0], self.D, self.M
+        ps = self.params
+        item_idx = torch.cat([ids["pos"], ids["neg"]])
+        fn(ps[0], ids["user"], gr[0], D)
+        fn(ps[1], item_idx, gr[1:3].reshape(2 * B, D), D)
+        fn(ps[2], ids["user"], gl[0].reshape(B, 1), 1)
+        fn(ps[3], item_idx, gl[1:3].reshape(2 * B, 1), 1)
+        for m in range(M):
+            midx = torch.cat([ids["pos_meta"][:, m], ids["neg_meta"][:, m]]).contiguous()
+            sl = slice(3 + 2 * m, 5 + 2 * m)
+            fn(ps[4 + m], midx, gr[sl].reshape(2 * B, D), D)
+            if net_has_meta_lin(self.net):
+                fn(ps[4 + M + m], midx, gl[sl].reshape(2 * B, 1), 1)
+
+    def check_errors(self):
+        from .collaborative._scorer import check_err_flag
+        check_err_flag(self.err, "fit")
+
+
+def net_has_meta_lin(net):
+    return bool(getattr(net, "META_LIN_NAME", None))

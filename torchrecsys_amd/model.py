@@ -1,0 +1,307 @@
+# -*- coding: utf-8 -*-
+"""TorchRecSys — drop-in for the reference's torchrecsys.model.TorchRecSys (reference model.py:18-452) whose
+fit() / evaluate() / predict() run on hand-written HIP kernels on the MI355X.
+
+Same constructor keywords, same methods, same printed strings, same state_dict keys.  Extra keywords (superset API):
+  hidden_layers, use_batch_norm : reach the MLP (the reference advertises them but cannot pass them)
+  rng : 'reference' (default) replays the reference's host RNG streams (torch.randperm shuffle, numpy legacy sampler) so
+        a seeded run sees bit-identical batches;  'device' keeps the whole interaction stream in HBM and shuffles /
+        samples on the GPU with counter-based generators (same distributions, different streams) — the mode the
+        benchmark runs in
+  seed : seed of the device-side generators (rng='device')
+"""
+import math
+from typing import List
+
+import numpy as np
+import pandas as pd
+import torch
+import torch.profiler
+
+from . import ops
+from .collaborative._scorer import check_err_flag
+from .collaborative.fm import FM
+from .collaborative.linear import Linear
+from .dataset.dataset import FastDataLoader, ProcessData, sample_negatives_reference_stream
+from .engine import SparseScorerTrainer
+from .evaluate.metrics import Metrics
+from .helper.cuda import gpu
+from .helper.loss import hinge_loss  # noqa: F401  (part of the reference's module surface)
+
+_NO_GPU_MSG = ("torchrecsys_amd needs an AMD Instinct MI355X (gfx950) visible to PyTorch-ROCm; "
+               "it has no CPU fallback (use_cuda=False only means: hand results back as CPU tensors)")
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise RuntimeError(_NO_GPU_MSG)
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _mix64(a, b):
+    """SplitMix64-style hash of two integers -> 64-bit key (device shuffle / sampler keys per epoch)."""
+    x = (a * 0x9E3779B97F4A7C15 + b + 0x632BE59BD9B4E019) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 30
+    x = (x * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 27
+    x = (x * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 31
+    return x or 1
+
+
+class TorchRecSys(torch.nn.Module):
+
+    def __init__(self,
+                 dataset: pd.DataFrame,
+                 user_id_col: str,
+                 item_id_col: str,
+                 n_factors: int = 80,
+                 net_type: str = 'linear',
+                 metadata_id_col: List[str] = None,
+                 split_ratio: float = 0.8,
+                 dynamic_neg_sampling: bool = False,
+                 use_amp: bool = False,
+                 use_cuda: bool = False,
+                 debug: bool = False,
+                 path: str = './',
+                 hidden_layers: List[int] = None,
+                 use_batch_norm: bool = True,
+                 rng: str = 'reference',
+                 seed: int = 0):
+        super().__init__()
+        assert rng in ('reference', 'device'), 'rng must be "reference" or "device"'
+        self.path = path
+        self.dynamic_neg_sampling = dynamic_neg_sampling
+        self.use_amp = use_amp
+        self.use_cuda = use_cuda
+        self.rng = rng
+        self.seed = seed
+        self.grad_scaler = None  # bf16 GEMM inputs with fp32 accumulation need no loss scaling
+
+        self.data_processor = ProcessData(dataset=dataset, user_id_col=user_id_col, item_id_col=item_id_col,
+                                          metadata_id_col=metadata_id_col, split_ratio=split_ratio,
+                                          dynamic_neg_sampling=self.dynamic_neg_sampling)
+        self.data_processor.prepare_data()
+        self.config = self.data_processor.config
+        self.n_users = self.config.get('num_users')
+        self.n_items = self.config.get('num_items')
+        self.metadata_size = self.config.get('num_metadata')
+        self.metadata_name = metadata_id_col if hasattr(self.data_processor, 'metadata_id_col') else None
+        self.n_factors = n_factors
+        self.net_type = net_type
+        self.use_metadata = True if self.metadata_name else False
+        self.debug = debug
+        self.hidden_layers = hidden_layers
+        self.use_batch_norm = use_batch_norm
+        self._fit_epochs_done = 0
+        self._dev_cache = {}
+        self._init_net(net_type=net_type)
+
+    # ------------------------------------------------------------------------------------------------ net
+    def _init_net(self, net_type='linear'):
+        assert net_type in ('linear', 'mlp', 'neucf', 'fm', 'lstm'), \
+            'Net type must be one of "linear", "mlp", "neu", "ease" or "lstm"'
+        kw = dict(n_users=self.n_users, n_items=self.n_items, n_metadata=self.metadata_size,
+                  n_factors=self.n_factors, use_metadata=self.use_metadata, use_cuda=self.use_cuda)
+        if net_type == 'linear':
+            print('Linear Collaborative Filtering')
+            self.net = Linear(**kw)
+        elif net_type == 'mlp':
+            print('Multi Layer Perceptron')
+            from .collaborative.mlp import MLP
+            self.net = MLP(use_batch_norm=self.use_batch_norm, hidden_layers=self.hidden_layers,
+                           use_bf16=self.use_amp, **kw)
+        elif net_type == 'fm':
+            print('Factorization Machine')
+            self.net = FM(**kw)
+        else:  # the reference silently leaves self.net undefined here (model.py:162-166)
+            raise NotImplementedError(f'{net_type} is not implemented (nor is it in the reference)')
+        # parameters are created on the host from torch's CPU generator (bit-identical init), then live in HBM
+        if torch.cuda.is_available():
+            self.net = self.net.to(_device())
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def forward(self, net, batch):
+        """Positive and negative scores of one batch (reference model.py:171-185), one fused kernel."""
+        if hasattr(net, 'forward_pair'):
+            return net.forward_pair(batch)
+        positive = net.forward(batch, user_key='user_id', item_key='pos_item_id', metadata_key='pos_metadata_id')
+        negative = net.forward(batch, user_key='user_id', item_key='neg_item_id', metadata_key='neg_metadata_id')
+        return positive, negative
+
+    def backward(self, loss_value, optimizer):
+        """Generic autograd step (reference model.py:188-200) for callers that drive forward()/hinge_loss() themselves;
+        fit() uses the fused engine instead."""
+        optimizer.zero_grad()
+        loss_value.backward()
+        optimizer.step()
+        return loss_value.item()
+
+    # ------------------------------------------------------------------------------------------------ data staging
+    def _id_dtype(self):
+        big = max(self.n_users, self.n_items, *(list(self.metadata_size.values()) or [0]))
+        return torch.int32 if big < 2 ** 31 else torch.int64
+
+    def _host_epoch(self, data, loader):
+        """All batches of one epoch in visiting order, consuming the reference's RNG streams exactly as its
+        FastDataLoader would batch by batch (shuffle in __iter__, then the sampler walk in row order)."""
+        order = loader.epoch_order()
+        take = (lambda t: t[order]) if loader.shuffle else (lambda t: t)
+        ep = {'user': take(data['user_id']), 'pos': take(data['pos_item_id'])}
+        has_meta = 'pos_metadata_id' in data
+        if has_meta:
+            ep['pos_meta'] = take(data['pos_metadata_id'])
+        if not self.dynamic_neg_sampling:
+            ep['neg'] = take(data['neg_item_id'])
+            if has_meta:
+                ep['neg_meta'] = take(data['neg_metadata_id'])
+        else:
+            pos = ep['pos'].numpy()
+            B = loader.batch_size
+            neg = np.concatenate([sample_negatives_reference_stream(pos[i:i + B], self.n_items)
+                                  for i in range(0, len(pos), B)]) if len(pos) else np.zeros(0, np.int64)
+            ep['neg'] = torch.from_numpy(neg)
+            if has_meta:
+                ep['neg_meta'] = torch.from_numpy(self.data_processor.item_meta_table[neg])
+        dt, dev = self._id_dtype(), _device()
+        return {k: v.to(dt).contiguous().to(dev, non_blocking=True) for k, v in ep.items()}
+
+    def _device_stream(self, which):
+        """The train/test interaction stream resident in HBM as int32 (rng='device')."""
+        if which not in self._dev_cache:
+            data = self.data_processor.train_data if which == 'train' else self.data_processor.test_data
+            dev = _device()
+            d = {'user': data['user_id'].to(torch.int32).to(dev), 'pos': data['pos_item_id'].to(torch.int32).to(dev)}
+            d['neg'] = data['neg_item_id'].to(torch.int32).to(dev) if 'neg_item_id' in data else None
+            tab = self.data_processor.item_meta_table
+            d['item_meta'] = None if tab is None else torch.from_numpy(tab).to(torch.int32).to(dev)
+            self._dev_cache[which] = d
+        return self._dev_cache[which]
+
+    def _item_meta_dev(self):
+        tab = self.data_processor.item_meta_table
+        if tab is None:
+            return None
+        if 'item_meta' not in self._dev_cache:
+            self._dev_cache['item_meta'] = torch.from_numpy(tab).to(torch.int32).to(_device())
+        return self._dev_cache['item_meta']
+
+    def _make_trainer(self, optimizer, batch_size):
+        if self.net_type == 'mlp':
+            from .mlp_engine import MLPTrainer
+            return MLPTrainer(self.net, optimizer, batch_size)
+        return SparseScorerTrainer(self.net, optimizer, batch_size)
+
+    # ------------------------------------------------------------------------------------------------ fit
+    def fit(self, optimizer, epochs=10, batch_size=512, profile_epochs: int = 0):
+        """Fits the model (reference model.py:203-288).  Per step: [shuffle slice + negative sampling] -> fused
+        gather + scoring + hinge + backward -> sparse-row optimiser update; the loss stays on the device and is
+        read back once per epoch (the reference syncs every step, model.py:200)."""
+        dev = _device()
+        data = self.data_processor.train_data
+        n_train = data['user_id'].shape[0]
+        loader = FastDataLoader(data=data, batch_size=batch_size, shuffle=True,
+                                dynamic_neg_sampling=self.dynamic_neg_sampling, n_items=self.n_items,
+                                item_to_metadata_map=self.data_processor.item_meta_table,
+                                metadata_id_cols=self.metadata_name)
+        num_batches = loader.num_batches
+        trainer = self._make_trainer(optimizer, min(batch_size, max(n_train, 1)))
+        loss_sums = torch.zeros(max(num_batches, 1), dtype=torch.float32, device=dev)
+
+        for epoch in range(epochs):
+            self.net = self.net.train()
+            loss_sums.zero_()
+            prof = None
+            if profile_epochs > 0 and epoch == 0:
+                print(f"\n--- Starting Profiling for Epoch {epoch+1} ---")
+                prof = torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU,
+                                                          torch.profiler.ProfilerActivity.CUDA],
+                                              record_shapes=True, profile_memory=True, with_stack=True)
+                prof.__enter__()
+            if num_batches > 0:
+                if self.rng == 'reference':
+                    iter(loader)  # reshuffle: one torch.randperm per epoch (dataset.py:369-373)
+                    ep = self._host_epoch(data, loader)
+                    for b in range(num_batches):
+                        s, e = b * batch_size, min((b + 1) * batch_size, n_train)
+                        trainer.step({k: v[s:e] for k, v in ep.items()}, loss_sums[b:b + 1])
+                else:
+                    st = self._device_stream('train')
+                    ge = self._fit_epochs_done
+                    shuffle_key, sample_seed = _mix64(self.seed, 2 * ge + 1), _mix64(self.seed, 2 * ge + 2)
+                    for b in range(num_batches):
+                        s, e = b * batch_size, min((b + 1) * batch_size, n_train)
+                        ids = ops.batch_prepare(st['user'], st['pos'], st['neg'], shuffle_key, s, e - s, self.n_items,
+                                                sample_seed, s, st['item_meta'])
+                        trainer.step(ids, loss_sums[b:b + 1])
+            self._fit_epochs_done += 1
+            sums = loss_sums.cpu().numpy()  # the one device->host sync of the epoch
+            trainer.check_errors()
+            if prof is not None:
+                prof.__exit__(None, None, None)
+                print("--- Profiler Results (First Epoch) ---")
+                print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=20))
+            total_loss = 0.0
+            for b in range(num_batches):
+                nb = min((b + 1) * batch_size, n_train) - b * batch_size
+                total_loss += float(np.float32(sums[b]) / np.float32(nb))
+            avg_loss = total_loss / num_batches if num_batches > 0 else 0
+            print(f'|--- Epoch {epoch+1}/{epochs} --- Training Loss: {avg_loss:.4f}')
+
+    # ------------------------------------------------------------------------------------------------ evaluate
+    def evaluate(self, batch_size=512, eval_metrics=['loss', 'auc']):
+        """reference model.py:292-338: eval-mode scores of the test split, hinge loss and pairwise AUC per batch,
+        unweighted means over batches, printed; returns None."""
+        self.net = self.net.eval()
+        data = self.data_processor.test_data
+        n_test = data.get('user_id', torch.empty(0)).numel()
+        if n_test == 0:
+            print("|--- No test data to evaluate.")
+            return
+        dev = _device()
+        loader = FastDataLoader(data=data, batch_size=batch_size, shuffle=False,
+                                dynamic_neg_sampling=self.dynamic_neg_sampling, n_items=self.n_items,
+                                item_to_metadata_map=self.data_processor.item_meta_table,
+                                metadata_id_cols=self.metadata_name)
+        nb = loader.num_batches
+        loss_sums = torch.zeros(nb, dtype=torch.float32, device=dev)
+        auc_counts = torch.zeros(nb, dtype=torch.int32, device=dev)
+        if self.rng == 'reference':
+            iter(loader)
+            ep = self._host_epoch(data, loader)
+        else:
+            st = self._device_stream('test')
+            sample_seed = _mix64(self.seed, 0xE7A1)
+        for b in range(nb):
+            s, e = b * batch_size, min((b + 1) * batch_size, n_test)
+            if self.rng == 'reference':
+                ids = {k: v[s:e] for k, v in ep.items()}
+            else:
+                ids = ops.batch_prepare(st['user'], st['pos'], st['neg'], 0, s, e - s, self.n_items, sample_seed, s,
+                                        st['item_meta'])
+            pos, neg = self.net.score_ids(ids)
+            ops.hinge_auc(pos, neg, loss_sums[b:b + 1], auc_counts[b:b + 1])
+        ls, ac = loss_sums.cpu().numpy(), auc_counts.cpu().numpy()
+        sizes = [min((b + 1) * batch_size, n_test) - b * batch_size for b in range(nb)]
+        results = {}
+        if 'loss' in eval_metrics:
+            results['loss'] = [float(np.float32(ls[b]) / np.float32(sizes[b])) for b in range(nb)]
+        if 'auc' in eval_metrics:
+            results['auc'] = [float(np.float32(ac[b]) / np.float32(sizes[b])) for b in range(nb)]
+        for metric in eval_metrics:
+            values = results.get(metric, [])
+            value = sum(values) / len(values) if values else 0
+            print(f'|--- Testing {metric}: {value:.4f}')
+
+    # ------------------------------------------------------------------------------------------------ predict
+    def predict(self, user_id: int, top_k: int = 10, prediction_batch_size: int = 4096):
+        """Top-K item ids for one user (reference model.py:341-452): score every item, sort descending, first top_k.
+        Ties are ordered by ascending item id (unspecified in the reference).  Returns an int64 CPU tensor.
+        `prediction_batch_size` is accepted for compatibility; the fused kernel streams the item table once and the
+        result does not depend on it."""
+        self.net = self.net.eval()
+        scores = self.net.score_all_items(int(user_id), self._item_meta_dev())
+        k = min(int(top_k), self.n_items)
+        if k <= 0:
+            return torch.empty(0, dtype=torch.int64)
+        return ops.topk(scores, k).cpu()
