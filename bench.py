@@ -1,0 +1,178 @@
+# -*- coding: utf-8 -*-
+"""bench.py — throughput of the north-star hot path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the training hot path over one batch of synthetic interactions already resident in HBM:
+epoch-shuffle slice + dynamic negative sampling -> fused embedding gather + FM pairwise scoring + hinge + backward ->
+sparse embedding-row SGD update.  Workload (BASELINE.json configs[1], SURVEY §8d "c2"): net_type='fm',
+1M users x 100K items x 100M interactions (80M train triples after the 0.8 split), dim=64, dynamic_neg_sampling=True,
+batch 65 536, torch.optim.SGD(lr=1e-2), fp32.  metric = training interactions/s (pos+neg) = 2 x triples/s.
+
+Multi-GPU: one process per GPU; the interaction stream is sharded across ranks (each rank owns an
+independent 100M-interaction shard, weak scaling: per-GPU batch fixed); embedding tables are replicated and the FM has
+no dense parameters, so the step has no data-path collective.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md "Chip-level parameters")
+
+CONFIGS = {
+    # name: (net, n_users, n_items, interactions, D, batch, description)
+    "c2": ("fm", 1_000_000, 100_000, 100_000_000, 64, 65_536,
+           "c2: net_type='fm', 1M users x 100K items x 100M interactions, dim=64, dynamic_neg_sampling=True, "
+           "batch 65536, SGD(lr=1e-2), fp32"),
+    "c1": ("linear", 3_000, 1_000, 100_000, 32, 1_024,
+           "c1: net_type='linear', 3000 users x 1000 items x 100000 interactions, dim=32, batch 1024, static negatives"),
+    "c4": ("fm", 10_000_000, 1_000_000, 125_000_000, 128, 32_768,
+           "c4 per-GPU shard: net_type='fm', 10M users x 1M items, 125M-interaction shard of 1B, dim=128, "
+           "per-GPU batch 32768 (global 262144 at 8 GPUs)"),
+}
+
+
+def synth_stream(n_users, n_items, n, device, seed):
+    """Uniform synthetic interactions with guaranteed dense id coverage, generated in HBM."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    users = torch.cat([torch.arange(n_users, device=device, dtype=torch.int32),
+                       torch.randint(0, n_users, (n - n_users,), device=device, dtype=torch.int32, generator=g)])
+    reps = -(-n_users // n_items)
+    items = torch.cat([torch.arange(n_items, device=device, dtype=torch.int32).repeat(reps)[:n_users],
+                       torch.randint(0, n_items, (n - n_users,), device=device, dtype=torch.int32, generator=g)])
+    perm = torch.randperm(n, device=device, generator=g)
+    return users[perm].contiguous(), items[perm].contiguous()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip per-kernel HIP event timing")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+
+    from torchrecsys_amd import _lib
+    from torchrecsys_amd.model import TorchRecSys
+    _lib.check(_lib.load().trs_check_device(), "trs_check_device")
+
+    net, n_users, n_items, n_inter, D, B, desc = CONFIGS[args.config]
+    dynamic = args.config != "c1"
+    users, items = synth_stream(n_users, n_items, n_inter, dev, seed=1000 + rank)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        torch.manual_seed(7)
+        model = TorchRecSys.from_tensors(users, items, n_users=n_users, n_items=n_items, n_factors=D, net_type=net,
+                                         split_ratio=0.8, dynamic_neg_sampling=dynamic, rng="device", seed=7 + rank)
+    del users, items
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+    runner = model.make_runner(opt, B)
+    model.net.train()
+
+    full = runner.n_train // B  # only full batches are timed; an epoch's partial last batch is skipped
+    assert full > 0, "stream shorter than one batch"
+    state = {"started": False}
+
+    def run(k):
+        """k steps, rolling into the next epoch (new shuffle key, loss read-back) when the current one ends."""
+        done = 0
+        while done < k:
+            if not state["started"] or runner.next_batch >= full:
+                if state["started"]:
+                    runner.end_epoch()
+                runner.begin_epoch()
+                state["started"] = True
+            done += runner.run_steps(min(k - done, full - runner.next_batch))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup)
+    barrier()
+    if not args.no_kernel_events:
+        runner.trainer.kernel_events = {}
+    t0 = time.perf_counter()
+    run(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    events = runner.trainer.kernel_events or {}
+    runner.trainer.kernel_events = None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    runner.end_epoch()  # also raises if any id was out of range
+
+    triples = args.steps * B * world
+    value = 2.0 * triples / elapsed
+    R = 3
+    step_bytes = 16 + 2 * R * (4 * D + 4)  # FM/Linear fused SGD step, rows read once + written once
+    out = {
+        "metric": "training interactions/sec (pos+neg)", "value": value, "unit": "interactions/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": desc, "global_batch": B * world, "per_gpu_batch": B,
+                   "parallelism": f"dp{world}: interaction stream sharded, tables replicated, no per-step collective "
+                                  f"(FM/Linear have no dense parameters)",
+                   "rng": "device (Feistel epoch shuffle + Philox4x32-10 negative sampler)"},
+        "step_algorithmic_GBps_per_gpu": step_bytes * B * args.steps / elapsed / 1e9,
+    }
+    # ---- roofline of the dominant kernel: algorithmic bytes per launch / mean launch duration (HIP events) ----
+    if events:
+        mean_ms = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in events.items()}
+        dom = max(mean_ms, key=mean_ms.get)
+        # algorithmic bytes per triple of each kernel (DESIGN.md "Kernels"): the forward+backward pass reads the ids and
+        # the R rows (+1-wide terms) once: 16 + R(4D+4) + 8; the update pass writes the R rows once: 12 + R(4D+4)
+        per_triple = {"score_kernel<fwd_bwd>": 16 + R * (4 * D + 4) + 8, "score_sgd_update_kernel": 12 + R * (4 * D + 4)}
+        ach = per_triple[dom] * B / (mean_ms[dom] * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "mean_launch_us": {k: 1e3 * v for k, v in mean_ms.items()},
+                           "algorithmic_bytes_per_triple": per_triple[dom]}
+    # ---- CPU baseline: the op-sequence port of the reference's fit() loop on this box's host cores ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import cpu_fit
+        cores = min(16, len(os.sched_getaffinity(0)))  # the one-GPU box share (oversubscribing collapses torch CPU ops)
+        n_rows = min(n_inter, 4_000_000)
+        res = cpu_fit.time_steps(net, n_users, n_items, D, B, n_rows=n_rows, steps=40, warmup=1, dynamic=dynamic,
+                                 threads=cores, max_seconds=20.0)
+        out["cpu_baseline"] = {"value": res["interactions_per_s"], "unit": "interactions/s", "cores": res["threads"],
+                               "kind": "port",
+                               "sample": f"{res['steps']} steps of batch {B} ({res['seconds']:.1f} s) on full-size "
+                                         f"tables, {n_rows} synthetic interactions, oracle/cpu_fit.py"}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,58 @@
+# -*- coding: utf-8 -*-
+"""The C-ABI library loads on a machine without a GPU and exports exactly what include/trs.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "trs.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(trs_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_declares_functions():
+    fns = header_functions()
+    assert "trs_score_fwd_bwd" in fns and "trs_topk" in fns and len(fns) >= 15
+
+
+def test_library_exports_every_declared_symbol():
+    from torchrecsys_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in header_functions():
+        assert hasattr(lib, name), f"{name} declared in include/trs.h but not exported"
+
+
+def test_binding_matches_header():
+    from torchrecsys_amd import _lib
+    assert sorted(_lib.PROTOTYPES) == header_functions()
+    lib = _lib.load()
+    assert lib.trs_abi_version() == _lib.ABI_VERSION
+    assert lib.trs_topk_workspace_bytes(100_000, 10) > 0  # host-only helper: callable without a GPU
+
+
+def test_struct_layout_matches_header():
+    """ctypes mirrors of trs_tables / trs_batch have the C layout (x86-64 SysV: natural alignment)."""
+    from torchrecsys_amd import _lib
+    assert ctypes.sizeof(_lib.TrsTables) == 4 * 8 + 8 * 8 + 8 * 8 + 2 * 8 + 8 * 8 + 2 * 4
+    assert ctypes.sizeof(_lib.TrsBatch) == 5 * 8 + 8 + 4 + 4 + 8
+    assert _lib.TrsTables.D.offset == 4 * 8 + 8 * 8 + 8 * 8 + 2 * 8 + 8 * 8
+    assert _lib.TrsBatch.err_flag_dev.offset == 56
+
+
+def test_bad_arguments_return_error_codes_without_a_gpu():
+    """Argument validation happens on the host before any launch."""
+    from torchrecsys_amd import _lib
+    lib = _lib.load()
+    T, B = _lib.TrsTables(), _lib.TrsBatch()
+    assert lib.trs_score_forward(1, ctypes.byref(T), ctypes.byref(B), None, None, None) == -1
+    assert b"NULL" in lib.trs_last_error() or b"table" in lib.trs_last_error()
+    assert lib.trs_topk(None, 0, 1, None, None, 0, None) == -1
+    assert lib.trs_sample_neg(None, 3, 10, 5, 0, 0, None, None) == -1
+    with pytest.raises(_lib.TrsError):
+        _lib.check(-1, "x")

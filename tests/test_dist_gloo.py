@@ -1,0 +1,84 @@
+# -*- coding: utf-8 -*-
+"""The N>1 path on CPU: world_size-2 `gloo` processes exercising stream sharding, the flat dense-gradient all-reduce,
+table averaging and the initial broadcast (torchrecsys_amd/dist.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from torchrecsys_amd import dist as tdist
+        assert tdist.world_info() == (rank, world)
+        # --- stream sharding: contiguous and by-user partitions are disjoint and cover the stream
+        users = torch.arange(1001) % 37
+        items = torch.arange(1001) % 11
+        u, i = tdist.shard_stream(users, items)
+        s, e = tdist.shard_bounds(1001, rank, world)
+        assert torch.equal(u, users[s:e]) and torch.equal(i, items[s:e])
+        cnt = torch.tensor([u.numel()])
+        dist.all_reduce(cnt)
+        assert cnt.item() == 1001
+        ub, ib = tdist.shard_stream(users, items, by_user=True)
+        assert ((ub % world) == rank).all()
+        cnt = torch.tensor([ub.numel()])
+        dist.all_reduce(cnt)
+        assert cnt.item() == 1001
+        # --- flat dense-gradient bucket: ONE all-reduce gives every rank the mean gradient
+        torch.manual_seed(0)
+        params = [torch.nn.Parameter(torch.zeros(8, 4)), torch.nn.Parameter(torch.zeros(5))]
+        bucket = tdist.FlatGradBucket(params)
+        bucket.grad_of(params[0]).copy_(torch.full((8, 4), float(rank + 1)))
+        bucket.grad_of(params[1]).copy_(torch.arange(5.0) * (rank + 1))
+        bucket.allreduce_mean_()
+        assert torch.allclose(bucket.grad_of(params[0]), torch.full((8, 4), 1.5))
+        assert torch.allclose(bucket.grad_of(params[1]), torch.arange(5.0) * 1.5)
+        # async form (overlap with backward)
+        bucket.flat.fill_(float(rank))
+        work = bucket.allreduce_mean_(async_op=True)
+        bucket.finish_(work)
+        assert torch.allclose(bucket.flat, torch.full_like(bucket.flat, 0.5))
+        # --- replicas: broadcast of initial weights, periodic averaging, scalar reduction
+        t = torch.full((6, 3), float(rank + 10))
+        tdist.broadcast_([t])
+        assert (t == 10).all()
+        t += rank * 2
+        tdist.average_tables_([t])
+        assert torch.allclose(t, torch.full((6, 3), 11.0))
+        tot = tdist.allreduce_scalar_sum([1.0, float(rank)], torch.device("cpu"))
+        assert tot == [2.0, 1.0]
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_data_parallel_path():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+def test_single_process_helpers_are_no_ops():
+    from torchrecsys_amd import dist as tdist
+    assert tdist.world_info() == (0, 1)
+    u, i = tdist.shard_stream(torch.arange(5), torch.arange(5))
+    assert u.numel() == 5
+    b = tdist.FlatGradBucket([torch.nn.Parameter(torch.ones(3))])
+    assert b.allreduce_mean_() is None
+    assert tdist.shard_bounds(10, 0, 3) == (0, 4) and tdist.shard_bounds(10, 2, 3) == (7, 10)

@@ -1,0 +1,197 @@
+# -*- coding: utf-8 -*-
+"""Host-side logic (no GPU): data pipeline invariants of the reference's own tests, optimiser dispatch, loud failure
+without a device."""
+import contextlib
+import io
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from oracle import loader as oloader
+from torchrecsys_amd.dataset.dataset import (FastDataLoader, ProcessData, TensorProcessData,
+                                            sample_negatives_reference_stream)
+
+N_USERS, N_ITEMS, N = 100, 50, 1000
+
+
+def dummy_df(with_meta=False, seed=0):
+    rs = np.random.RandomState(seed)
+    df = pd.DataFrame({"user_id": np.concatenate([np.arange(N_USERS), rs.randint(0, N_USERS, N - N_USERS)]),
+                       "item_id": np.concatenate([np.arange(N_ITEMS), rs.randint(0, N_ITEMS, N - N_ITEMS)])})
+    if with_meta:
+        cat = rs.randint(0, 5, N_ITEMS)
+        cat[:5] = np.arange(5)
+        df["category"] = cat[df["item_id"].values]
+        df["brand"] = [f"[{(i * 7) % 3}]" for i in df["item_id"].values]  # string-encoded 1-element lists
+    return df
+
+
+def test_process_data_static_neg_sampling():  # reference tests/test_model_and_features.py:52-59
+    dp = ProcessData(dummy_df(), "user_id", "item_id", dynamic_neg_sampling=False)
+    dp.prepare_data()
+    assert "neg_item_id" in dp.train_data and dp.train_data["neg_item_id"].numel() > 0
+    assert dp.train_data["user_id"].dtype == torch.int64
+    assert dp.train_data["user_id"].numel() + dp.test_data["user_id"].numel() == N
+    assert dp.config == {"num_users": N_USERS, "num_items": N_ITEMS, "num_metadata": {}}
+
+
+def test_process_data_dynamic_neg_sampling():  # :74-80
+    dp = ProcessData(dummy_df(), "user_id", "item_id", dynamic_neg_sampling=True)
+    dp.prepare_data()
+    assert "neg_item_id" not in dp.train_data
+
+
+def test_process_data_does_not_mutate_callers_frame():
+    df = dummy_df()
+    cols = list(df.columns)
+    ProcessData(df, "user_id", "item_id").prepare_data()
+    assert list(df.columns) == cols
+
+
+@pytest.mark.parametrize("dyn", [False, True])
+def test_process_data_with_metadata_int_contract(dyn):  # the (B,M) contract, int and "[k]" columns
+    dp = ProcessData(dummy_df(True), "user_id", "item_id", metadata_id_col=["category", "brand"],
+                     dynamic_neg_sampling=dyn)
+    dp.prepare_data()
+    tr = dp.train_data
+    assert tr["pos_metadata_id"].shape == (tr["user_id"].numel(), 2)
+    assert ("neg_metadata_id" in tr) == (not dyn)
+    assert dp.config["num_metadata"] == {"category": 5, "brand": 3}
+    tab = dp.item_meta_table
+    assert np.array_equal(tab[tr["pos_item_id"].numpy()], tr["pos_metadata_id"].numpy())
+    if not dyn:
+        assert np.array_equal(tab[tr["neg_item_id"].numpy()], tr["neg_metadata_id"].numpy())
+    assert dp.item_to_metadata_map[3] == {"category": [int(tab[3, 0])], "brand": [int(tab[3, 1])]}
+
+
+def test_multi_valued_metadata_is_rejected_loudly():
+    df = dummy_df()
+    df["tags"] = [[1, 2]] * len(df)
+    with pytest.raises(NotImplementedError):
+        ProcessData(df, "user_id", "item_id", metadata_id_col=["tags"])
+
+
+def test_non_dense_ids_raise_index_error():
+    df = dummy_df()
+    df.loc[0, "item_id"] = 10_000
+    with pytest.raises(IndexError):
+        ProcessData(df, "user_id", "item_id").prepare_data()
+
+
+def test_dataloader_dynamic_sampling_batch():  # :93-109
+    dp = ProcessData(dummy_df(), "user_id", "item_id", dynamic_neg_sampling=True)
+    dp.prepare_data()
+    loader = FastDataLoader(dp.train_data, batch_size=32, shuffle=True, dynamic_neg_sampling=True, n_items=N_ITEMS)
+    nb = 0
+    for batch in loader:
+        nb += 1
+        assert "neg_item_id" in batch and batch["neg_item_id"].shape == batch["pos_item_id"].shape
+        assert (batch["neg_item_id"] != batch["pos_item_id"]).all()
+        assert batch["neg_item_id"].dtype == torch.int64
+    assert nb == loader.num_batches == int(np.ceil(dp.train_data["user_id"].numel() / 32))
+
+
+def test_dataloader_dynamic_sampling_with_metadata():  # :111-131 (fails in the reference: unhashable list)
+    dp = ProcessData(dummy_df(True), "user_id", "item_id", metadata_id_col=["category", "brand"],
+                     dynamic_neg_sampling=True)
+    dp.prepare_data()
+    for mapping in (dp.item_meta_table, dp.item_to_metadata_map):  # array form and the reference's dict form
+        loader = FastDataLoader(dp.train_data, batch_size=64, shuffle=False, dynamic_neg_sampling=True,
+                                n_items=N_ITEMS, item_to_metadata_map=mapping, metadata_id_cols=["category", "brand"])
+        b = next(iter(loader))
+        assert b["neg_metadata_id"].shape == b["pos_metadata_id"].shape == (64, 2)
+        assert np.array_equal(dp.item_meta_table[b["neg_item_id"].numpy()], b["neg_metadata_id"].numpy())
+
+
+def test_dataloader_argument_errors():  # dataset.py:347-351
+    data = {"user_id": torch.arange(4), "pos_item_id": torch.arange(4)}
+    with pytest.raises(ValueError):
+        FastDataLoader(data, dynamic_neg_sampling=True)
+    with pytest.raises(ValueError):
+        FastDataLoader(data, dynamic_neg_sampling=True, n_items=4, metadata_id_cols=["a"])
+    empty = FastDataLoader({"user_id": torch.empty(0, dtype=torch.long), "pos_item_id": torch.empty(0, dtype=torch.long)})
+    assert list(empty) == [] and empty.num_batches == 0
+
+
+def test_vectorised_sampler_equals_the_literal_loop():
+    for n_items, B in ((2, 300), (3, 1000), (50, 4096)):
+        pos = np.random.RandomState(B).randint(0, n_items, B)
+        np.random.seed(4)
+        a = sample_negatives_reference_stream(pos, n_items)
+        s1 = np.random.randint(0, 1 << 30)
+        np.random.seed(4)
+        b = oloader.dynamic_negatives_loop(pos, n_items)
+        s2 = np.random.randint(0, 1 << 30)
+        assert np.array_equal(a, b) and s1 == s2 and (a != pos).all()
+
+
+def test_tensor_ingest_matches_dataframe_ingest():
+    df = dummy_df()
+    np.random.seed(1)
+    a = ProcessData(df, "user_id", "item_id", split_ratio=0.8)
+    a.prepare_data()
+    np.random.seed(1)
+    b = TensorProcessData(torch.from_numpy(df["user_id"].values), torch.from_numpy(df["item_id"].values),
+                          split_ratio=0.8)
+    b.prepare_data()
+    assert b.config == a.config
+    for k in ("user_id", "pos_item_id", "neg_item_id"):
+        assert torch.equal(a.train_data[k], b.train_data[k]) and torch.equal(a.test_data[k], b.test_data[k])
+
+
+def test_optimizer_dispatch():
+    from torchrecsys_amd.engine import classify_optimizer
+    ps = [torch.nn.Parameter(torch.zeros(4, 2)), torch.nn.Parameter(torch.zeros(3, 2))]
+    assert classify_optimizer(torch.optim.SGD(ps, lr=0.1), ps) == "sgd"
+    assert classify_optimizer(torch.optim.SGD(ps, lr=0.1, momentum=0.9), ps) == "generic"
+    assert classify_optimizer(torch.optim.SGD(ps, lr=0.1, weight_decay=1e-4), ps) == "generic"
+    assert classify_optimizer(torch.optim.SparseAdam(ps, lr=0.1), ps) == "sparse_adam"
+    assert classify_optimizer(torch.optim.Adagrad(ps, lr=0.1), ps) == "adagrad"
+    assert classify_optimizer(torch.optim.Adagrad(ps, lr=0.1, weight_decay=0.1), ps) == "generic"
+    assert classify_optimizer(torch.optim.RMSprop(ps, lr=0.1), ps) == "generic"
+    assert classify_optimizer(torch.optim.SGD(ps[:1], lr=0.1), ps) == "generic"  # a parameter the optimiser lacks
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_compute_fails_loudly_without_a_gpu():
+    from torchrecsys_amd.model import TorchRecSys
+    with contextlib.redirect_stdout(io.StringIO()) as out:
+        model = TorchRecSys(dummy_df(), "user_id", "item_id", n_factors=8, net_type="fm")
+    assert "Factorization Machine" in out.getvalue()
+    assert sorted(model.state_dict()) == ["net.item.weight", "net.linear_item.weight", "net.linear_user.weight",
+                                          "net.user.weight"]
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    for call in (lambda: model.fit(opt, epochs=1), lambda: model.evaluate(), lambda: model.predict(0),
+                 lambda: model.net.forward({"user_id": torch.tensor([0]), "pos_item_id": torch.tensor([0])},
+                                           "user_id", "pos_item_id")):
+        with pytest.raises(RuntimeError, match="MI355X"):
+            call()
+
+
+def test_unimplemented_net_types_raise():
+    from torchrecsys_amd.model import TorchRecSys
+    with pytest.raises(NotImplementedError):
+        TorchRecSys(dummy_df(), "user_id", "item_id", net_type="neucf")
+    with pytest.raises(AssertionError):
+        TorchRecSys(dummy_df(), "user_id", "item_id", net_type="nope")
+
+
+def test_seeded_construction_reproduces_reference_initial_weights():
+    """Same RNG calls in the same order as the reference: bit-identical initial state_dict (golden G4 'init')."""
+    from conftest import load_golden, sub
+    from torchrecsys_amd.model import TorchRecSys
+    for net_type in ("linear", "fm"):
+        for dyn in (False, True):
+            g = load_golden(f"g4_{net_type}_{'dyn' if dyn else 'static'}.npz")
+            df = pd.DataFrame({"user": g["df_user"], "item": g["df_item"]})
+            np.random.seed(7)
+            torch.manual_seed(7)
+            with contextlib.redirect_stdout(io.StringIO()):
+                model = TorchRecSys(df, "user", "item", n_factors=16, net_type=net_type, dynamic_neg_sampling=dyn)
+            sd = model.state_dict()
+            ref = sub(g, "init")
+            assert sorted(sd) == sorted(ref)
+            for k, v in ref.items():
+                assert np.array_equal(sd[k].cpu().numpy(), v), k

@@ -126,6 +126,77 @@ class ProcessData(Data):
             self.meta_data_df.to_csv(f"{path}/meta.csv", index=False)
 
 
+class TensorProcessData:
+    """Tensor-native ingest: the same `train_data` / `test_data` / `config` surface as ProcessData, built
+    from id tensors without a DataFrame.  At 1e8-1e9 rows the pandas copies of the reference (dataset.py:162,240)
+    dominate start-up and host memory; here ids go straight to int32 in HBM.
+
+    user_ids, item_ids : (N,) integer tensors, CPU or GPU, dense ids 0..n-1
+    item_metadata      : optional (n_items, M) integer tensor — the metadata ids of every item ((B,M) contract)
+    Split: CPU tensors use the reference's RandomState(42) permutation (identical rows to ProcessData); GPU tensors are
+    split on the device with a seeded torch.randperm (same proportions, different rows — one-time ingest, not the
+    training path)."""
+
+    def __init__(self, user_ids, item_ids, n_users=None, n_items=None, item_metadata=None, metadata_names=None,
+                 split_ratio=0.8, dynamic_neg_sampling=False):
+        assert user_ids.dim() == 1 and user_ids.shape == item_ids.shape
+        self.dynamic_neg_sampling = dynamic_neg_sampling
+        self.split_ratio = split_ratio
+        N = user_ids.shape[0]
+        self.num_users = int(n_users) if n_users is not None else (int(user_ids.max()) + 1 if N else 0)
+        self.num_items = int(n_items) if n_items is not None else (int(item_ids.max()) + 1 if N else 0)
+        self._users, self._items = user_ids, item_ids
+        self._neg = None
+        if not dynamic_neg_sampling:
+            if user_ids.is_cuda:
+                g = torch.Generator(device=user_ids.device)
+                g.manual_seed(int(np.random.randint(0, 2 ** 31 - 1)))
+                self._neg = torch.randint(0, self.num_items, (N,), device=user_ids.device, dtype=item_ids.dtype,
+                                          generator=g)
+            else:  # the reference's single legacy-stream draw (dataset.py:56-64)
+                self._neg = torch.from_numpy(np.random.randint(low=0, high=self.num_items, size=N)).to(item_ids.dtype)
+        self.item_meta_table = None
+        self.metadata_id_col = None
+        self.metadata_size = {}
+        if item_metadata is not None:
+            tab = item_metadata.cpu().numpy().astype(np.int64)
+            assert tab.shape[0] == self.num_items
+            self.item_meta_table = tab
+            self.metadata_id_col = list(metadata_names) if metadata_names else [f"meta_{m}" for m in range(tab.shape[1])]
+            self.metadata_size = {c: int(tab[:, k].max()) + 1 for k, c in enumerate(self.metadata_id_col)}
+        self.item_to_metadata_map = None
+        self.meta_data_df = None
+
+    def prepare_data(self):
+        N = self._users.shape[0]
+        self.config = {"num_users": self.num_users, "num_items": self.num_items, "num_metadata": self.metadata_size}
+        if self.split_ratio < 1:
+            n_test = int(math.ceil((1 - self.split_ratio) * N))
+            if self._users.is_cuda:
+                g = torch.Generator(device=self._users.device)
+                g.manual_seed(42)
+                perm = torch.randperm(N, device=self._users.device, generator=g)
+            else:
+                perm = torch.from_numpy(np.random.RandomState(42).permutation(N))
+            tr, te = perm[n_test:], perm[:n_test]
+        else:
+            tr = torch.arange(N, device=self._users.device)
+            te = tr[:0]
+        self.train_data, self.test_data = self._rows(tr), self._rows(te)
+        self._users = self._items = self._neg = None  # the split copies are the only ones kept
+
+    def _rows(self, rows):
+        d = {"user_id": self._users[rows], "pos_item_id": self._items[rows]}
+        if self._neg is not None:
+            d["neg_item_id"] = self._neg[rows]
+        if self.item_meta_table is not None and not self._items.is_cuda:  # device streams look metadata up per batch
+            tab = torch.from_numpy(self.item_meta_table).to(self._items.device)
+            d["pos_metadata_id"] = tab[d["pos_item_id"].long()]
+            if self._neg is not None:
+                d["neg_metadata_id"] = tab[d["neg_item_id"].long()]
+        return d
+
+
 def sample_negatives_reference_stream(pos_item_ids: np.ndarray, n_items: int) -> np.ndarray:
     """The dynamic sampler of dataset.py:435-447 as a vectorised walk over the SAME global legacy numpy stream: row k
     takes the next stream value that differs from its own positive.  Scalar `np.random.randint(0, n)` calls consume the

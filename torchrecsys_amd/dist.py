@@ -1,0 +1,108 @@
+# -*- coding: utf-8 -*-
+"""Multi-GPU plumbing (one process per GPU, torch.distributed; backend "nccl" is RCCL over xGMI on ROCm).
+
+The reference is single-process (no collective anywhere).  The data-parallel design of this framework
+(BASELINE.json north_star):
+  * the interaction stream is sharded across ranks — each rank trains on its own rows, no per-step exchange of ids;
+  * embedding tables are replicated and updated locally (no all-to-all, no row exchange: xGMI's per-link bandwidth is
+    ~1/50 of HBM's, so exchanging rows every step would cap 8 GPUs below one GPU's own roofline);
+  * only the dense MLP parameters are kept identical: their gradients live in ONE flat buffer that is all-reduced
+    (SUM, then scaled by 1/world) once per step — 1.45 MB at config c3, 7.9 MB at c5, a single ring collective;
+  * optionally the replicated tables are re-averaged once per epoch (average_tables_).
+Everything here is device-agnostic so the N>1 path is exercised by world_size-2 `gloo` tests on CPU.
+"""
+import torch
+import torch.distributed as dist
+
+
+def world_info():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous [start, end) of `n` rows owned by `rank` (sizes differ by at most one)."""
+    base, rem = divmod(n, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def shard_stream(user_ids, item_ids, rank=None, world=None, by_user=False):
+    """This rank's rows of the interaction stream.  by_user=True partitions by user_id % world (every user row is then
+    owned by exactly one rank — the largest table never drifts between replicas)."""
+    if rank is None:
+        rank, world = world_info()
+    if world == 1:
+        return user_ids, item_ids
+    if by_user:
+        keep = (user_ids % world) == rank
+        return user_ids[keep], item_ids[keep]
+    s, e = shard_bounds(user_ids.shape[0], rank, world)
+    return user_ids[s:e], item_ids[s:e]
+
+
+class FlatGradBucket:
+    """Dense parameters' gradients as views of one contiguous buffer, so a step needs ONE all-reduce."""
+
+    def __init__(self, params):
+        self.params = [p for p in params]
+        n = sum(p.numel() for p in self.params)
+        ref = self.params[0]
+        self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
+        self.views = []
+        o = 0
+        for p in self.params:
+            v = self.flat[o:o + p.numel()].view_as(p)
+            self.views.append(v)
+            o += p.numel()
+
+    def grad_of(self, p):
+        for q, v in zip(self.params, self.views):
+            if q is p:
+                return v
+        raise KeyError("parameter not in bucket")
+
+    def allreduce_mean_(self, group=None, async_op=False):
+        """SUM over ranks, then 1/world: every replica applies the gradient of the global batch mean."""
+        rank, world = world_info()
+        if world == 1:
+            return None
+        work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        if async_op:
+            return work
+        self.flat.mul_(1.0 / world)
+        return None
+
+    def finish_(self, work):
+        if work is not None:
+            work.wait()
+            self.flat.mul_(1.0 / world_info()[1])
+
+
+def average_tables_(tables, group=None):
+    """Replace every replicated table by its mean over ranks (periodic re-synchronisation of embedding replicas)."""
+    rank, world = world_info()
+    if world == 1:
+        return
+    for t in tables:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        t.mul_(1.0 / world)
+
+
+def broadcast_(tensors, src=0, group=None):
+    """Initial weights from rank 0 so that every replica starts identical."""
+    rank, world = world_info()
+    if world == 1:
+        return
+    for t in tensors:
+        dist.broadcast(t, src=src, group=group)
+
+
+def allreduce_scalar_sum(values, device):
+    """Sum of a few host scalars over ranks (epoch loss / AUC counters)."""
+    rank, world = world_info()
+    t = torch.tensor(values, dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.tolist()

@@ -99,6 +99,7 @@ class SparseScorerTrainer:
         self.grad_rows = torch.empty((self.R, batch_capacity, self.D), dtype=torch.float32, device=dev)
         self.grad_lin = torch.empty((self.R, batch_capacity), dtype=torch.float32, device=dev)
         self.err = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.kernel_events = None  # bench.py: {"kernel name": [(start_event, end_event), ...]} on the launch stream
         self.row_state = {}
         if self.kind in ("sparse_adam", "adagrad"):
             self.row_state = {id(p): RowState(p) for p in self.params}
@@ -120,13 +121,23 @@ class SparseScorerTrainer:
         Bt, keep = ops.make_batch(ids["user"], ids["pos"], ids["neg"], ids.get("pos_meta"), ids.get("neg_meta"),
                                   self.err)
         gr, gl = self._views(B)
+        ev = self.kernel_events
+        if ev is not None:
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record()
         ops.score_fwd_bwd(net.NET, T, Bt, B, self.D, self.M, self.dev, loss_slot, auc_slot, want_scores=False,
                           grad_rows=gr, grad_lin=gl)
+        if ev is not None:
+            e1.record()
         if self.kind == "sgd":
             groups = [_group_of(self.opt, p) for p in self.params]
             lrs = {g["lr"] for g in groups}
             if len(lrs) == 1:
                 ops.score_sgd_update(net.NET, T, Bt, gr, gl, lrs.pop())
+                if ev is not None:
+                    e2.record()
+                    ev.setdefault("score_kernel<fwd_bwd>", []).append((e0, e1))
+                    ev.setdefault("score_sgd_update_kernel", []).append((e1, e2))
             else:
                 self._per_table(ids, gr, gl, lambda p, idx, vals, ld: ops.rows_scatter_add(
                     p.data, idx, vals, -_group_of(self.opt, p)["lr"], ld=ld))

@@ -69,6 +69,34 @@ class TorchRecSys(torch.nn.Module):
                  rng: str = 'reference',
                  seed: int = 0):
         super().__init__()
+        data_processor = ProcessData(dataset=dataset, user_id_col=user_id_col, item_id_col=item_id_col,
+                                     metadata_id_col=metadata_id_col, split_ratio=split_ratio,
+                                     dynamic_neg_sampling=dynamic_neg_sampling)
+        self._setup(data_processor, metadata_id_col, n_factors, net_type, dynamic_neg_sampling, use_amp, use_cuda,
+                    debug, path, hidden_layers, use_batch_norm, rng, seed)
+
+    @classmethod
+    def from_tensors(cls, user_ids, item_ids, n_users=None, n_items=None, item_metadata=None, metadata_names=None,
+                     n_factors=80, net_type='linear', split_ratio=0.8, dynamic_neg_sampling=False, use_amp=False,
+                     use_cuda=False, debug=False, path='./', hidden_layers=None, use_batch_norm=True, rng=None,
+                     seed=0):
+        """Tensor-native ingest (no DataFrame): id tensors on the CPU or already in HBM.  GPU tensors default to
+        rng='device' (stream resident in HBM, on-device shuffle and sampler)."""
+        from .dataset.dataset import TensorProcessData
+        self = cls.__new__(cls)
+        torch.nn.Module.__init__(self)
+        dp = TensorProcessData(user_ids, item_ids, n_users, n_items, item_metadata, metadata_names, split_ratio,
+                               dynamic_neg_sampling)
+        if rng is None:
+            rng = 'device' if user_ids.is_cuda else 'reference'
+        if user_ids.is_cuda and rng != 'device':
+            raise ValueError("GPU-resident id tensors require rng='device'")
+        self._setup(dp, dp.metadata_id_col, n_factors, net_type, dynamic_neg_sampling, use_amp, use_cuda, debug, path,
+                    hidden_layers, use_batch_norm, rng, seed)
+        return self
+
+    def _setup(self, data_processor, metadata_id_col, n_factors, net_type, dynamic_neg_sampling, use_amp, use_cuda,
+               debug, path, hidden_layers, use_batch_norm, rng, seed):
         assert rng in ('reference', 'device'), 'rng must be "reference" or "device"'
         self.path = path
         self.dynamic_neg_sampling = dynamic_neg_sampling
@@ -77,16 +105,13 @@ class TorchRecSys(torch.nn.Module):
         self.rng = rng
         self.seed = seed
         self.grad_scaler = None  # bf16 GEMM inputs with fp32 accumulation need no loss scaling
-
-        self.data_processor = ProcessData(dataset=dataset, user_id_col=user_id_col, item_id_col=item_id_col,
-                                          metadata_id_col=metadata_id_col, split_ratio=split_ratio,
-                                          dynamic_neg_sampling=self.dynamic_neg_sampling)
+        self.data_processor = data_processor
         self.data_processor.prepare_data()
         self.config = self.data_processor.config
         self.n_users = self.config.get('num_users')
         self.n_items = self.config.get('num_items')
         self.metadata_size = self.config.get('num_metadata')
-        self.metadata_name = metadata_id_col if hasattr(self.data_processor, 'metadata_id_col') else None
+        self.metadata_name = metadata_id_col if getattr(self.data_processor, 'metadata_id_col', None) else None
         self.n_factors = n_factors
         self.net_type = net_type
         self.use_metadata = True if self.metadata_name else False
@@ -193,24 +218,17 @@ class TorchRecSys(torch.nn.Module):
         return SparseScorerTrainer(self.net, optimizer, batch_size)
 
     # ------------------------------------------------------------------------------------------------ fit
+    def make_runner(self, optimizer, batch_size):
+        """The step-level driver fit() is built on (bench.py times exactly this object)."""
+        return FitRunner(self, optimizer, batch_size)
+
     def fit(self, optimizer, epochs=10, batch_size=512, profile_epochs: int = 0):
         """Fits the model (reference model.py:203-288).  Per step: [shuffle slice + negative sampling] -> fused
         gather + scoring + hinge + backward -> sparse-row optimiser update; the loss stays on the device and is
         read back once per epoch (the reference syncs every step, model.py:200)."""
-        dev = _device()
-        data = self.data_processor.train_data
-        n_train = data['user_id'].shape[0]
-        loader = FastDataLoader(data=data, batch_size=batch_size, shuffle=True,
-                                dynamic_neg_sampling=self.dynamic_neg_sampling, n_items=self.n_items,
-                                item_to_metadata_map=self.data_processor.item_meta_table,
-                                metadata_id_cols=self.metadata_name)
-        num_batches = loader.num_batches
-        trainer = self._make_trainer(optimizer, min(batch_size, max(n_train, 1)))
-        loss_sums = torch.zeros(max(num_batches, 1), dtype=torch.float32, device=dev)
-
+        runner = self.make_runner(optimizer, batch_size)
         for epoch in range(epochs):
             self.net = self.net.train()
-            loss_sums.zero_()
             prof = None
             if profile_epochs > 0 and epoch == 0:
                 print(f"\n--- Starting Profiling for Epoch {epoch+1} ---")
@@ -218,34 +236,13 @@ class TorchRecSys(torch.nn.Module):
                                                           torch.profiler.ProfilerActivity.CUDA],
                                               record_shapes=True, profile_memory=True, with_stack=True)
                 prof.__enter__()
-            if num_batches > 0:
-                if self.rng == 'reference':
-                    iter(loader)  # reshuffle: one torch.randperm per epoch (dataset.py:369-373)
-                    ep = self._host_epoch(data, loader)
-                    for b in range(num_batches):
-                        s, e = b * batch_size, min((b + 1) * batch_size, n_train)
-                        trainer.step({k: v[s:e] for k, v in ep.items()}, loss_sums[b:b + 1])
-                else:
-                    st = self._device_stream('train')
-                    ge = self._fit_epochs_done
-                    shuffle_key, sample_seed = _mix64(self.seed, 2 * ge + 1), _mix64(self.seed, 2 * ge + 2)
-                    for b in range(num_batches):
-                        s, e = b * batch_size, min((b + 1) * batch_size, n_train)
-                        ids = ops.batch_prepare(st['user'], st['pos'], st['neg'], shuffle_key, s, e - s, self.n_items,
-                                                sample_seed, s, st['item_meta'])
-                        trainer.step(ids, loss_sums[b:b + 1])
-            self._fit_epochs_done += 1
-            sums = loss_sums.cpu().numpy()  # the one device->host sync of the epoch
-            trainer.check_errors()
+            runner.begin_epoch()
+            runner.run_steps(runner.num_batches)
+            avg_loss = runner.end_epoch()
             if prof is not None:
                 prof.__exit__(None, None, None)
                 print("--- Profiler Results (First Epoch) ---")
                 print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=20))
-            total_loss = 0.0
-            for b in range(num_batches):
-                nb = min((b + 1) * batch_size, n_train) - b * batch_size
-                total_loss += float(np.float32(sums[b]) / np.float32(nb))
-            avg_loss = total_loss / num_batches if num_batches > 0 else 0
             print(f'|--- Epoch {epoch+1}/{epochs} --- Training Loss: {avg_loss:.4f}')
 
     # ------------------------------------------------------------------------------------------------ evaluate
@@ -305,3 +302,72 @@ class TorchRecSys(torch.nn.Module):
         if k <= 0:
             return torch.empty(0, dtype=torch.int64)
         return ops.topk(scores, k).cpu()
+
+
+class FitRunner:
+    """One training run at a fixed batch size: owns the optimiser plan, the staging buffers and the per-epoch batch
+    feed.  begin_epoch() -> run_steps(k) (any number of calls) -> end_epoch()."""
+
+    def __init__(self, model, optimizer, batch_size):
+        self.m = model
+        self.batch_size = batch_size
+        self.dev = _device()
+        self.data = model.data_processor.train_data
+        self.n_train = self.data['user_id'].shape[0]
+        self.loader = FastDataLoader(data=self.data, batch_size=batch_size, shuffle=True,
+                                     dynamic_neg_sampling=model.dynamic_neg_sampling, n_items=model.n_items,
+                                     item_to_metadata_map=model.data_processor.item_meta_table,
+                                     metadata_id_cols=model.metadata_name) if model.rng == 'reference' else None
+        self.num_batches = int(math.ceil(self.n_train / batch_size)) if self.n_train > 0 else 0
+        self.trainer = model._make_trainer(optimizer, min(batch_size, max(self.n_train, 1)))
+        self.loss_sums = torch.zeros(max(self.num_batches, 1), dtype=torch.float32, device=self.dev)
+        self.next_batch = 0
+        self.ep = None
+        self.prep_out = None
+
+    def begin_epoch(self):
+        m = self.m
+        self.loss_sums.zero_()
+        self.next_batch = 0
+        if self.num_batches == 0:
+            return
+        if m.rng == 'reference':
+            iter(self.loader)  # reshuffle: one torch.randperm per epoch (dataset.py:369-373)
+            self.ep = m._host_epoch(self.data, self.loader)
+        else:
+            self.st = m._device_stream('train')
+            ge = m._fit_epochs_done
+            self.shuffle_key, self.sample_seed = _mix64(m.seed, 2 * ge + 1), _mix64(m.seed, 2 * ge + 2)
+
+    def run_steps(self, k):
+        """Run the next k steps of the current epoch (stops at the epoch's end).  Returns the number of steps run."""
+        m, B = self.m, self.batch_size
+        done = 0
+        while done < k and self.next_batch < self.num_batches:
+            b = self.next_batch
+            s, e = b * B, min((b + 1) * B, self.n_train)
+            if m.rng == 'reference':
+                ids = {key: v[s:e] for key, v in self.ep.items()}
+            else:
+                st = self.st
+                out = self.prep_out if (self.prep_out is not None and e - s == B) else None
+                ids = ops.batch_prepare(st['user'], st['pos'], st['neg'], self.shuffle_key, s, e - s, m.n_items,
+                                        self.sample_seed, s, st['item_meta'], out)
+                if e - s == B:
+                    self.prep_out = ids
+            self.trainer.step(ids, self.loss_sums[b:b + 1])
+            self.next_batch += 1
+            done += 1
+        return done
+
+    def end_epoch(self):
+        """Sync once, check the id-range flag, return the reference's epoch loss (unweighted mean of batch means)."""
+        m, B = self.m, self.batch_size
+        m._fit_epochs_done += 1
+        sums = self.loss_sums.cpu().numpy()
+        self.trainer.check_errors()
+        total = 0.0
+        for b in range(self.next_batch):
+            nb = min((b + 1) * B, self.n_train) - b * B
+            total += float(np.float32(sums[b]) / np.float32(nb))
+        return total / self.next_batch if self.next_batch > 0 else 0
