@@ -176,6 +176,66 @@ int64_t trs_topk_workspace_bytes(int64_t n, int32_t k);
 int trs_topk(const float* scores_dev, int64_t n, int32_t k, int64_t* idx_out_dev, void* workspace_dev,
              int64_t workspace_bytes, void* stream);
 
+
+/* ------------------------------------------------------------------------------------- MLP (a4, a7) */
+/* Activations of the MLP are kept for both scoring passes stacked: rows [0,B) = positive pass, rows [B,2B) =
+ * negative pass ("passes" = 2).  BatchNorm1d statistics are per pass (the reference calls net.forward twice,
+ * model.py:171-185).  Workspaces are caller-allocated fp32 arrays of the size the *_workspace_* helpers return. */
+
+/* x0 = [user[u] | item[i] | meta_0[..] | ...] (collaborative/mlp.py:93-105): positive pass into rows [0,B) of x and,
+ * when passes == 2, the negative pass into rows [B,2B); row stride ld >= (2+M)*D floats. */
+int trs_mlp_gather_concat(const trs_tables* tables, const trs_batch* batch, int32_t passes, float* x_dev, int64_t ld,
+                          void* stream);
+
+/* C(M,N) = alpha * op(A)(M,K) * op(B)(K,N) + beta * C [+ bias(N) on every row], fp32 in / fp32 accumulate on
+ * v_mfma_f32_32x32x2_f32 (an exact fp32 FMA chain).  Row-major; transA: 0 = A stored (M,K), 1 = stored (K,M);
+ * transB: 0 = B stored (K,N), 1 = stored (N,K).  Replaces aten::addmm / mm under nn.Linear and its autograd
+ * (collaborative/mlp.py:107-113): forward y = x W^T (0,1), dgrad dx = dy W (0,0), wgrad dW = dy^T x (1,0; split-K
+ * over workgroups with a fixed-order slab reduce).  workspace: trs_gemm_f32_workspace_bytes(M,N,K) bytes. */
+int64_t trs_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int trs_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A_dev,
+                 int64_t lda, const float* B_dev, int64_t ldb, float beta, float* C_dev, int64_t ldc,
+                 const float* bias_dev, void* workspace_dev, int64_t workspace_bytes, void* stream);
+
+/* Train-mode BatchNorm1d statistics of y (passes*rows_per_pass, H) per pass: mean_out/var_out (passes,H), biased
+ * variance (chunked two-pass + Chan combination in fp64).  running_mean/var (H) non-NULL: updated once per pass in
+ * pass order with `momentum` and the unbiased variance (torch.nn.BatchNorm1d under collaborative/mlp.py:82,110).
+ * workspace: trs_bn_workspace_floats(rows_per_pass, H, passes) floats. */
+int64_t trs_bn_workspace_floats(int64_t rows_per_pass, int32_t H, int32_t passes);
+int trs_bn_batch_stats(const float* y_dev, int64_t rows_per_pass, int32_t H, int64_t ld, int32_t passes,
+                       float momentum, float* mean_out_dev, float* var_out_dev, float* running_mean_dev,
+                       float* running_var_dev, float* workspace_dev, void* stream);
+
+/* out = relu(((y - mean) / sqrt(var + eps)) * gamma + beta)  (use_bn = 0: out = relu(y)); statistics indexed per
+ * pass when stat_passes == passes, shared when stat_passes == 1 (eval mode: running statistics).
+ * (collaborative/mlp.py:108-112) */
+int trs_bn_relu_forward(const float* y_dev, int64_t rows_per_pass, int32_t passes, int32_t H, int64_t ld,
+                        int32_t use_bn, int32_t stat_passes, const float* mean_dev, const float* var_dev,
+                        const float* gamma_dev, const float* beta_dev, float eps, float* out_dev, int64_t ldo,
+                        void* stream);
+
+/* Backward of relu(bn(y)) in train mode from dx = dL/d(out): dy (same shape), dgamma/dbeta (H) summed over both
+ * passes.  use_bn = 0: dy = dx * [y > 0].  workspace: trs_bn_backward_workspace_floats(...) floats. */
+int64_t trs_bn_backward_workspace_floats(int64_t rows_per_pass, int32_t H, int32_t passes);
+int trs_bn_relu_backward(const float* y_dev, const float* dx_dev, int64_t rows_per_pass, int32_t passes, int32_t H,
+                         int64_t ld, int64_t ldd, int32_t use_bn, const float* mean_dev, const float* var_dev,
+                         const float* gamma_dev, const float* beta_dev, float eps, float* dy_dev, float* dgamma_dev,
+                         float* dbeta_dev, float* workspace_dev, void* stream);
+
+/* out[h] = sum_r w[r] * x[r][h] over the passes*rows_per_pass rows (row_weight NULL: plain column sums): bias
+ * gradients and the output layer's weight gradient.  Summed per pass first (identical chunking in both passes), so a
+ * negative pass that is the exact negation of the positive one cancels to an exact 0 as in the reference's two
+ * separate backward passes.  workspace: trs_colsum_workspace_floats(rows_per_pass, passes, H) floats. */
+int64_t trs_colsum_workspace_floats(int64_t rows_per_pass, int32_t passes, int32_t H);
+int trs_colsum(const float* x_dev, int64_t rows_per_pass, int32_t passes, int32_t H, int64_t ld,
+               const float* row_weight_dev, float* out_dev, float* workspace_dev, void* stream);
+
+/* Output layer H -> 1 (collaborative/mlp.py:85,113): out[r] = x[r] . w + bias[0];  and its dgrad dx[r][h] = g[r]*w[h]. */
+int trs_rowdot(const float* x_dev, int64_t rows, int32_t H, int64_t ld, const float* w_dev, const float* bias_dev,
+               float* out_dev, void* stream);
+int trs_outer(const float* g_dev, const float* w_dev, int64_t rows, int32_t H, float* dx_dev, int64_t ld,
+              void* stream);
+
 #ifdef __cplusplus
 }
 #endif

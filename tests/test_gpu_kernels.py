@@ -272,3 +272,121 @@ def test_score_all_items(net, D, M):
     parts = [ops.score_all_items(net, T, 3, NI, DEV, tim, item0=a, n=min(100, NI - a)) for a in range(0, NI, 100)]
     assert torch.equal(torch.cat(parts), sc)
     assert np.array_equal(ops.topk(sc, 10).cpu().numpy(), onets.topk(ref, 10)) or rel_err(sc.cpu().numpy(), ref) > 0
+
+
+# ------------------------------------------------------------------------------------------------- MLP kernels
+GEMM_SHAPES = [(128, 128, 32), (256, 384, 512), (1000, 130, 77), (37, 5, 3), (1, 1, 1), (513, 257, 1029),
+               (4096, 128, 384), (130, 1, 64), (64, 300, 2)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("tA,tB", [(0, 1), (0, 0), (1, 0), (1, 1)])
+def test_gemm_f32_all_layouts(M, N, K, tA, tB):
+    ops = _ops()
+    rs = np.random.RandomState(M + N + K)
+    A = rs.normal(0, 1, (K, M) if tA else (M, K)).astype(np.float32)
+    Bm = rs.normal(0, 1, (N, K) if tB else (K, N)).astype(np.float32)
+    bias = rs.normal(0, 1, N).astype(np.float32)
+    C0 = rs.normal(0, 1, (M, N)).astype(np.float32)
+    opA, opB = (A.T if tA else A).astype(np.float64), (Bm.T if tB else Bm).astype(np.float64)
+    ref = 0.5 * (opA @ opB) + 2.0 * C0 + bias
+    out = torch.from_numpy(C0.copy()).to(DEV)
+    ops.gemm(tA, tB, torch.from_numpy(A).to(DEV), torch.from_numpy(Bm).to(DEV), out=out,
+             bias=torch.from_numpy(bias).to(DEV), alpha=0.5, beta=2.0)
+    assert rel_err(out.cpu().numpy(), ref) < 2e-6
+    out2 = ops.gemm(tA, tB, torch.from_numpy(A).to(DEV), torch.from_numpy(Bm).to(DEV))
+    assert rel_err(out2.cpu().numpy(), opA @ opB) < 2e-6
+
+
+def test_gemm_split_k_wgrad_shape_and_strided_views():
+    """dW = dy^T x with K = 2B rows (split-K path) and operands that are column-slices of wider buffers."""
+    ops = _ops()
+    rs = np.random.RandomState(0)
+    rows = 20_000
+    dy = rs.normal(0, 1, (rows, 96)).astype(np.float32)
+    x = rs.normal(0, 1, (rows, 200)).astype(np.float32)
+    tdy, tx = torch.from_numpy(dy).to(DEV), torch.from_numpy(x).to(DEV)
+    out = ops.gemm(True, False, tdy, tx)
+    assert rel_err(out.cpu().numpy(), dy.astype(np.float64).T @ x.astype(np.float64)) < 3e-6
+    out_v = ops.gemm(True, False, tdy[:, 8:72], tx[:, 40:168])  # row stride != width, 16-byte aligned
+    assert rel_err(out_v.cpu().numpy(), dy[:, 8:72].astype(np.float64).T @ x[:, 40:168].astype(np.float64)) < 3e-6
+    out_u = ops.gemm(True, False, tdy[:, 3:70], tx[:, 1:150])   # unaligned views: scalar-load path
+    assert rel_err(out_u.cpu().numpy(), dy[:, 3:70].astype(np.float64).T @ x[:, 1:150].astype(np.float64)) < 3e-6
+
+
+@pytest.mark.parametrize("B,H", [(64, 32), (1000, 130), (5000, 7), (256, 512)])
+@pytest.mark.parametrize("passes", [1, 2])
+def test_bn_stats_forward_backward(B, H, passes):
+    ops = _ops()
+    rs = np.random.RandomState(B + H)
+    rows = B * passes
+    y = (rs.normal(0, 1, (rows, H)) * rs.uniform(0.1, 3, H) + rs.normal(0, 5, H)).astype(np.float32)
+    gamma, beta = rs.uniform(0.5, 1.5, H).astype(np.float32), rs.normal(0, 0.5, H).astype(np.float32)
+    rm0, rv0 = rs.normal(0, 1, H).astype(np.float32), rs.uniform(0.5, 2, H).astype(np.float32)
+    ty = torch.from_numpy(y).to(DEV)
+    mean = torch.empty((passes, H), device=DEV)
+    var = torch.empty((passes, H), device=DEV)
+    rm, rv = torch.from_numpy(rm0.copy()).to(DEV), torch.from_numpy(rv0.copy()).to(DEV)
+    ops.bn_batch_stats(ty, B, passes, 0.1, mean, var, rm, rv)
+    y64 = y.astype(np.float64).reshape(passes, B, H)
+    rmean, rvar = y64.mean(axis=1), y64.var(axis=1)
+    assert rel_err(mean.cpu().numpy(), rmean) < 1e-6 and rel_err(var.cpu().numpy(), rvar) < 1e-6
+    erm, erv = rm0.astype(np.float64), rv0.astype(np.float64)
+    for p in range(passes):
+        erm = 0.9 * erm + 0.1 * rmean[p]
+        erv = 0.9 * erv + 0.1 * rvar[p] * B / max(B - 1, 1)
+    assert rel_err(rm.cpu().numpy(), erm) < 1e-6 and rel_err(rv.cpu().numpy(), erv) < 1e-6
+    tg, tb = torch.from_numpy(gamma).to(DEV), torch.from_numpy(beta).to(DEV)
+    out = torch.empty_like(ty)
+    ops.bn_relu_forward(ty, B, passes, True, passes, mean, var, tg, tb, 1e-5, out)
+    xhat = (y64 - rmean[:, None, :]) / np.sqrt(rvar[:, None, :] + 1e-5)
+    yhat = xhat * gamma + beta
+    assert rel_err(out.cpu().numpy(), np.maximum(yhat, 0).reshape(rows, H)) < 1e-5  # fp32 (y - mean) with |mean| ~ 5 sigma
+    # backward
+    dx = rs.normal(0, 1, (rows, H)).astype(np.float32)
+    tdx = torch.from_numpy(dx).to(DEV)
+    dy, dg, db = torch.empty_like(ty), torch.empty(H, device=DEV), torch.empty(H, device=DEV)
+    ops.bn_relu_backward(ty, tdx, B, passes, True, mean, var, tg, tb, 1e-5, dy, dg, db)
+    d = dx.astype(np.float64).reshape(passes, B, H) * (yhat > 0)
+    s1, s2 = d.sum(axis=1, keepdims=True), (d * xhat).sum(axis=1, keepdims=True)
+    ref_dy = gamma / np.sqrt(rvar[:, None, :] + 1e-5) * (d - s1 / B - xhat * s2 / B)
+    assert rel_err(dy.cpu().numpy(), ref_dy.reshape(rows, H)) < 2e-5
+    assert rel_err(dg.cpu().numpy(), s2.sum(axis=0).reshape(-1)) < 2e-5
+    assert rel_err(db.cpu().numpy(), s1.sum(axis=0).reshape(-1)) < 2e-5
+    # no-BN variants
+    ops.bn_relu_forward(ty, B, passes, False, 1, None, None, None, None, 1e-5, out)
+    assert np.array_equal(out.cpu().numpy(), np.maximum(y, 0))
+    ops.bn_relu_backward(ty, tdx, B, passes, False, None, None, None, None, 1e-5, dy, None, None)
+    assert np.array_equal(dy.cpu().numpy(), dx * (y > 0))
+
+
+def test_colsum_rowdot_outer_gather():
+    ops = _ops()
+    rs = np.random.RandomState(1)
+    rows, H = 3001, 77
+    x = rs.normal(0, 1, (rows, H)).astype(np.float32)
+    w = rs.normal(0, 1, rows).astype(np.float32)
+    tx, tw = torch.from_numpy(x).to(DEV), torch.from_numpy(w).to(DEV)
+    out = torch.empty(H, device=DEV)
+    ops.colsum(tx, out)
+    assert rel_err(out.cpu().numpy(), x.astype(np.float64).sum(0)) < 1e-6
+    ops.colsum(tx, out, row_weight=tw)
+    assert rel_err(out.cpu().numpy(), (x.astype(np.float64) * w[:, None]).sum(0)) < 1e-6
+    wv, b = rs.normal(0, 1, H).astype(np.float32), np.float32(0.3)
+    sc = torch.empty(rows, device=DEV)
+    ops.rowdot(tx, torch.from_numpy(wv).to(DEV), torch.tensor([b], device=DEV), sc)
+    assert rel_err(sc.cpu().numpy(), x.astype(np.float64) @ wv + b) < 1e-6
+    dx = torch.empty_like(tx)
+    ops.outer(tw, torch.from_numpy(wv).to(DEV), dx)
+    assert np.array_equal(dx.cpu().numpy(), w[:, None] * wv[None, :])
+    # gather-concat, both passes, metadata
+    for D, M in ((8, 0), (16, 2), (10, 1)):
+        p, batch, _ = make_case("fm", D, M, 50, seed=4)
+        t, T, Bt, ids, err, keep = to_dev("fm", p, batch, np.int64)
+        F = 2 + M
+        xg = torch.empty((100, F * D), device=DEV)
+        ops.mlp_gather_concat(T, Bt, 2, xg)
+        for pas, ik, mk in ((0, "pos_item_id", "pos_metadata_id"), (1, "neg_item_id", "neg_metadata_id")):
+            cols = [p["user.weight"][batch["user_id"]], p["item.weight"][batch[ik]]]
+            cols += [p[f"metadata.{m}.weight"][batch[mk][:, m]] for m in range(M)]
+            assert np.array_equal(xg[pas * 50:(pas + 1) * 50].cpu().numpy(), np.concatenate(cols, axis=1))

@@ -58,9 +58,10 @@ def dev_ids(net, b):
 
 
 SPARSE_NETS = ["linear", "fm"]
+ALL_NETS = ["linear", "fm", "mlp", "mlp_nobn"]
 
 
-@pytest.mark.parametrize("name", SPARSE_NETS)
+@pytest.mark.parametrize("name", ALL_NETS)
 @pytest.mark.parametrize("M", [0, 1, 3])
 def test_g1_autograd_bridge(name, M):
     """net.forward x2 + hinge_loss + loss.backward() through the HIP autograd Functions == reference autograd."""
@@ -79,12 +80,29 @@ def test_g1_autograd_bridge(name, M):
     assert abs(loss.item() - float(g["loss"])) <= TOL * abs(float(g["loss"]))
     assert float(Metrics().auc_score(pos, neg).item()) == pytest.approx(float(g["auc"]), abs=1e-6)
     ref = sub(g, "grad")
+    is_mlp = name.startswith("mlp")
     for k, p in net.named_parameters():
-        assert p.grad is not None and p.grad.is_sparse, k
-        assert rel_err(p.grad.to_dense().cpu().numpy(), ref[k]) < TOL, k
-    # fused pair forward gives the same scores
-    p2, n2 = net.forward_pair(b)
-    assert torch.equal(p2, pos.detach()) and torch.equal(n2, neg.detach())  # both passes run the same code: bitwise
+        assert p.grad is not None, k
+        gd = p.grad.to_dense() if p.grad.is_sparse else p.grad
+        if name == "mlp" and k.startswith("fcs") and k.endswith("bias"):
+            assert float(gd.abs().max()) < 1e-6  # bias in front of train-mode BN: mathematically zero gradient
+            continue
+        assert rel_err(gd.cpu().numpy(), ref[k]) < (2 * TOL if is_mlp else TOL), k
+    if name == "mlp":  # BatchNorm running statistics after the two training passes (positive first)
+        after = sub(g, "after_fwd")
+        sd = net.state_dict()
+        for k, v in after.items():
+            if "running" in k:
+                assert rel_err(sd[k].cpu().numpy(), v) < TOL, k
+            if "num_batches_tracked" in k:
+                assert int(sd[k]) == int(v) == 2
+        net.eval()  # G6: eval-mode scores use the running statistics
+        pe = net.forward(b, "user_id", "pos_item_id", mk[0])
+        assert rel_err(pe.detach().cpu().numpy(), g["pos_eval"]) < TOL
+        net.train()
+    if not is_mlp:  # fused pair forward gives the same scores (both passes run the same code: bitwise)
+        p2, n2 = net.forward_pair(b)
+        assert torch.equal(p2, pos.detach()) and torch.equal(n2, neg.detach())
 
 
 @pytest.mark.parametrize("name", SPARSE_NETS)
@@ -114,6 +132,44 @@ def test_g2_engine_optimizer_trajectories(name, M, oname):
     if oname == "sparseadam":  # optimizer.state stays truthful
         st = opt.state[net.user.weight]
         assert st["step"] == 3 and st["exp_avg"].shape == net.user.weight.shape
+
+
+@pytest.mark.parametrize("name", ["mlp", "mlp_nobn"])
+@pytest.mark.parametrize("M", [0, 1, 3])
+@pytest.mark.parametrize("oname", ["sgd", "sgdm", "adagrad", "adam"])
+def test_g2_mlp_trainer_trajectories(name, M, oname):
+    """Fused MLP training steps (stacked passes, MFMA GEMMs, per-pass BN) vs the reference's trajectories."""
+    from torchrecsys_amd.mlp_engine import MLPTrainer
+    g = load_golden(f"g2_{name}_M{M}_{oname}.npz")
+    net, b = build_net(name, M, g), golden_batch(g)
+    net.train()
+    ps = list(net.parameters())
+    opt = {"sgd": lambda: torch.optim.SGD(ps, lr=0.05), "sgdm": lambda: torch.optim.SGD(ps, lr=0.05, momentum=0.9),
+           "adagrad": lambda: torch.optim.Adagrad(ps, lr=0.05), "adam": lambda: torch.optim.Adam(ps, lr=0.01)}[oname]()
+    tr = MLPTrainer(net, opt, 64)
+    assert tr.kind == {"sgd": "sgd", "sgdm": "generic", "adagrad": "adagrad", "adam": "sparse_adam"}[oname]
+    ids = dev_ids(net, b)
+    losses = torch.zeros(3, dtype=torch.float32, device=DEV)
+    adaptive = oname in ("adagrad", "adam")
+    for t in range(3):
+        tr.step(ids, losses[t:t + 1])
+        sd = net.state_dict()
+        for k, v in sub(g, f"step{t}").items():
+            if v.dtype != np.float32:
+                continue
+            got = sd[k].cpu().numpy()
+            if adaptive:
+                # adaptive optimisers turn rounding-noise gradients into +-lr steps (in the reference too): compare the
+                # bulk, skip the pure-noise parameters (tests/test_oracle_golden.py explains)
+                if k.endswith("bias") or k.endswith("running_mean"):
+                    continue
+                d = np.abs(got.astype(np.float64) - v) / max(np.abs(v).max(), 1e-12)
+                assert np.quantile(d, 0.95) < (1e-4 if t == 0 else 1e-2), (k, t)
+            else:
+                assert rel_err(got, v) < 5 * TOL, (k, t)
+    tr.check_errors()
+    ltol = 1e-3 if adaptive else 2e-5
+    assert np.allclose(losses.cpu().numpy() / 64, g["losses"], rtol=ltol, atol=1e-6)
 
 
 @pytest.mark.parametrize("name", SPARSE_NETS)
@@ -151,7 +207,7 @@ def run_model(net_type, dyn, g, rng="reference", **kw):
     return model, init, final, top, buf.getvalue()
 
 
-@pytest.mark.parametrize("net_type", SPARSE_NETS)
+@pytest.mark.parametrize("net_type", SPARSE_NETS + ["mlp"])
 @pytest.mark.parametrize("dyn", [False, True])
 def test_g4_end_to_end_fit_evaluate_predict(net_type, dyn):
     g = load_golden(f"g4_{net_type}_{'dyn' if dyn else 'static'}.npz")
@@ -159,14 +215,34 @@ def test_g4_end_to_end_fit_evaluate_predict(net_type, dyn):
     for k, v in sub(g, "init").items():  # seeded construction: bit-identical initial weights
         assert np.array_equal(init[k], v), k
     losses = [float(x) for x in re.findall(r"Training Loss: ([0-9.]+)", txt)]
-    assert losses == pytest.approx(list(g["epoch_losses"]), abs=1.01e-4)  # printed with 4 decimals
+    is_mlp = net_type == "mlp"
+    # printed with 4 decimals.  The MLP trajectory (BatchNorm, 156 steps) amplifies summation-order differences — the
+    # reference itself differs between 1 and 8 BLAS threads, and the numpy oracle deviates from the
+    # golden run by the same 1% (tests/test_oracle_golden.py::test_g4_oracle_end_to_end) — so it is held to 3e-4 (losses) / 0.2 (weights, max-norm; oracle-vs-golden is 0.1).
+    assert losses == pytest.approx(list(g["epoch_losses"]), abs=3e-4 if is_mlp else 1.01e-4)
     for k, v in sub(g, "final").items():
-        assert rel_err(final[k], v) < 2e-5, k  # 78 SGD steps of accumulated fp32 rounding
+        if v.dtype != np.float32:
+            assert int(final[k]) == int(v), k  # BatchNorm num_batches_tracked: two per step
+            continue
+        # 78 SGD steps of accumulated fp32 rounding; the MLP's GEMMs sum in a different order than MKL's
+        if is_mlp and not k.endswith(("user.weight", "item.weight")):
+            continue  # near-zero BN biases etc. have no meaningful relative scale on a chaotic trajectory
+        assert rel_err(final[k], v) < (0.2 if is_mlp else 2e-5), k
     assert isinstance(top, torch.Tensor) and top.dtype == torch.int64 and top.device.type == "cpu"
-    assert np.array_equal(top.numpy(), g["top10_user3"])  # bit-exact top-k (tie-free fixture)
+    if not is_mlp:
+        assert np.array_equal(top.numpy(), g["top10_user3"])  # bit-exact top-k (tie-free fixture)
     if not dyn:
-        assert float(re.findall(r"Testing loss: ([0-9.]+)", txt)[0]) == pytest.approx(float(g["eval_loss"]), abs=1.01e-4)
-        assert float(re.findall(r"Testing auc: ([0-9.]+)", txt)[0]) == pytest.approx(float(g["eval_auc"]), abs=1.01e-4)
+        tol = 2e-3 if is_mlp else 1.01e-4
+        assert float(re.findall(r"Testing loss: ([0-9.]+)", txt)[0]) == pytest.approx(float(g["eval_loss"]), abs=tol)
+        assert float(re.findall(r"Testing auc: ([0-9.]+)", txt)[0]) == pytest.approx(float(g["eval_auc"]), abs=5 * tol)
+    # predict()/evaluate() parity on IDENTICAL weights: load the reference's final state_dict, then the eval-mode scores
+    # of user 3 match to 1e-5 and the top-10 is bit-exact (all three nets)
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sub(g, "final").items()})
+    model.net.eval()
+    sc = model.net.score_all_items(3, model._item_meta_dev())
+    assert rel_err(sc.cpu().numpy(), g["scores_user3"]) < TOL
+    with contextlib.redirect_stdout(io.StringIO()):
+        assert np.array_equal(model.predict(user_id=3, top_k=10).numpy(), g["top10_user3"])
     # same banner / line formats as the reference
     ref_lines = [l for l in str(g["stdout"]).splitlines() if l.strip()]
     got_lines = [l for l in txt.splitlines() if l.strip()]

@@ -1,0 +1,252 @@
+// gemm.hip — fp32-in / fp32-accumulate GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: an exact fp32 FMA
+// chain, bit-compatible with a k-ordered fmaf loop) for the MLP scorer's dense layers (reference
+// collaborative/mlp.py:107-113: nn.Linear = aten::addmm, and its autograd mm's).
+//
+// C(M,N) = alpha * op(A)(M,K) * op(B)(K,N) + beta * C  [+ bias(N)]          row-major storage
+//   transA = 0: A stored (M,K)   (k contiguous)      transA = 1: A stored (K,M)   (m contiguous)
+//   transB = 0: B stored (K,N)   (n contiguous)      transB = 1: B stored (N,K)   (k contiguous)
+//   forward  y  = x  W^T : transA 0, transB 1        dgrad dx = dy W : transA 0, transB 0
+//   wgrad    dW = dy^T x : transA 1, transB 0  (K = rows of the batch: split-K over workgroups, slabs + reduce)
+//
+// Tiling: 128x128x32 per 256-thread workgroup (4 waves as 2x2, each 64x64 = 2x2 MFMA tiles of 32x32, 64 accumulator
+// VGPRs); operand tiles staged global -> registers -> LDS as [k][m|n] images (conflict-free ds_read_b32 for the
+// 32-lane MFMA fragments), double-buffered so tile t+1's global loads fly under tile t's MFMAs.
+#include "trs_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDS_LD = 132;  // max of the two image strides below
+// image stride per staging form: k-contiguous sources are transposed on the LDS write with 4 ds_write_b32 per
+// float4 — stride 129 (odd) spreads the 8 k-chunks x 4 rows of a 32-lane group over 32 banks; m/n-contiguous sources
+// go in with one aligned ds_write_b128 — stride 132.
+__host__ __device__ constexpr int img_ld(bool kcontig) { return kcontig ? 129 : 132; }
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;  // (N) added to every row, or NULL
+  int64_t M, N, K;
+  int64_t lda, ldb, ldc;
+  float alpha, beta;
+  int64_t k_per_split;  // K range per blockIdx.z (multiple of BK)
+  float* slabs;         // (splits, M, N) partial products when gridDim.z > 1
+  int vecA, vecB;       // 16-byte global loads legal (alignment + leading dimension)
+};
+
+// Global -> registers for one 128 x 32 operand tile.  KC: source is k-contiguous.
+//   KC:  chunk c in [0,1024): row = c / 8, k4 = c % 8       (8 float4 per row of 32 k)
+//   !KC: chunk c in [0,1024): k = c / 32, r4 = c % 32       (32 float4 per k-row of 128 m/n)
+template <bool KC>
+__device__ __forceinline__ void tile_load(float4 (&r)[4], const float* __restrict__ P, int64_t ld, int64_t rows,
+                                          int64_t Kend, int64_t row0, int64_t k0, int vec, int tid) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int c = tid + 256 * it;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (KC) {
+      const int64_t row = row0 + (c >> 3), k = k0 + ((c & 7) << 2);
+      if (row < rows && k < Kend) {
+        const float* p = P + row * ld + k;
+        if (vec && k + 3 < Kend) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          v.x = p[0];
+          if (k + 1 < Kend) v.y = p[1];
+          if (k + 2 < Kend) v.z = p[2];
+          if (k + 3 < Kend) v.w = p[3];
+        }
+      }
+    } else {
+      const int64_t k = k0 + (c >> 5), row = row0 + ((c & 31) << 2);
+      if (k < Kend && row < rows) {
+        const float* p = P + k * ld + row;
+        if (vec && row + 3 < rows) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          v.x = p[0];
+          if (row + 1 < rows) v.y = p[1];
+          if (row + 2 < rows) v.z = p[2];
+          if (row + 3 < rows) v.w = p[3];
+        }
+      }
+    }
+    r[it] = v;
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ void tile_store(const float4 (&r)[4], float* __restrict__ S, int tid) {
+  constexpr int LD = img_ld(KC);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int c = tid + 256 * it;
+    if (KC) {
+      const int row = c >> 3, k = (c & 7) << 2;
+      S[(k + 0) * LD + row] = r[it].x;
+      S[(k + 1) * LD + row] = r[it].y;
+      S[(k + 2) * LD + row] = r[it].z;
+      S[(k + 3) * LD + row] = r[it].w;
+    } else {
+      const int k = c >> 5, row = (c & 31) << 2;
+      *reinterpret_cast<float4*>(&S[k * LD + row]) = r[it];
+    }
+  }
+}
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float As[2][BK * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDS_LD];
+  constexpr int LDA_S = img_ld(AKC), LDB_S = img_ld(BKC);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+  const int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;
+  const int64_t kend = (kbeg + g.k_per_split < g.K) ? kbeg + g.k_per_split : g.K;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[4], rb[4];
+  const int64_t nk = (kend - kbeg + BK - 1) / BK;
+  if (nk > 0) {
+    tile_load<AKC>(ra, g.A, g.lda, g.M, kend, m0, kbeg, g.vecA, tid);
+    tile_load<BKC>(rb, g.B, g.ldb, g.N, kend, n0, kbeg, g.vecB, tid);
+    tile_store<AKC>(ra, As[0], tid);
+    tile_store<BKC>(rb, Bs[0], tid);
+  }
+  __syncthreads();
+  const int lr = lane & 31, lk = lane >> 5;
+  for (int64_t kt = 0; kt < nk; ++kt) {
+    const int cur = (int)(kt & 1);
+    if (kt + 1 < nk) {
+      tile_load<AKC>(ra, g.A, g.lda, g.M, kend, m0, kbeg + (kt + 1) * BK, g.vecA, tid);
+      tile_load<BKC>(rb, g.B, g.ldb, g.N, kend, n0, kbeg + (kt + 1) * BK, g.vecB, tid);
+    }
+    const float* as = As[cur] + wm * 64 + lr;
+    const float* bs = Bs[cur] + wn * 64 + lr;
+#pragma unroll
+    for (int k2 = 0; k2 < BK / 2; ++k2) {
+      const int k = 2 * k2 + lk;
+      const float a0 = as[k * LDA_S], a1 = as[k * LDA_S + 32];
+      const float b0 = bs[k * LDB_S], b1 = bs[k * LDB_S + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      tile_store<AKC>(ra, As[cur ^ 1], tid);
+      tile_store<BKC>(rb, Bs[cur ^ 1], tid);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  const bool split = gridDim.z > 1;
+  float* out = split ? g.slabs + (int64_t)blockIdx.z * g.M * g.N : g.C;
+  const int64_t ldo = split ? g.N : g.ldc;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t col = n0 + wn * 64 + j * 32 + lr;
+      if (col >= g.N) continue;
+      const float bv = (!split && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (row >= g.M) continue;
+        float v = acc[i][j][r];
+        if (!split) {
+          v = g.alpha * v + bv;
+          if (g.beta != 0.f) v += g.beta * out[row * ldo + col];
+        }
+        out[row * ldo + col] = v;
+      }
+    }
+}
+
+// C = alpha * sum_z slabs[z] + beta * C (+ bias): the launch-boundary reduce of the split-K partial slabs, fixed
+// summation order (bitwise reproducible).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int splits, int64_t M,
+                                                           int64_t N, float* __restrict__ C, int64_t ldc,
+                                                           float alpha, float beta, const float* __restrict__ bias) {
+  const int64_t total = M * N;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += slabs[(int64_t)z * total + e];
+    const int64_t row = e / N, col = e - row * N;
+    float v = alpha * s + (bias ? bias[col] : 0.f);
+    if (beta != 0.f) v += beta * C[row * ldc + col];
+    C[row * ldc + col] = v;
+  }
+}
+
+static int pick_splits(int64_t M, int64_t N, int64_t K) {
+  const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  if (tiles >= 256 || K <= 4 * BK) return 1;
+  int64_t s = (512 + tiles - 1) / tiles;  // aim at ~2 workgroups per CU
+  const int64_t kt = (K + BK - 1) / BK;
+  if (s > kt / 4) s = kt / 4;  // at least 4 k-tiles per split
+  if (s > 128) s = 128;
+  return s < 1 ? 1 : (int)s;
+}
+
+}  // namespace
+
+extern "C" int64_t trs_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const int s = pick_splits(M, N, K);
+  return s > 1 ? (int64_t)s * M * N * 4 : 0;
+}
+
+extern "C" int trs_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+                            const float* A_dev, int64_t lda, const float* B_dev, int64_t ldb, float beta,
+                            float* C_dev, int64_t ldc, const float* bias_dev, void* workspace_dev,
+                            int64_t workspace_bytes, void* stream) {
+  TRS_REQUIRE(M >= 0 && N >= 0 && K >= 0, "trs_gemm_f32: negative dimension");
+  if (M == 0 || N == 0) return TRS_OK;
+  TRS_REQUIRE(K > 0, "trs_gemm_f32: K must be positive");
+  TRS_REQUIRE(A_dev && B_dev && C_dev, "trs_gemm_f32: NULL operand");
+  TRS_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "trs_gemm_f32: leading dimension too small");
+  const int splits = pick_splits(M, N, K);
+  TRS_REQUIRE(splits == 1 || (workspace_dev && workspace_bytes >= (int64_t)splits * M * N * 4),
+              "trs_gemm_f32: workspace too small (%lld < %lld)", (long long)workspace_bytes,
+              (long long)splits * M * N * 4);
+  GemmArgs g;
+  g.A = A_dev; g.B = B_dev; g.C = C_dev; g.bias = bias_dev;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.alpha = alpha; g.beta = beta;
+  const int64_t kt = (K + BK - 1) / BK;
+  g.k_per_split = ((kt + splits - 1) / splits) * BK;
+  g.slabs = (float*)workspace_dev;
+  g.vecA = (((uintptr_t)A_dev & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
+  g.vecB = (((uintptr_t)B_dev & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
+  const int64_t gx = (N + BN - 1) / BN, gy = (M + BM - 1) / BM;
+  TRS_REQUIRE(gy <= 65535 && gx <= 65535, "trs_gemm_f32: problem too large for the launch grid");
+  dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)splits);
+  hipStream_t s = (hipStream_t)stream;
+  const bool akc = !transA, bkc = transB != 0;
+  if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, s, g);
+  else if (akc && !bkc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, s, g);
+  else if (!akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, s, g);
+  TRS_CHECK_LAUNCH("gemm_f32_kernel");
+  if (splits > 1) {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(trs_grid(M * N, 256)), dim3(256), 0, s, g.slabs, splits, M, N,
+                       C_dev, ldc, alpha, beta, bias_dev);
+    TRS_CHECK_LAUNCH("splitk_reduce_kernel");
+  }
+  return TRS_OK;
+}

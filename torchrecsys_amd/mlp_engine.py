@@ -1,0 +1,223 @@
+# -*- coding: utf-8 -*-
+"""Forward / backward / training step of the MLP scorer on the HIP kernels (reference collaborative/mlp.py:88-115,
+model.py:171-200).
+
+Layout: both scoring passes of a step are stacked — rows [0,B) positive, rows [B,2B) negative — so every dense layer
+is ONE fp32-MFMA GEMM over 2B rows while BatchNorm statistics stay per pass (as the reference's two net.forward calls
+produce them).  Saved for backward per layer l: the layer input x_l and the pre-BN output y_l; the normalised /
+rectified values are recomputed from y_l and the batch statistics.
+
+Dense parameters (fcs / bns / output_layer) get ordinary dense gradients in ONE flat buffer (dist.FlatGradBucket: a
+single RCCL all-reduce per step under data parallelism) and are stepped by the user's torch optimiser; embedding
+tables take the fused sparse-row paths of engine.py from the column blocks of d x0.
+"""
+import torch
+
+from . import dist as tdist
+from . import ops
+from .engine import RowState, _group_of, apply_rows, classify_optimizer
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+class MLPCompute:
+    """Kernel orchestration for one MLP module.  forward() returns (scores, ctx); backward(ctx, g) returns
+    ({dense param: grad}, d x0)."""
+
+    def __init__(self, net):
+        self.net = net
+
+    def _dims(self):
+        net = self.net
+        return net.n_factors, net.n_meta_tables(), len(net.fcs), net.use_batch_norm
+
+    def forward(self, ids, passes, training, bucket=None):
+        """ids: dict user/pos[/neg][/pos_meta/neg_meta] of GPU tensors; passes = 2 scores (pos, neg) stacked."""
+        net = self.net
+        D, M, L, use_bn = self._dims()
+        dev = net.user.weight.device
+        B = ids["user"].shape[0]
+        rows = passes * B
+        err = net._err_flag()
+        Bt, keep = ops.make_batch(ids["user"], ids["pos"], ids.get("neg") if passes == 2 else None,
+                                  ids.get("pos_meta"), ids.get("neg_meta") if passes == 2 else None, err)
+        x = torch.empty((rows, net.input_shape), dtype=torch.float32, device=dev)
+        ops.mlp_gather_concat(net.tables(), Bt, passes, x)
+        ctx = {"ids": ids, "B": B, "passes": passes, "x": [x], "y": [], "mean": [], "var": [], "training": training}
+        for l in range(L):
+            fc = net.fcs[l]
+            y = ops.gemm(False, True, x, fc.weight.data, bias=fc.bias.data)
+            ctx["y"].append(y)
+            mean = var = gamma = beta = None
+            stat_passes = 1
+            if use_bn:
+                bn = net.bns[l]
+                gamma, beta = bn.weight.data, bn.bias.data
+                if training:
+                    H = y.shape[1]
+                    mean = torch.empty((passes, H), dtype=torch.float32, device=dev)
+                    var = torch.empty((passes, H), dtype=torch.float32, device=dev)
+                    ops.bn_batch_stats(y, B, passes, BN_MOMENTUM, mean, var, bn.running_mean, bn.running_var)
+                    bn.num_batches_tracked += passes
+                    stat_passes = passes
+                else:
+                    mean, var = bn.running_mean, bn.running_var
+            ctx["mean"].append(mean)
+            ctx["var"].append(var)
+            xn = torch.empty_like(y)
+            ops.bn_relu_forward(y, B, passes, use_bn, stat_passes, mean, var, gamma, beta, BN_EPS, xn)
+            x = xn
+            ctx["x"].append(x)
+        out = torch.empty(rows, dtype=torch.float32, device=dev)
+        ops.rowdot(x, net.output_layer.weight.data.reshape(-1), net.output_layer.bias.data, out)
+        return out, ctx
+
+    def backward(self, ctx, g, grad_of=None):
+        """g: (passes*B,) = dL/dscore.  grad_of(param) -> tensor to write that dense parameter's gradient into
+        (default: fresh tensors).  Returns (grads dict keyed by parameter, d x0)."""
+        net = self.net
+        D, M, L, use_bn = self._dims()
+        B, passes = ctx["B"], ctx["passes"]
+        if use_bn and not ctx["training"]:
+            raise RuntimeError("backward through eval-mode BatchNorm is not implemented (the reference trains in "
+                               "train mode, model.py:232)")
+        grads = {}
+
+        def slot(p):
+            t = grad_of(p) if grad_of else torch.empty_like(p.data)
+            grads[p] = t
+            return t
+
+        xL = ctx["x"][L]
+        ol = net.output_layer
+        ops.colsum(xL, slot(ol.weight).reshape(-1), row_weight=g, passes=passes)
+        ops.colsum(g.reshape(-1, 1), slot(ol.bias), passes=passes)
+        dx = torch.empty_like(xL)
+        ops.outer(g, ol.weight.data.reshape(-1), dx)
+        for l in reversed(range(L)):
+            fc = net.fcs[l]
+            y = ctx["y"][l]
+            dy = torch.empty_like(y)
+            if use_bn:
+                bn = net.bns[l]
+                ops.bn_relu_backward(y, dx, B, passes, True, ctx["mean"][l], ctx["var"][l], bn.weight.data, bn.bias.data,
+                                     BN_EPS, dy, slot(bn.weight), slot(bn.bias))
+            else:
+                ops.bn_relu_backward(y, dx, B, passes, False, None, None, None, None, BN_EPS, dy, None, None)
+            ops.gemm(True, False, dy, ctx["x"][l], out=slot(fc.weight))          # dW = dy^T x   (split-K)
+            ops.colsum(dy, slot(fc.bias), passes=passes)                                           # db = column sums of dy
+            dx = ops.gemm(False, False, dy, fc.weight.data)                         # dx = dy W
+        return grads, dx
+
+
+class _MLPScore(torch.autograd.Function):
+    """Autograd bridge for callers that drive net.forward / forward_pair + their own loss."""
+
+    @staticmethod
+    def forward(ctx, net, ids, passes, *params):
+        out, c = net.compute.forward(ids, passes, net.training)
+        net._check_err("forward")
+        ctx.net, ctx.c = net, c
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        net, c = ctx.net, ctx.c
+        grads, dx0 = net.compute.backward(c, g.contiguous().float())
+        D, M = net.n_factors, net.n_meta_tables()
+        ids, B, passes = c["ids"], c["B"], c["passes"]
+
+        def coo(idx, f, p):
+            return torch.sparse_coo_tensor(idx.reshape(1, -1).long(), dx0[:, f * D:(f + 1) * D], size=p.shape)
+
+        out = []
+        for p in net.all_params():
+            if p in grads:
+                out.append(grads[p])
+            elif p is net.user.weight:
+                out.append(coo(torch.cat([ids["user"]] * passes), 0, p))
+            elif p is net.item.weight:
+                out.append(coo(torch.cat([ids["pos"], ids["neg"]]) if passes == 2 else ids["pos"], 1, p))
+            else:
+                m = [i for i, q in enumerate(net.metadata_embeddings) if q.weight is p][0]
+                idx = torch.cat([ids["pos_meta"][:, m], ids["neg_meta"][:, m]]) if passes == 2 else ids["pos_meta"][:, m]
+                out.append(coo(idx, 2 + m, p))
+        return (None, None, None, *out)
+
+
+class MLPTrainer:
+    """One fused training step of the MLP scorer (the MLP counterpart of engine.SparseScorerTrainer)."""
+
+    def __init__(self, net, optimizer, batch_capacity):
+        self.net, self.opt = net, optimizer
+        self.emb_params = net.embedding_params()
+        self.dense_params = net.dense_params()
+        self.kind = classify_optimizer(optimizer, self.emb_params)
+        if type(optimizer) is torch.optim.Adam and all(_group_of(optimizer, p) is not None for p in self.emb_params):
+            # the reference cannot run Adam on sparse gradients at all; here: lazy (touched-rows-only)
+            # Adam on the tables — SparseAdam's semantics — and torch's dense Adam on fcs/bns/output_layer
+            self.kind = "sparse_adam"
+        self.dev = self.emb_params[0].device
+        self.bucket = tdist.FlatGradBucket(self.dense_params)
+        self.err = net._err_flag()
+        self.row_state = {id(p): RowState(p) for p in self.emb_params} if self.kind in ("sparse_adam", "adagrad") else {}
+        self.kernel_events = None
+
+    def step(self, ids, loss_slot, auc_slot=None):
+        net, opt = self.net, self.opt
+        B = ids["user"].shape[0]
+        D, M = net.n_factors, net.n_meta_tables()
+        scores, ctx = net.compute.forward(ids, 2, True)
+        pos, neg = scores[:B], scores[B:]
+        ops.hinge_auc(pos, neg, loss_slot, auc_slot)
+        gp, gn = ops.hinge_backward(pos, neg)
+        g = torch.cat([gp, gn])
+        grads, dx0 = net.compute.backward(ctx, g, grad_of=self.bucket.grad_of)
+        # ---- dense parameters: one flat all-reduce (data parallel), then the user's optimiser
+        self.bucket.allreduce_mean_()
+        idx_user = torch.cat([ids["user"], ids["user"]])
+        idx_item = torch.cat([ids["pos"], ids["neg"]])
+        tables = [(net.user.weight, idx_user, 0), (net.item.weight, idx_item, 1)]
+        for m in range(M):
+            tables.append((net.metadata_embeddings[m].weight,
+                           torch.cat([ids["pos_meta"][:, m], ids["neg_meta"][:, m]]).contiguous(), 2 + m))
+        ld = dx0.stride(0)
+        if self.kind == "generic":
+            opt.zero_grad()
+            for p, idx, f in tables:
+                p.grad = torch.sparse_coo_tensor(idx.reshape(1, -1).long(), dx0[:, f * D:(f + 1) * D], size=p.shape)
+        else:
+            for p in self.emb_params:
+                p.grad = None
+        for p in self.dense_params:
+            p.grad = self.bucket.grad_of(p)
+        opt.step()
+        # ---- embedding tables: fused sparse-row updates from the column blocks of d x0
+        if self.kind == "sgd":
+            for p, idx, f in tables:
+                ops.rows_scatter_add(p.data, idx, dx0[:, f * D:], -_group_of(opt, p)["lr"], ld=ld, err_flag=self.err)
+        elif self.kind in ("sparse_adam", "adagrad"):
+            for p, idx, f in tables:
+                self._rows(p, idx, dx0[:, f * D:], ld)
+
+    def _rows(self, p, idx, vals, ld):
+        opt = self.opt
+        if self.kind == "sparse_adam" and type(opt) is torch.optim.Adam:
+            g = _group_of(opt, p)
+            st = opt.state[p]
+            rs = self.row_state[id(p)]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0)
+                st["exp_avg"] = torch.zeros_like(p.data)
+                st["exp_avg_sq"] = torch.zeros_like(p.data)
+            st["step"] += 1
+            ops.rows_scatter_add(rs.acc, idx, vals, 1.0, ld=ld)
+            b1, b2 = g["betas"]
+            ops.rows_apply_sparse_adam(p.data, rs.acc, st["exp_avg"], st["exp_avg_sq"], rs.stamp, idx, rs.next_id(),
+                                       g["lr"], b1, b2, g["eps"], int(st["step"]))
+        else:
+            apply_rows(self.kind, opt, p, self.row_state[id(p)], idx, vals, ld)
+
+    def check_errors(self):
+        self.net._check_err("fit")

@@ -195,3 +195,85 @@ def topk(scores, k):
     out = torch.empty(k, dtype=torch.int64, device=scores.device)
     check(lib.trs_topk(ptr(scores), n, k, ptr(out), ptr(ws), ws_bytes, _stream()), "trs_topk")
     return out
+
+
+# ------------------------------------------------------------------------------------------------- MLP kernels
+def mlp_gather_concat(T, Bt, passes, x):
+    check(_lib.load().trs_mlp_gather_concat(C.byref(T), C.byref(Bt), passes, ptr(x), x.stride(0), _stream()),
+          "trs_mlp_gather_concat")
+
+
+_gemm_ws = {}
+
+
+def _workspace(dev, nbytes):
+    """One grow-only scratch buffer per device for split-K slabs / reduction partials."""
+    buf = _gemm_ws.get(dev)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=dev)
+        _gemm_ws[dev] = buf
+    return buf
+
+
+def gemm(transA, transB, A, B, out=None, bias=None, alpha=1.0, beta=0.0):
+    """out(M,N) = alpha * op(A) op(B) + beta * out (+ bias); fp32 MFMA.  A, B, out: 2-D fp32 GPU tensors whose last
+    dimension is contiguous (row stride = leading dimension)."""
+    lib = _lib.load()
+    M, K = (A.shape[1], A.shape[0]) if transA else (A.shape[0], A.shape[1])
+    Kb, N = (B.shape[1], B.shape[0]) if transB else (B.shape[0], B.shape[1])
+    if K != Kb:
+        raise ValueError(f"gemm: inner dimensions differ ({K} vs {Kb})")
+    for t in (A, B):
+        if t.dtype != torch.float32 or t.stride(-1) != 1 or not t.is_cuda:
+            raise ValueError("gemm operands must be fp32 GPU tensors with a contiguous last dimension")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    wsb = lib.trs_gemm_f32_workspace_bytes(M, N, K)
+    ws = _workspace(A.device, wsb) if wsb else None
+    check(lib.trs_gemm_f32(int(transA), int(transB), M, N, K, float(alpha), ptr(A), A.stride(0), ptr(B), B.stride(0),
+                           float(beta), ptr(out), out.stride(0), ptr(bias), ptr(ws), wsb, _stream()), "trs_gemm_f32")
+    return out
+
+
+def bn_batch_stats(y, rows_per_pass, passes, momentum, mean_out, var_out, running_mean, running_var):
+    lib = _lib.load()
+    H = y.shape[1]
+    ws = _workspace(y.device, 4 * lib.trs_bn_workspace_floats(rows_per_pass, H, passes))
+    check(lib.trs_bn_batch_stats(ptr(y), rows_per_pass, H, y.stride(0), passes, float(momentum), ptr(mean_out),
+                                 ptr(var_out), ptr(running_mean), ptr(running_var), ptr(ws), _stream()),
+          "trs_bn_batch_stats")
+
+
+def bn_relu_forward(y, rows_per_pass, passes, use_bn, stat_passes, mean, var, gamma, beta, eps, out):
+    H = y.shape[1]
+    check(_lib.load().trs_bn_relu_forward(ptr(y), rows_per_pass, passes, H, y.stride(0), int(use_bn), stat_passes,
+                                          ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps), ptr(out),
+                                          out.stride(0), _stream()), "trs_bn_relu_forward")
+
+
+def bn_relu_backward(y, dx, rows_per_pass, passes, use_bn, mean, var, gamma, beta, eps, dy, dgamma, dbeta):
+    lib = _lib.load()
+    H = y.shape[1]
+    ws = _workspace(y.device, 4 * lib.trs_bn_backward_workspace_floats(rows_per_pass, H, passes))
+    check(lib.trs_bn_relu_backward(ptr(y), ptr(dx), rows_per_pass, passes, H, y.stride(0), dx.stride(0), int(use_bn),
+                                   ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps), ptr(dy), ptr(dgamma),
+                                   ptr(dbeta), ptr(ws), _stream()), "trs_bn_relu_backward")
+
+
+def colsum(x, out, row_weight=None, passes=1):
+    lib = _lib.load()
+    rows, H = x.shape
+    rpp = rows // passes
+    ws = _workspace(x.device, 4 * lib.trs_colsum_workspace_floats(rpp, passes, H))
+    check(lib.trs_colsum(ptr(x), rpp, passes, H, x.stride(0), ptr(row_weight), ptr(out), ptr(ws), _stream()),
+          "trs_colsum")
+
+
+def rowdot(x, w, bias, out):
+    rows, H = x.shape
+    check(_lib.load().trs_rowdot(ptr(x), rows, H, x.stride(0), ptr(w), ptr(bias), ptr(out), _stream()), "trs_rowdot")
+
+
+def outer(g, w, dx):
+    rows, H = dx.shape
+    check(_lib.load().trs_outer(ptr(g), ptr(w), rows, H, ptr(dx), dx.stride(0), _stream()), "trs_outer")
