@@ -151,7 +151,11 @@ def main():
         dom = max(mean_ms, key=mean_ms.get)
         # algorithmic bytes per triple of each kernel (DESIGN.md "Kernels"): the forward+backward pass reads the ids and
         # the R rows (+1-wide terms) once: 16 + R(4D+4) + 8; the update pass writes the R rows once: 12 + R(4D+4)
-        per_triple = {"score_kernel<fwd_bwd>": 16 + R * (4 * D + 4) + 8, "score_sgd_update_kernel": 12 + R * (4 * D + 4)}
+        per_triple = {"score_kernel<fwd_bwd>": 16 + R * (4 * D + 4) + 8, "score_sgd_update_kernel": 12 + R * (4 * D + 4),
+                      # fast path (csrc/fast_step.hip): K1 reads the ids + R rows (+1-wide terms); K2 writes the 2 item
+                      # rows (+terms) and needs the user row; K3 writes the user row (+term)
+                      "fwd_stage_kernel": 16 + R * (4 * D + 4) + 8, "item_update_kernel": 12 + 3 * (4 * D + 4),
+                      "user_update_kernel": 4 + (4 * D + 4)}
         ach = per_triple[dom] * B / (mean_ms[dom] * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS, "traffic": None,

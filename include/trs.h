@@ -130,6 +130,32 @@ int trs_score_fwd_bwd(int net, const trs_tables* tables, const trs_batch* batch,
 int trs_score_backward(int net, const trs_tables* tables, const trs_batch* batch, const float* gpos_dev,
                        const float* gneg_dev, float* grad_rows_dev, float* grad_lin_dev, void* stream);
 
+/* ---------------------------------------------------------------- fused SGD training steps (a2,a3,a5-a9) */
+/* n_steps whole training steps of a Linear / FM scorer WITHOUT metadata under plain SGD, driven from C (four kernel
+ * launches per step, no host work in between) — the inner loop of TorchRecSys.fit (model.py:274-285) for
+ * torch.optim.SGD(momentum=0, weight_decay=0).  Step s covers epoch positions [first_pos + s*batch, +batch).
+ *   K1  forward + hinge + backward-to-scores at the PRE-update tables (software-pipelined row gathers); derives the
+ *       batch from the resident stream (same shuffle / sampler as trs_batch_prepare, sample_offset = epoch position)
+ *       when stream_user is non-NULL and writes it to user/pos/neg_buf (int32, (batch,)); otherwise reads the ids from
+ *       those buffers (n_steps <= 1).  Stages gz (2,batch) and the user-row gradient du (batch,D);
+ *       loss_sums[s] += sum of hinge terms.
+ *   K1b marks rows referenced more than once in the step (needs scratch).
+ *   K2  item[pos] -= lr*gz+ * user[u], item[neg] -= lr*gz- * user[u] (+ 1-wide item terms) from the unmodified user rows.
+ *   K3  user[u] -= lr*du (+ 1-wide user term).
+ *   K2/K3 use plain read-modify-write for rows with a single reference in the step and float atomics for the others
+ *   (all atomics when scratch is NULL).
+ * Same results as trs_score_fwd_bwd + trs_score_sgd_update (to summation order of duplicate rows).
+ * scratch: NULL or trs_train_scratch_bytes(n_users, n_items, batch, D) bytes, zero-initialised once; first_stamp: step counter
+ * of the first step, non-zero, strictly increasing over the life of the scratch (re-zero the scratch before it wraps).
+ * events: NULL, or 4*n_steps hipEvent_t handles recorded at the K1 | K1b+K2 | K3 boundaries of every step (bench.py). */
+int64_t trs_train_scratch_bytes(int64_t n_users, int64_t n_items, int64_t batch, int32_t D);
+int trs_train_steps_sgd(int net, const trs_tables* tables, const int32_t* stream_user_dev,
+                        const int32_t* stream_item_dev, const int32_t* neg_static_dev, int64_t N,
+                        uint64_t shuffle_key, uint64_t sample_seed, int64_t first_pos, int64_t batch, int32_t n_steps,
+                        float lr, int32_t* user_buf_dev, int32_t* pos_buf_dev, int32_t* neg_buf_dev,
+                        float* gz_buf_dev, float* du_buf_dev, float* loss_sums_dev, int32_t* err_flag_dev,
+                        void* scratch_dev, uint32_t first_stamp, void** events, void* stream);
+
 /* ---------------------------------------------------------------- sparse row optimisers (a7, App. A.5) */
 /* table[idx[t]] += alpha * vals[t]  for t < n, rows of D floats, vals row t at vals + t*ld.  Float atomics, one
  * 256-B segment per wave-instruction.  alpha = -lr is torch.optim.SGD's sparse param.add_(grad, alpha=-lr)

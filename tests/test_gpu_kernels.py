@@ -390,3 +390,71 @@ def test_colsum_rowdot_outer_gather():
             cols = [p["user.weight"][batch["user_id"]], p["item.weight"][batch[ik]]]
             cols += [p[f"metadata.{m}.weight"][batch[mk][:, m]] for m in range(M)]
             assert np.array_equal(xg[pas * 50:(pas + 1) * 50].cpu().numpy(), np.concatenate(cols, axis=1))
+
+
+@pytest.mark.parametrize("net,D", [("fm", 64), ("fm", 8), ("fm", 128), ("fm", 80), ("fm", 10), ("linear", 32),
+                                   ("linear", 256), ("linear", 7)])
+def test_fast_sgd_step_matches_oracle_and_generic_path(net, D):
+    """csrc/fast_step.hip (3-kernel exact SGD step, ids given) vs the oracle and vs the generic staged path."""
+    ops = _ops()
+    B, lr = 777, 0.05
+    p, batch, _ = make_case(net, D, 0, B, NU=90, NI=41, seed=D)
+    t, T, Bt, ids, err, keep = to_dev(net, p, batch, np.int32)
+    gz = torch.empty((2, B), device=DEV)
+    du = torch.empty((B, D), device=DEV)
+    ref = {k: v.copy() for k, v in p.items()}
+    losses = torch.zeros(3, device=DEV)
+    scratch = ops.train_scratch(90, 41, B, D, DEV) if D != 8 else None  # D == 8 exercises the all-atomic variant
+    for step in range(3):
+        ops.train_steps_sgd(net, T, None, None, None, 0, 0, 0, B, 1, lr, ids["user_id"], ids["pos_item_id"],
+                            ids["neg_item_id"], gz, du, losses[step:step + 1], err, scratch, 1 + step)
+        _, _, loss, grads = onets.train_forward_backward(net, ref, batch)
+        ooptim.sgd_step(ref, grads, lr)
+        assert abs(losses[step].item() / B - float(loss)) <= TOL * max(abs(float(loss)), 1e-3)
+    for k, v in ref.items():
+        assert rel_err(t[k].cpu().numpy(), v) < TOL, k
+    assert err.item() == 0
+    # generic path from the same start: same result to rounding
+    t2, T2, Bt2, ids2, err2, keep2 = to_dev(net, p, batch, np.int32)
+    for step in range(3):
+        ls = torch.zeros(1, device=DEV)
+        _, _, gr, gl = ops.score_fwd_bwd(net, T2, Bt2, B, D, 0, DEV, ls, want_scores=False)
+        ops.score_sgd_update(net, T2, Bt2, gr, gl, lr)
+    for k in p:
+        assert rel_err(t[k].cpu().numpy(), t2[k].cpu().numpy()) < 1e-6, k
+
+
+def test_fast_sgd_steps_from_resident_stream():
+    """The C step loop deriving its batches from the stream == batch_prepare + generic step, step by step."""
+    ops = _ops()
+    rs = np.random.RandomState(3)
+    N, NU, NI, D, B, lr = 5000, 300, 77, 16, 512, 0.1
+    su, si = rs.randint(0, NU, N).astype(np.int32), rs.randint(0, NI, N).astype(np.int32)
+    p, _, _ = make_case("fm", D, 0, 8, NU=NU, NI=NI, seed=1)
+    dsu, dsi = torch.from_numpy(su).to(DEV), torch.from_numpy(si).to(DEV)
+    key, seed_, n_steps = 0xFEEDBEEF12, 4242, 5
+    # fast: one C call for 5 steps starting at epoch position 1024
+    ta = {k: torch.from_numpy(v.copy()).to(DEV) for k, v in p.items()}
+    Ta, keepa = ops.make_tables(ta["user.weight"], ta["item.weight"], ta["linear_user.weight"], ta["linear_item.weight"])
+    bufs = [torch.empty(B, dtype=torch.int32, device=DEV) for _ in range(3)]
+    gz, du = torch.empty((2, B), device=DEV), torch.empty((B, D), device=DEV)
+    la = torch.zeros(n_steps, device=DEV)
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.train_steps_sgd("fm", Ta, dsu, dsi, None, key, seed_, 1024, B, n_steps, lr, *bufs, gz, du, la, err,
+                        ops.train_scratch(NU, NI, B, D, DEV), 7)
+    # generic: batch_prepare + fwd_bwd + sgd_update per step
+    tb = {k: torch.from_numpy(v.copy()).to(DEV) for k, v in p.items()}
+    Tb, keepb = ops.make_tables(tb["user.weight"], tb["item.weight"], tb["linear_user.weight"], tb["linear_item.weight"])
+    lb = torch.zeros(n_steps, device=DEV)
+    for s in range(n_steps):
+        t0 = 1024 + s * B
+        out = ops.batch_prepare(dsu, dsi, None, key, t0, B, NI, seed_, t0)
+        Bt, kb = ops.make_batch(out["user"], out["pos"], out["neg"], None, None, err)
+        _, _, gr, gl = ops.score_fwd_bwd("fm", Tb, Bt, B, D, 0, DEV, lb[s:s + 1], want_scores=False)
+        ops.score_sgd_update("fm", Tb, Bt, gr, gl, lr)
+    torch.cuda.synchronize()
+    assert torch.equal(bufs[0], out["user"]) and torch.equal(bufs[1], out["pos"]) and torch.equal(bufs[2], out["neg"])
+    assert np.allclose(la.cpu().numpy(), lb.cpu().numpy(), rtol=1e-6)
+    for k in p:
+        assert rel_err(ta[k].cpu().numpy(), tb[k].cpu().numpy()) < 1e-6, k
+    assert err.item() == 0

@@ -1,0 +1,553 @@
+// fast_step.hip — the specialised SGD training step of the Linear / FM scorers without metadata (M = 0), and the
+// C-side step loop (one C call runs many steps: no per-step host work beyond four kernel launches).
+//
+// Exact reference semantics (every gradient of a step is taken at the PRE-update tables, reference model.py:188-200)
+// with the least staging that allows it:
+//   K1  fwd_stage    reads u, i, j rows (+1-wide terms) once — software-pipelined: the rows of the group's next triple
+//                    and the ids of the one after are in flight while the current triple is reduced; [optionally]
+//                    derives the batch from the resident interaction stream (Feistel shuffle + Philox sampler,
+//                    = trs_batch_prepare); writes the per-triple score gradients gz+ / gz- (FM: through the sigmoid), the
+//                    user-row gradient du (B,D), the loss sum, and an ownership mark per referenced row.
+//   K1b mark_dups    a row whose ownership mark is not this reference's own has several references in the batch: stamp
+//                    it as duplicated (plain stores, no atomics, no resets: marks and stamps carry the step number).
+//   K2  item_update  re-reads the still-unmodified user rows (L2 / Infinity-Cache hot) and applies
+//                    item[i] -= lr*gz+ * u, item[j] -= lr*gz- * u (+ 1-wide terms): plain read-modify-write for rows
+//                    referenced once in the batch, float atomics (one 256-B wave-instruction per row segment) for
+//                    duplicated rows.  Touches only item tables.
+//   K3  user_update  user[u] -= lr*du (+ 1-wide term) from the staged rows, same plain / atomic split.  Touches only
+//                    user tables.
+// Float atomics run at ~1.3 TB/s chip-wide against ~6 TB/s for plain stores (MI355X_MICROARCH.md "Global float
+// atomics"), so every reference that is provably alone on its row takes the plain path.
+#include "score_kernels.h"
+
+#include <stdlib.h>
+
+namespace trs {
+
+struct FastArgs {
+  trs_tables T;
+  // batch ids (int32): outputs of K1 when `from_stream`, inputs otherwise
+  int32_t* user;
+  int32_t* pos;
+  int32_t* neg;
+  int64_t B;
+  int32_t* err;
+  // resident stream (from_stream != 0)
+  int from_stream;
+  const int32_t* su;
+  const int32_t* si;
+  const int32_t* neg_static;
+  int64_t N;
+  uint64_t shuffle_key;
+  int hb;
+  int64_t t0;
+  uint64_t sample_seed;
+  uint64_t sample_offset;
+  // staging
+  float* gz;  // (2,B): score gradients of the positive / negative pass (after the FM sigmoid)
+  float* du;  // (B,D)
+  float inv_B;
+  float lr;
+  float* loss_sum;
+  // duplicate detection (all NULL: every update is atomic)
+  uint64_t* uown;  // (n_users) last reference of the step that named the row: (stamp << 32) | t
+  uint64_t* iown;  // (n_items) (stamp << 32) | (2t + which)
+  uint32_t* udup;  // (n_users) == stamp: the row has more than one reference in this step
+  uint32_t* idup;  // (n_items)
+  uint32_t stamp;
+};
+
+struct RawIds {   // loads issued, nothing consumed yet
+  int32_t u, p, n;
+  int64_t v;      // SRC 1: uniform draw over n_items-1 values (the negative is v + (v >= pos))
+  bool valid;
+};
+
+struct TripleIds {
+  int32_t u, p, n;
+  bool valid, ok;
+};
+
+// SRC: 0 = ids given in user/pos/neg; 1 = resident stream + dynamic sampler; 2 = resident stream + static negatives.
+// A template parameter, not a run-time branch: a conditional block that contains a load ends in s_waitcnt vmcnt(0),
+// which would also drain the row gathers in flight.  issue_ids only ISSUES the loads (and does the id-independent
+// Philox arithmetic); finalize_ids consumes them one iteration later, so the wait it implies covers loads that are
+// older than every row gather still in flight (vmcnt is in-order).
+template <int SRC>
+__device__ __forceinline__ RawIds issue_ids(const FastArgs& a, int64_t t) {
+  RawIds r;
+  r.valid = t < a.B;
+  const int64_t tc = r.valid ? t : a.B - 1;  // loads stay unconditional
+  r.v = 0;
+  if (SRC != 0) {
+    const int64_t p = trs_feistel_perm(a.t0 + tc, a.N, a.shuffle_key, a.hb);
+    r.u = a.su[p];
+    r.p = a.si[p];
+    if (SRC == 2) {
+      r.n = a.neg_static[p];
+    } else {
+      const trs_u4 x = trs_philox4x32_10(a.sample_offset + (uint64_t)tc, a.sample_seed);
+      const uint64_t x64 = ((uint64_t)x.y << 32) | (uint64_t)x.x;
+      r.v = a.T.n_items > 1 ? (int64_t)trs_mulhi64(x64, (uint64_t)(a.T.n_items - 1)) : 0;
+      r.n = 0;
+    }
+  } else {
+    r.u = a.user[tc];
+    r.p = a.pos[tc];
+    r.n = a.neg[tc];
+  }
+  return r;
+}
+
+template <int SRC>
+__device__ __forceinline__ TripleIds finalize_ids(const FastArgs& a, const RawIds& w) {
+  TripleIds r;
+  r.valid = w.valid;
+  int64_t uid = w.u, pid = w.p;
+  int64_t nid = SRC == 1 ? (a.T.n_items > 1 ? w.v + (w.v >= pid ? 1 : 0) : 0) : (int64_t)w.n;
+  r.ok = true;
+  if ((uint64_t)uid >= (uint64_t)a.T.n_users) { r.ok = false; uid = 0; }
+  if ((uint64_t)pid >= (uint64_t)a.T.n_items) { r.ok = false; pid = 0; }
+  if ((uint64_t)nid >= (uint64_t)a.T.n_items) { r.ok = false; nid = 0; }
+  r.u = (int32_t)uid;
+  r.p = (int32_t)pid;
+  r.n = (int32_t)nid;
+  return r;
+}
+
+template <int VEC, int K>
+struct TripleRows {
+  RowReg<VEC, K> u, pi, ni;
+  float ul, pl, nl;
+};
+
+template <int VEC, int G, int K, bool FULL>
+__device__ __forceinline__ void load_rows(TripleRows<VEC, K>& r, const trs_tables& T, const TripleIds& id, int lig) {
+  row_load<VEC, G, K, FULL>(r.u, T.user, id.u, T.D, lig);
+  row_load<VEC, G, K, FULL>(r.pi, T.item, id.p, T.D, lig);
+  row_load<VEC, G, K, FULL>(r.ni, T.item, id.n, T.D, lig);
+  r.ul = T.user_lin[id.u];
+  r.pl = T.item_lin[id.p];
+  r.nl = T.item_lin[id.n];
+}
+
+template <int NET, int VEC, int G, int K, int SRC, bool FULL>
+__global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) {
+  constexpr int N = K * VEC;
+  constexpr int TPW = TRS_WAVE / G;
+  const trs_tables& T = a.T;
+  const int D = T.D;
+  const int64_t B = a.B;
+  const int lane = threadIdx.x & 63;
+  const int lig = lane % G;
+  const int64_t wave = ((int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x) >> 6;
+  const int64_t nwave = ((int64_t)gridDim.x * TRS_BLOCK) >> 6;
+  const int64_t stride = nwave * TPW;  // triples between two iterations of one lane group
+  float loss_acc = 0.f;
+
+  int64_t t = wave * TPW + lane / G;
+  // wave-uniform trip count: the wave's first group decides (its t is the smallest of the wave)
+  const int64_t t_first = wave * TPW;
+  const int64_t niter = t_first < B ? (B - t_first + stride - 1) / stride : 0;
+
+  // Reduce one triple whose rows are in registers and write its staging (stores only: no waits on loads in flight).
+  auto reduce = [&](const TripleRows<VEC, K>& r, const TripleIds& id, int64_t tt) {
+    const bool live = id.valid && id.ok;
+    if (id.valid && !id.ok && lig == 0 && a.err) atomicOr(a.err, 1);
+    float pp = 0.f, pn = 0.f;
+    if (NET == TRS_NET_FM) {
+      // (u+i)^2 - (u^2 + i^2) per element, exactly the reference's power_of_sum - sum_of_power (fm.py:83-86)
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        const float sp_ = r.u.v[n] + r.pi.v[n], sn_ = r.u.v[n] + r.ni.v[n];
+        const float uu = r.u.v[n] * r.u.v[n];
+        pp += sp_ * sp_ - (uu + r.pi.v[n] * r.pi.v[n]);
+        pn += sn_ * sn_ - (uu + r.ni.v[n] * r.ni.v[n]);
+      }
+    } else {
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        pp += r.u.v[n] * r.pi.v[n];
+        pn += r.u.v[n] * r.ni.v[n];
+      }
+    }
+    pp = trs_group_sum<G>(pp);
+    pn = trs_group_sum<G>(pn);
+    float sp, sn;
+    if (NET == TRS_NET_FM) {
+      sp = sigmoidf_((r.ul + r.pl) + 0.5f * pp);
+      sn = sigmoidf_((r.ul + r.nl) + 0.5f * pn);
+    } else {
+      sp = (pp + r.ul) + r.pl;
+      sn = (pn + r.ul) + r.nl;
+    }
+    const float h = sn - sp + 1.0f;
+    const float act = (live && h >= 0.f) ? 1.f : 0.f;
+    float gp = -act * a.inv_B, gn = act * a.inv_B;
+    if (live && lig == 0) loss_acc += fmaxf(h, 0.f);
+    if (NET == TRS_NET_FM) {
+      gp = gp * ((1.0f - sp) * sp);
+      gn = gn * ((1.0f - sn) * sn);
+    }
+    if (id.valid) {
+      RowReg<VEC, K> g;
+#pragma unroll
+      for (int n = 0; n < N; ++n) g.v[n] = gp * r.pi.v[n] + gn * r.ni.v[n];
+      row_store<VEC, G, K>(g, a.du + tt * (int64_t)D, D, lig);
+      if (lig == 0) {
+        a.gz[tt] = gp;
+        a.gz[B + tt] = gn;
+        if (SRC != 0) {  // the batch this step was derived from, for K1b / K2 / K3 (and for the caller)
+          a.user[tt] = id.u;
+          a.pos[tt] = id.p;
+          a.neg[tt] = id.n;
+        }
+        if (live && a.uown) {
+          const uint64_t hi = (uint64_t)a.stamp << 32;
+          a.uown[id.u] = hi | (uint64_t)(uint32_t)tt;
+          a.iown[id.p] = hi | (uint64_t)(uint32_t)(2 * tt);
+          a.iown[id.n] = hi | (uint64_t)(uint32_t)(2 * tt + 1);
+        }
+      }
+    }
+  };
+
+  // Software pipeline, unrolled by two so that nothing in flight is ever copied between registers (a copy of a loaded
+  // value forces the wait for it): triple k's rows live in the "even" or "odd" register set by parity; in triple k's
+  // phase the ids of k+2 are issued, the ids of k+1 consumed and its rows issued, then triple k is reduced.  Program
+  // order = issue order, so each wait covers only loads older than everything that should stay in flight.
+  const int64_t niter2 = (niter + 1) & ~(int64_t)1;  // even trip count: surplus phases run on clamped, invalid triples
+  RawIds wE = issue_ids<SRC>(a, t);
+  RawIds wO = issue_ids<SRC>(a, t + stride);
+  TripleIds idE = finalize_ids<SRC>(a, wE);
+  TripleIds idO;
+  TripleRows<VEC, K> rE, rO;
+  load_rows<VEC, G, K, FULL>(rE, T, idE, lig);
+  for (int64_t it = 0; it < niter2; it += 2) {
+    wE = issue_ids<SRC>(a, t + 2 * stride);
+    idO = finalize_ids<SRC>(a, wO);
+    load_rows<VEC, G, K, FULL>(rO, T, idO, lig);
+    reduce(rE, idE, t);
+
+    wO = issue_ids<SRC>(a, t + 3 * stride);
+    idE = finalize_ids<SRC>(a, wE);
+    load_rows<VEC, G, K, FULL>(rE, T, idE, lig);
+    reduce(rO, idO, t + stride);
+    t += 2 * stride;
+  }
+  __shared__ float s_loss[TRS_BLOCK / TRS_WAVE];
+  const float wl = trs_wave_sum(loss_acc);
+  if (lane == 0) s_loss[threadIdx.x >> 6] = wl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float L = 0.f;
+#pragma unroll
+    for (int w = 0; w < TRS_BLOCK / TRS_WAVE; ++w) L += s_loss[w];
+    if (L != 0.f) atomicAdd(a.loss_sum, L);
+  }
+}
+
+// K1b: a reference that does not find its own mark lost the row to another reference of the same step.
+__global__ __launch_bounds__(TRS_BLOCK) void mark_dups_kernel(const FastArgs a) {
+  const int64_t stride = (int64_t)gridDim.x * TRS_BLOCK;
+  const uint64_t hi = (uint64_t)a.stamp << 32;
+  for (int64_t t = (int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x; t < a.B; t += stride) {
+    const int64_t uid = a.user[t], pid = a.pos[t], nid = a.neg[t];
+    if ((uint64_t)uid >= (uint64_t)a.T.n_users || (uint64_t)pid >= (uint64_t)a.T.n_items ||
+        (uint64_t)nid >= (uint64_t)a.T.n_items)
+      continue;
+    if (a.uown[uid] != (hi | (uint64_t)(uint32_t)t)) a.udup[uid] = a.stamp;
+    if (a.iown[pid] != (hi | (uint64_t)(uint32_t)(2 * t))) a.idup[pid] = a.stamp;
+    if (a.iown[nid] != (hi | (uint64_t)(uint32_t)(2 * t + 1))) a.idup[nid] = a.stamp;
+  }
+}
+
+// K2 / K3 mapping: LPR lanes cover one row (4 B per lane: a D = 64 row is ONE 256-B wave-instruction, the full-rate
+// float-atomic shape); a wave works on U x (64 / LPR) triples per iteration with every load of the iteration issued
+// before the first store / atomic (no conditional block contains a load), KD = ceil(D / LPR) elements per lane.
+struct UpdIds {
+  int64_t u, p, n;
+  bool live;
+};
+
+__device__ __forceinline__ UpdIds upd_ids(const FastArgs& a, int64_t t) {
+  UpdIds r;
+  const bool valid = t < a.B;
+  const int64_t tc = valid ? t : a.B - 1;
+  r.u = a.user[tc];
+  r.p = a.pos[tc];
+  r.n = a.neg[tc];
+  const bool ok = (uint64_t)r.u < (uint64_t)a.T.n_users && (uint64_t)r.p < (uint64_t)a.T.n_items &&
+                  (uint64_t)r.n < (uint64_t)a.T.n_items;  // bad ids were flagged by K1
+  if (!ok) r.u = r.p = r.n = 0;
+  r.live = valid && ok;
+  return r;
+}
+
+template <int LPR, int KD, int U, bool DEDUP>
+__global__ __launch_bounds__(TRS_BLOCK) void item_update_kernel(const FastArgs a) {
+  constexpr int EPW = TRS_WAVE / LPR;
+  const trs_tables& T = a.T;
+  const int D = T.D;
+  const int64_t B = a.B;
+  const int lane = threadIdx.x & 63;
+  const int lir = lane % LPR;
+  const int64_t wave = ((int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x) >> 6;
+  const int64_t nwave = ((int64_t)gridDim.x * TRS_BLOCK) >> 6;
+  const int64_t per_it = (int64_t)EPW * U;
+  const int64_t niter = (B + per_it - 1) / per_it;
+  for (int64_t it = wave; it < niter; it += nwave) {
+    UpdIds id[U];
+    float cp[U], cn[U], uv[U][KD], pv[U][KD], nv[U][KD], pl[U], nl[U];
+    bool pa[U], na[U];
+    int64_t t[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      t[k] = it * per_it + k * EPW + lane / LPR;
+      id[k] = upd_ids(a, t[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int64_t tc = id[k].live ? t[k] : 0;
+      cp[k] = -a.lr * a.gz[tc];
+      cn[k] = -a.lr * a.gz[B + tc];
+      pa[k] = DEDUP ? a.idup[id[k].p] != a.stamp : false;
+      na[k] = DEDUP ? a.idup[id[k].n] != a.stamp : false;
+      pl[k] = T.item_lin[id[k].p];
+      nl[k] = T.item_lin[id[k].n];
+#pragma unroll
+      for (int q = 0; q < KD; ++q) {
+        const int d = q * LPR + lir;
+        const int dc = d < D ? d : 0;
+        uv[k][q] = T.user[id[k].u * (int64_t)D + dc];
+        pv[k][q] = T.item[id[k].p * (int64_t)D + dc];
+        nv[k][q] = T.item[id[k].n * (int64_t)D + dc];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      if (!id[k].live) continue;
+      float* prow = T.item + id[k].p * (int64_t)D;
+      float* nrow = T.item + id[k].n * (int64_t)D;
+#pragma unroll
+      for (int q = 0; q < KD; ++q) {
+        const int d = q * LPR + lir;
+        if (d < D) {
+          if (pa[k]) prow[d] = pv[k][q] + cp[k] * uv[k][q]; else atomicAdd(prow + d, cp[k] * uv[k][q]);
+          if (na[k]) nrow[d] = nv[k][q] + cn[k] * uv[k][q]; else atomicAdd(nrow + d, cn[k] * uv[k][q]);
+        }
+      }
+      if (lir == 0) {
+        if (pa[k]) T.item_lin[id[k].p] = pl[k] + cp[k]; else atomicAdd(T.item_lin + id[k].p, cp[k]);
+        if (na[k]) T.item_lin[id[k].n] = nl[k] + cn[k]; else atomicAdd(T.item_lin + id[k].n, cn[k]);
+      }
+    }
+  }
+}
+
+template <int LPR, int KD, int U, bool DEDUP>
+__global__ __launch_bounds__(TRS_BLOCK) void user_update_kernel(const FastArgs a) {
+  constexpr int EPW = TRS_WAVE / LPR;
+  const trs_tables& T = a.T;
+  const int D = T.D;
+  const int64_t B = a.B;
+  const int lane = threadIdx.x & 63;
+  const int lir = lane % LPR;
+  const int64_t wave = ((int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x) >> 6;
+  const int64_t nwave = ((int64_t)gridDim.x * TRS_BLOCK) >> 6;
+  const int64_t per_it = (int64_t)EPW * U;
+  const int64_t niter = (B + per_it - 1) / per_it;
+  for (int64_t it = wave; it < niter; it += nwave) {
+    UpdIds id[U];
+    float c[U], gv[U][KD], wv[U][KD], wl[U];
+    bool al[U];
+    int64_t t[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      t[k] = it * per_it + k * EPW + lane / LPR;
+      id[k] = upd_ids(a, t[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int64_t tc = id[k].live ? t[k] : 0;
+      c[k] = -a.lr * (a.gz[tc] + a.gz[B + tc]);
+      al[k] = DEDUP ? a.udup[id[k].u] != a.stamp : false;
+      wl[k] = T.user_lin[id[k].u];
+#pragma unroll
+      for (int q = 0; q < KD; ++q) {
+        const int d = q * LPR + lir;
+        const int dc = d < D ? d : 0;
+        gv[k][q] = a.du[tc * (int64_t)D + dc];
+        wv[k][q] = T.user[id[k].u * (int64_t)D + dc];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      if (!id[k].live) continue;
+      float* urow = T.user + id[k].u * (int64_t)D;
+#pragma unroll
+      for (int q = 0; q < KD; ++q) {
+        const int d = q * LPR + lir;
+        if (d < D) {
+          if (al[k]) urow[d] = wv[k][q] + (-a.lr) * gv[k][q]; else atomicAdd(urow + d, -a.lr * gv[k][q]);
+        }
+      }
+      if (lir == 0) {
+        if (al[k]) T.user_lin[id[k].u] = wl[k] + c[k]; else atomicAdd(T.user_lin + id[k].u, c[k]);
+      }
+    }
+  }
+}
+
+template <int NET>
+static int launch_fwd_stage(const FastArgs& a, hipStream_t s) {
+  RowCfg c;
+  if (!pick_row_cfg(a.T.D, c)) {
+    trs_set_error("unsupported n_factors D=%d", a.T.D);
+    return TRS_E_ARG;
+  }
+  const int tpw = TRS_WAVE / c.g;
+  // ~8 pipelined iterations per lane group: few enough workgroups that every wave overlaps its own loads with its
+  // own reductions, enough (>= 2 per CU) to fill the chip
+  static const int iters = getenv("TRS_K1_ITERS") ? atoi(getenv("TRS_K1_ITERS")) : 8;  // tuning knob (scratch)
+  int64_t grid = ((a.B + tpw - 1) / tpw + 4 * iters - 1) / (4 * iters);
+  if (grid < 1) grid = 1;
+  if (grid > 4096) grid = 4096;
+  const int src = !a.from_stream ? 0 : (a.neg_static ? 2 : 1);
+#define TRS_LAUNCH(V, GG, KK, FULL)                                                                             \
+  {                                                                                                             \
+    const dim3 gr((unsigned)grid), bl(TRS_BLOCK);                                                               \
+    if (src == 0) hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL>), gr, bl, 0, s, a);              \
+    else if (src == 1) hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 1, FULL>), gr, bl, 0, s, a);         \
+    else hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 2, FULL>), gr, bl, 0, s, a);                       \
+  }
+#define TRS_CASE(V, GG, KK)                                                                                     \
+  if (c.vec == V && c.g == GG && c.k == KK) {                                                                   \
+    if (V * GG * KK == a.T.D) TRS_LAUNCH(V, GG, KK, true) else TRS_LAUNCH(V, GG, KK, false)                      \
+    TRS_CHECK_LAUNCH("fwd_stage_kernel");                                                                       \
+    return TRS_OK;                                                                                              \
+  }
+  TRS_CASE(4, 2, 1)
+  TRS_CASE(4, 4, 1)
+  TRS_CASE(4, 8, 1)
+  TRS_CASE(4, 16, 1)
+  TRS_CASE(4, 32, 1)
+  TRS_CASE(4, 64, 1)
+  TRS_CASE(4, 64, 2)
+  TRS_CASE(4, 64, 4)
+  TRS_CASE(1, 4, 1)
+  TRS_CASE(1, 16, 1)
+  TRS_CASE(1, 64, 1)
+  TRS_CASE(1, 64, 4)
+#undef TRS_CASE
+#undef TRS_LAUNCH
+  trs_set_error("internal: no kernel for D=%d", a.T.D);
+  return TRS_E_ARG;
+}
+
+static int launch_updates(const FastArgs& a, hipStream_t s, hipEvent_t ev_k2, hipEvent_t ev_k3) {
+  const int D = a.T.D;
+  if (a.uown) {
+    hipLaunchKernelGGL(mark_dups_kernel, dim3(trs_grid(a.B, TRS_BLOCK)), dim3(TRS_BLOCK), 0, s, a);
+    TRS_CHECK_LAUNCH("mark_dups_kernel");
+  }
+  if (ev_k2) (void)hipEventRecord(ev_k2, s);
+#define TRS_UPD(L, KD, U)                                                                            \
+  {                                                                                                  \
+    constexpr int PER = (TRS_WAVE / L) * U;                                                          \
+    const int grid = trs_grid((a.B + PER - 1) / PER, TRS_BLOCK / TRS_WAVE);                          \
+    if (a.uown) hipLaunchKernelGGL((item_update_kernel<L, KD, U, true>), dim3(grid), dim3(TRS_BLOCK), 0, s, a);   \
+    else hipLaunchKernelGGL((item_update_kernel<L, KD, U, false>), dim3(grid), dim3(TRS_BLOCK), 0, s, a);        \
+    if (ev_k3) (void)hipEventRecord(ev_k3, s);                                                       \
+    if (a.uown) hipLaunchKernelGGL((user_update_kernel<L, KD, U, true>), dim3(grid), dim3(TRS_BLOCK), 0, s, a);   \
+    else hipLaunchKernelGGL((user_update_kernel<L, KD, U, false>), dim3(grid), dim3(TRS_BLOCK), 0, s, a);        \
+  }
+  if (D > 256) TRS_UPD(64, 16, 1)
+  else if (D > 128) TRS_UPD(64, 4, 2)
+  else if (D > 64) TRS_UPD(64, 2, 4)
+  else if (D > 32) TRS_UPD(64, 1, 4)
+  else if (D > 16) TRS_UPD(32, 1, 2)
+  else if (D > 8) TRS_UPD(16, 1, 2)
+  else if (D > 4) TRS_UPD(8, 1, 1)
+  else if (D > 1) TRS_UPD(4, 1, 1)
+  else TRS_UPD(1, 1, 1)
+#undef TRS_UPD
+  TRS_CHECK_LAUNCH("item/user_update_kernel");
+  return TRS_OK;
+}
+
+}  // namespace trs
+
+using namespace trs;
+
+extern "C" int64_t trs_train_scratch_bytes(int64_t n_users, int64_t n_items, int64_t batch, int32_t D) {
+  if (n_users <= 0 || n_items <= 0 || batch <= 0 || D <= 0) return 0;
+  return 12 * (n_users + n_items);  // uown, iown (8 B per row) + udup, idup (4 B per row)
+}
+
+extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int32_t* stream_user_dev,
+                                   const int32_t* stream_item_dev, const int32_t* neg_static_dev, int64_t N,
+                                   uint64_t shuffle_key, uint64_t sample_seed, int64_t first_pos, int64_t batch,
+                                   int32_t n_steps, float lr, int32_t* user_buf_dev, int32_t* pos_buf_dev,
+                                   int32_t* neg_buf_dev, float* gz_buf_dev, float* du_buf_dev, float* loss_sums_dev,
+                                   int32_t* err_flag_dev, void* scratch_dev, uint32_t first_stamp, void** events,
+                                   void* stream) {
+  TRS_REQUIRE(net == TRS_NET_LINEAR || net == TRS_NET_FM, "trs_train_steps_sgd: bad net");
+  TRS_REQUIRE(tables && tables->M == 0, "trs_train_steps_sgd: only scorers without metadata (M == 0)");
+  TRS_REQUIRE(tables->user && tables->item && tables->user_lin && tables->item_lin, "trs_train_steps_sgd: NULL table");
+  TRS_REQUIRE(batch > 0 && batch < ((int64_t)1 << 30) && n_steps >= 0, "trs_train_steps_sgd: bad batch / n_steps");
+  TRS_REQUIRE(user_buf_dev && pos_buf_dev && neg_buf_dev && gz_buf_dev && du_buf_dev && loss_sums_dev,
+              "trs_train_steps_sgd: NULL buffer");
+  TRS_REQUIRE(!scratch_dev || (first_stamp != 0 && (uint64_t)first_stamp + (uint64_t)n_steps < 0xFFFFFFFFull),
+              "trs_train_steps_sgd: stamps must be non-zero and must not wrap (zero the scratch and restart at 1)");
+  const bool from_stream = stream_user_dev != nullptr;
+  if (from_stream) {
+    TRS_REQUIRE(stream_item_dev && N > 0 && first_pos >= 0 && first_pos + (int64_t)n_steps * batch <= N,
+                "trs_train_steps_sgd: steps [%lld, %lld) outside the stream of %lld rows", (long long)first_pos,
+                (long long)(first_pos + (int64_t)n_steps * batch), (long long)N);
+    TRS_REQUIRE(neg_static_dev || tables->n_items >= 2, "trs_train_steps_sgd: dynamic sampling needs n_items >= 2");
+  } else {
+    TRS_REQUIRE(n_steps <= 1, "trs_train_steps_sgd: without a stream the id buffers hold exactly one batch");
+  }
+  hipStream_t s = (hipStream_t)stream;
+  FastArgs a = {};
+  a.T = *tables;
+  a.user = user_buf_dev;
+  a.pos = pos_buf_dev;
+  a.neg = neg_buf_dev;
+  a.B = batch;
+  a.err = err_flag_dev;
+  a.from_stream = from_stream ? 1 : 0;
+  a.su = stream_user_dev;
+  a.si = stream_item_dev;
+  a.neg_static = neg_static_dev;
+  a.N = N;
+  a.shuffle_key = shuffle_key;
+  a.hb = from_stream ? trs_feistel_half_bits(N) : 0;
+  a.sample_seed = sample_seed;
+  a.gz = gz_buf_dev;
+  a.du = du_buf_dev;
+  a.inv_B = 1.0f / (float)batch;
+  a.lr = lr;
+  if (scratch_dev) {
+    a.uown = (uint64_t*)scratch_dev;
+    a.iown = a.uown + tables->n_users;
+    a.udup = (uint32_t*)(a.iown + tables->n_items);
+    a.idup = a.udup + tables->n_users;
+  }
+  for (int32_t st = 0; st < n_steps; ++st) {
+    a.t0 = first_pos + (int64_t)st * batch;
+    a.sample_offset = (uint64_t)a.t0;
+    a.loss_sum = loss_sums_dev + st;
+    a.stamp = first_stamp + (uint32_t)st;
+    hipEvent_t* ev = events ? (hipEvent_t*)events + 4 * (int64_t)st : nullptr;  // K1 | K1b+K2 | K3 boundaries
+    if (ev) (void)hipEventRecord(ev[0], s);
+    int rc = net == TRS_NET_FM ? launch_fwd_stage<TRS_NET_FM>(a, s) : launch_fwd_stage<TRS_NET_LINEAR>(a, s);
+    if (rc) return rc;
+    if (ev) (void)hipEventRecord(ev[1], s);
+    rc = launch_updates(a, s, nullptr, ev ? ev[2] : nullptr);
+    if (rc) return rc;
+    if (ev) (void)hipEventRecord(ev[3], s);
+  }
+  return TRS_OK;
+}

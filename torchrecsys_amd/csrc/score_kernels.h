@@ -34,21 +34,29 @@ struct RowReg {
   float v[K * VEC];
 };
 
-template <int VEC, int G, int K>
+// Branch-free: hipcc closes every conditional block that contains a load with `s_waitcnt vmcnt(0)`, which serialises
+// the three row gathers of a triple (and drains anything prefetched).  Lanes past the row's end load the row's first
+// chunk instead and are zeroed by a multiply with a 0/1 mask (a select would let the optimiser sink the load back under
+// the condition); FULL = the lane group covers the row exactly (D == G*K*VEC): no mask at all.
+template <int VEC, int G, int K, bool FULL = false>
 __device__ __forceinline__ void row_load(RowReg<VEC, K>& r, const float* __restrict__ tab, int64_t row, int D,
                                          int lig) {
   const float* p = tab + row * (int64_t)D;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const int e = (k * G + lig) * VEC;
-    if (e < D) {
+    if (FULL) {
       typename VecT<VEC>::type x = *reinterpret_cast<const typename VecT<VEC>::type*>(p + e);
       const float* xs = reinterpret_cast<const float*>(&x);
 #pragma unroll
       for (int c = 0; c < VEC; ++c) r.v[k * VEC + c] = xs[c];
     } else {
+      const bool act = e < D;
+      const float m = act ? 1.0f : 0.0f;
+      typename VecT<VEC>::type x = *reinterpret_cast<const typename VecT<VEC>::type*>(p + (act ? e : 0));
+      const float* xs = reinterpret_cast<const float*>(&x);
 #pragma unroll
-      for (int c = 0; c < VEC; ++c) r.v[k * VEC + c] = 0.f;
+      for (int c = 0; c < VEC; ++c) r.v[k * VEC + c] = xs[c] * m;
     }
   }
 }
@@ -115,7 +123,7 @@ __device__ __forceinline__ float pass_forward(const trs_tables& T, const RowReg<
     lin_sum = 0.f;
   }
   for (int m = 0; m < T.M; ++m) {
-    int64_t mid = valid ? trs_ld_idx(meta, idx_bytes, t * T.M + m) : 0;
+    int64_t mid = trs_ld_idx(meta, idx_bytes, t * T.M + m);  // t is already clamped into the batch by the caller
     if ((uint64_t)mid >= (uint64_t)T.n_meta[m]) {
       ok = false;
       mid = 0;
@@ -166,9 +174,16 @@ __global__ __launch_bounds__(TRS_BLOCK) void score_kernel(const ScoreArgs a) {
     const bool valid = t < B;
     bool ok = true;
     const bool iota = a.iota_user >= 0;
-    int64_t uid = iota ? a.iota_user : (valid ? trs_ld_idx(a.Bt.user, ib, t) : 0);
-    int64_t pid = iota ? (valid ? a.iota_item0 + t : 0) : (valid ? trs_ld_idx(a.Bt.pos, ib, t) : 0);
-    int64_t nid = (valid && has_neg) ? trs_ld_idx(a.Bt.neg, ib, t) : 0;
+    const int64_t tc = valid ? t : 0;  // loads stay unconditional (a conditional load costs an s_waitcnt vmcnt(0))
+    int64_t uid, pid, nid = 0;
+    if (iota) {
+      uid = a.iota_user;
+      pid = a.iota_item0 + tc;
+    } else {
+      uid = trs_ld_idx(a.Bt.user, ib, tc);
+      pid = trs_ld_idx(a.Bt.pos, ib, tc);
+      if (has_neg) nid = trs_ld_idx(a.Bt.neg, ib, tc);
+    }
     if ((uint64_t)uid >= (uint64_t)T.n_users) { ok = false; uid = 0; }
     if ((uint64_t)pid >= (uint64_t)T.n_items) { ok = false; pid = 0; }
     if ((uint64_t)nid >= (uint64_t)T.n_items) { ok = false; nid = 0; }
@@ -178,11 +193,11 @@ __global__ __launch_bounds__(TRS_BLOCK) void score_kernel(const ScoreArgs a) {
     const float u_lin = T.user_lin ? T.user_lin[uid] : 0.f;
     float pi_lin, ni_lin = 0.f, lin_p, lin_n = 0.f;
     const float sp = pass_forward<NET, VEC, G, K>(T, u, u_lin, pid, iota ? (const void*)a.iota_item_meta : a.Bt.pos_meta,
-                                                  iota ? 4 : ib, iota ? pid : t, valid, lig, pi, Sp, pi_lin, lin_p,
+                                                  iota ? 4 : ib, iota ? pid : tc, valid, lig, pi, Sp, pi_lin, lin_p,
                                                   ok);
     float sn = 0.f;
     if (has_neg)
-      sn = pass_forward<NET, VEC, G, K>(T, u, u_lin, nid, a.Bt.neg_meta, ib, t, valid, lig, ni, Sn, ni_lin, lin_n,
+      sn = pass_forward<NET, VEC, G, K>(T, u, u_lin, nid, a.Bt.neg_meta, ib, tc, valid, lig, ni, Sn, ni_lin, lin_n,
                                         ok);
     if (valid && !ok && lig == 0 && a.Bt.err_flag_dev) atomicOr(a.Bt.err_flag_dev, 1);
     const bool live = valid && ok;

@@ -100,6 +100,17 @@ class SparseScorerTrainer:
         self.grad_lin = torch.empty((self.R, batch_capacity), dtype=torch.float32, device=dev)
         self.err = torch.zeros(1, dtype=torch.int32, device=dev)
         self.kernel_events = None  # bench.py: {"kernel name": [(start_event, end_event), ...]} on the launch stream
+        # specialised exact 3-kernel SGD step (csrc/fast_step.hip): no metadata, plain SGD with one learning rate
+        self.fast_lr = None
+        if self.kind == "sgd" and self.M == 0:
+            lrs = {_group_of(optimizer, p)["lr"] for p in self.params}
+            if len(lrs) == 1:
+                self.fast_lr = lrs.pop()
+                self.gz = torch.empty((2, batch_capacity), dtype=torch.float32, device=dev)
+                self.du = torch.empty((batch_capacity, self.D), dtype=torch.float32, device=dev)
+                self.id_bufs = [torch.empty(batch_capacity, dtype=torch.int32, device=dev) for _ in range(3)]
+                self.scratch = ops.train_scratch(self.params[0].shape[0], self.params[1].shape[0], batch_capacity, self.D, dev)
+                self.stamp = 1
         self.row_state = {}
         if self.kind in ("sparse_adam", "adagrad"):
             self.row_state = {id(p): RowState(p) for p in self.params}
@@ -112,11 +123,51 @@ class SparseScorerTrainer:
         gl = self.grad_lin.view(-1)[: self.R * B].view(self.R, B)
         return gr, gl
 
+    def _stamps(self, n):
+        """First of n consecutive step stamps of the duplicate-detection scratch (never 0, re-zeroed before wrapping)."""
+        if self.stamp + n >= 0xFFFFFFF0:
+            self.scratch.zero_()
+            self.stamp = 1
+        first = self.stamp
+        self.stamp += n
+        return first
+
+    def _make_events(self, n_steps):
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(4 * n_steps)]
+        for e in evs:
+            e.record()  # creates the underlying hipEvent_t; re-recorded by the C step loop
+        return evs
+
+    def _collect_events(self, evs):
+        ke = self.kernel_events
+        for s in range(len(evs) // 4):
+            ke.setdefault("fwd_stage_kernel", []).append((evs[4 * s], evs[4 * s + 1]))
+            ke.setdefault("item_update_kernel", []).append((evs[4 * s + 1], evs[4 * s + 2]))  # + mark_dups_kernel
+            ke.setdefault("user_update_kernel", []).append((evs[4 * s + 2], evs[4 * s + 3]))
+
+    def fast_stream_steps(self, st, shuffle_key, sample_seed, first_pos, batch, n_steps, loss_sums):
+        """n_steps fused steps straight from the resident stream `st` (dict user/pos/neg int32); loss_sums: (n_steps,)
+        view.  Only valid when self.fast_lr is not None and batch == capacity."""
+        evs = self._make_events(n_steps) if self.kernel_events is not None else None
+        ops.train_steps_sgd(self.net.NET, self.net.tables(), st["user"], st["pos"], st["neg"], shuffle_key,
+                            sample_seed, first_pos, batch, n_steps, self.fast_lr, *self.id_bufs, self.gz, self.du,
+                            loss_sums, self.err, self.scratch, self._stamps(n_steps), evs)
+        if evs is not None:
+            self._collect_events(evs)
+
     def step(self, ids, loss_slot, auc_slot=None):
         """ids: dict user/pos/neg[/pos_meta/neg_meta] of GPU id tensors.  loss_slot: 1-element fp32 view that receives
         the SUM of the batch's hinge terms (caller divides by B)."""
         B = ids["user"].shape[0]
         net = self.net
+        if self.fast_lr is not None and auc_slot is None and ids["user"].dtype == torch.int32:
+            evs = self._make_events(1) if self.kernel_events is not None else None
+            ops.train_steps_sgd(net.NET, net.tables(), None, None, None, 0, 0, 0, B, 1, self.fast_lr, ids["user"],
+                                ids["pos"], ids["neg"], self.gz, self.du, loss_slot, self.err, self.scratch,
+                                self._stamps(1), evs)
+            if evs is not None:
+                self._collect_events(evs)
+            return
         T = net.tables()
         Bt, keep = ops.make_batch(ids["user"], ids["pos"], ids["neg"], ids.get("pos_meta"), ids.get("neg_meta"),
                                   self.err)

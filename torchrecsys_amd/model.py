@@ -343,6 +343,16 @@ class FitRunner:
         """Run the next k steps of the current epoch (stops at the epoch's end).  Returns the number of steps run."""
         m, B = self.m, self.batch_size
         done = 0
+        fast = getattr(self.trainer, "fast_lr", None) is not None and m.rng == 'device'
+        if fast:  # whole batches straight from the resident stream, step loop in C (csrc/fast_step.hip)
+            full = self.n_train // B
+            while done < k and self.next_batch < full:
+                n = min(k - done, full - self.next_batch, 64)
+                b = self.next_batch
+                self.trainer.fast_stream_steps(self.st, self.shuffle_key, self.sample_seed, b * B, B, n,
+                                               self.loss_sums[b:b + n])
+                self.next_batch += n
+                done += n
         while done < k and self.next_batch < self.num_batches:
             b = self.next_batch
             s, e = b * B, min((b + 1) * B, self.n_train)

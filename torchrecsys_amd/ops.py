@@ -116,6 +116,28 @@ def score_sgd_update(net, T, Bt, grad_rows, grad_lin, lr):
                                            float(lr), _stream()), "trs_score_sgd_update")
 
 
+def train_scratch(n_users, n_items, batch, D, device):
+    """Zeroed scratch of trs_train_steps_sgd (ownership marks, duplicate stamps, item-bucket lists)."""
+    nbytes = _lib.load().trs_train_scratch_bytes(int(n_users), int(n_items), int(batch), int(D))
+    return torch.zeros(nbytes // 8 + 1, dtype=torch.int64, device=device)
+
+
+def train_steps_sgd(net, T, stream_user, stream_item, neg_static, shuffle_key, sample_seed, first_pos, batch, n_steps,
+                    lr, user_buf, pos_buf, neg_buf, gz_buf, du_buf, loss_sums, err_flag, scratch=None, first_stamp=1,
+                    events=None):
+    """n_steps fused SGD steps driven from C (trs_train_steps_sgd).  stream_user None: one step on the ids already in
+    user/pos/neg_buf.  events: optional flat list of 4*n_steps torch.cuda.Event (already created by a record())."""
+    ev = None
+    if events is not None:
+        ev = (C.c_void_p * len(events))(*[e.cuda_event for e in events])
+    N = 0 if stream_user is None else stream_user.numel()
+    check(_lib.load().trs_train_steps_sgd(NET_ID[net], C.byref(T), ptr(stream_user), ptr(stream_item), ptr(neg_static),
+                                          N, int(shuffle_key), int(sample_seed), int(first_pos), int(batch),
+                                          int(n_steps), float(lr), ptr(user_buf), ptr(pos_buf), ptr(neg_buf),
+                                          ptr(gz_buf), ptr(du_buf), ptr(loss_sums), ptr(err_flag), ptr(scratch),
+                                          int(first_stamp), ev, _stream()), "trs_train_steps_sgd")
+
+
 def rows_scatter_add(table, idx, vals, alpha, ld=None, err_flag=None):
     n_rows, D = table.shape
     n = idx.shape[0]
