@@ -139,15 +139,14 @@ int trs_score_backward(int net, const trs_tables* tables, const trs_batch* batch
  *       when stream_user is non-NULL and writes it to user/pos/neg_buf (int32, (batch,)); otherwise reads the ids from
  *       those buffers (n_steps <= 1).  Stages gz (2,batch) and the user-row gradient du (batch,D);
  *       loss_sums[s] += sum of hinge terms.
- *   K1b marks rows referenced more than once in the step (needs scratch).
- *   K2  item[pos] -= lr*gz+ * user[u], item[neg] -= lr*gz- * user[u] (+ 1-wide item terms) from the unmodified user rows.
- *   K3  user[u] -= lr*du (+ 1-wide user term).
- *   K2/K3 use plain read-modify-write for rows with a single reference in the step and float atomics for the others
- *   (all atomics when scratch is NULL).
+ *   K2  item[pos] -= lr*gz+ * user[u], item[neg] -= lr*gz- * user[u] (+ 1-wide item terms) from the unmodified user rows:
+ *       K2a the one reference per distinct row whose K1 ownership mark survived, by plain read-modify-write; K2b the
+ *       remaining references of duplicated rows, by float atomics.  (One all-atomic launch when scratch is NULL.)
+ *   K3  user[u] -= lr*du (+ 1-wide user term): plain for rows referenced once in the step, atomics for the others.
  * Same results as trs_score_fwd_bwd + trs_score_sgd_update (to summation order of duplicate rows).
  * scratch: NULL or trs_train_scratch_bytes(n_users, n_items, batch, D) bytes, zero-initialised once; first_stamp: step counter
  * of the first step, non-zero, strictly increasing over the life of the scratch (re-zero the scratch before it wraps).
- * events: NULL, or 4*n_steps hipEvent_t handles recorded at the K1 | K1b+K2 | K3 boundaries of every step (bench.py). */
+ * events: NULL, or 4*n_steps hipEvent_t handles recorded at the K1 | K2a+K2b | K3 boundaries of every step (bench.py). */
 int64_t trs_train_scratch_bytes(int64_t n_users, int64_t n_items, int64_t batch, int32_t D);
 int trs_train_steps_sgd(int net, const trs_tables* tables, const int32_t* stream_user_dev,
                         const int32_t* stream_item_dev, const int32_t* neg_static_dev, int64_t N,

@@ -8,14 +8,14 @@
 //                    derives the batch from the resident interaction stream (Feistel shuffle + Philox sampler,
 //                    = trs_batch_prepare); writes the per-triple score gradients gz+ / gz- (FM: through the sigmoid), the
 //                    user-row gradient du (B,D), the loss sum, and an ownership mark per referenced row.
-//   K1b mark_dups    a row whose ownership mark is not this reference's own has several references in the batch: stamp
-//                    it as duplicated (plain stores, no atomics, no resets: marks and stamps carry the step number).
-//   K2  item_update  re-reads the still-unmodified user rows (L2 / Infinity-Cache hot) and applies
-//                    item[i] -= lr*gz+ * u, item[j] -= lr*gz- * u (+ 1-wide terms): plain read-modify-write for rows
-//                    referenced once in the batch, float atomics (one 256-B wave-instruction per row segment) for
-//                    duplicated rows.  Touches only item tables.
-//   K3  user_update  user[u] -= lr*du (+ 1-wide term) from the staged rows, same plain / atomic split.  Touches only
-//                    user tables.
+//   K2a item_update<1> re-reads the still-unmodified user rows (L2 / Infinity-Cache hot) and applies
+//                    item[i] -= lr*gz+ * u, item[j] -= lr*gz- * u (+ 1-wide terms) for the references that OWN their
+//                    row (their K1 mark survived: exactly one per distinct row) with plain whole-row read-modify-writes;
+//                    stamps user rows that have several references (marks and stamps carry the step number: no resets).
+//   K2b item_update<2> the other references of duplicated item rows add with float atomics (one 256-B wave-instruction
+//                    per row segment).  K2a/K2b touch only item tables.
+//   K3  user_update  user[u] -= lr*du (+ 1-wide term) from the staged rows: plain for rows referenced once, atomics for
+//                    stamped rows.  Touches only user tables.
 // Float atomics run at ~1.3 TB/s chip-wide against ~6 TB/s for plain stores (MI355X_MICROARCH.md "Global float
 // atomics"), so every reference that is provably alone on its row takes the plain path.
 #include "score_kernels.h"
@@ -247,24 +247,6 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
   }
 }
 
-// K1b: a reference that does not find its own mark lost the row to another reference of the same step.
-__global__ __launch_bounds__(TRS_BLOCK) void mark_dups_kernel(const FastArgs a) {
-  const int64_t stride = (int64_t)gridDim.x * TRS_BLOCK;
-  const uint64_t hi = (uint64_t)a.stamp << 32;
-  for (int64_t t = (int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x; t < a.B; t += stride) {
-    const int64_t uid = a.user[t], pid = a.pos[t], nid = a.neg[t];
-    if ((uint64_t)uid >= (uint64_t)a.T.n_users || (uint64_t)pid >= (uint64_t)a.T.n_items ||
-        (uint64_t)nid >= (uint64_t)a.T.n_items)
-      continue;
-    if (a.uown[uid] != (hi | (uint64_t)(uint32_t)t)) a.udup[uid] = a.stamp;
-    if (a.iown[pid] != (hi | (uint64_t)(uint32_t)(2 * t))) a.idup[pid] = a.stamp;
-    if (a.iown[nid] != (hi | (uint64_t)(uint32_t)(2 * t + 1))) a.idup[nid] = a.stamp;
-  }
-}
-
-// K2 / K3 mapping: LPR lanes cover one row (4 B per lane: a D = 64 row is ONE 256-B wave-instruction, the full-rate
-// float-atomic shape); a wave works on U x (64 / LPR) triples per iteration with every load of the iteration issued
-// before the first store / atomic (no conditional block contains a load), KD = ceil(D / LPR) elements per lane.
 struct UpdIds {
   int64_t u, p, n;
   bool live;
@@ -284,7 +266,143 @@ __device__ __forceinline__ UpdIds upd_ids(const FastArgs& a, int64_t t) {
   return r;
 }
 
-template <int LPR, int KD, int U, bool DEDUP>
+// ---- plain (non-atomic) update passes in the K1 lane mapping: G lanes x VEC floats per row, 16 B per lane ------------
+// Rows whose update needs no atomic (one owner per distinct item row; user rows referenced once) are read, modified and
+// written whole with 16-byte accesses.  A reference that does not qualify loads row 0 instead (a hot line) and stores
+// nothing: no conditional block contains a load, and no random row is fetched for nothing.
+template <int VEC, int G, int K, bool FULL>
+__global__ __launch_bounds__(TRS_BLOCK) void item_owner_update_kernel(const FastArgs a) {
+  constexpr int N = K * VEC;
+  constexpr int TPW = TRS_WAVE / G;
+  constexpr int U = 2;
+  const trs_tables& T = a.T;
+  const int D = T.D;
+  const int64_t B = a.B;
+  const int lane = threadIdx.x & 63;
+  const int lig = lane % G;
+  const int64_t wave = ((int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x) >> 6;
+  const int64_t nwave = ((int64_t)gridDim.x * TRS_BLOCK) >> 6;
+  const int64_t per_it = (int64_t)TPW * U;
+  const int64_t niter = (B + per_it - 1) / per_it;
+  const uint64_t hi = (uint64_t)a.stamp << 32;
+  for (int64_t it = wave; it < niter; it += nwave) {
+    UpdIds id[U];
+    int64_t t[U];
+    bool po[U], no[U], ud[U];
+    float cp[U], cn[U], pl[U], nl[U];
+    RowReg<VEC, K> u[U], pr[U], nr[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      t[k] = it * per_it + k * TPW + lane / G;
+      id[k] = upd_ids(a, t[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int64_t tc = id[k].live ? t[k] : 0;
+      cp[k] = -a.lr * a.gz[tc];
+      cn[k] = -a.lr * a.gz[B + tc];
+      po[k] = id[k].live && a.iown[id[k].p] == (hi | (uint64_t)(uint32_t)(2 * tc));
+      no[k] = id[k].live && a.iown[id[k].n] == (hi | (uint64_t)(uint32_t)(2 * tc + 1));
+      ud[k] = id[k].live && a.uown[id[k].u] != (hi | (uint64_t)(uint32_t)tc);
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int64_t pr_ = po[k] ? id[k].p : 0, nr_ = no[k] ? id[k].n : 0;
+      row_load<VEC, G, K, FULL>(u[k], T.user, (po[k] || no[k]) ? id[k].u : 0, D, lig);
+      row_load<VEC, G, K, FULL>(pr[k], T.item, pr_, D, lig);
+      row_load<VEC, G, K, FULL>(nr[k], T.item, nr_, D, lig);
+      pl[k] = T.item_lin[pr_];
+      nl[k] = T.item_lin[nr_];
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      if (po[k]) {
+        RowReg<VEC, K> o;
+#pragma unroll
+        for (int n = 0; n < N; ++n) o.v[n] = pr[k].v[n] + cp[k] * u[k].v[n];
+        row_store<VEC, G, K>(o, T.item + id[k].p * (int64_t)D, D, lig);
+        if (lig == 0) T.item_lin[id[k].p] = pl[k] + cp[k];
+      }
+      if (no[k]) {
+        RowReg<VEC, K> o;
+#pragma unroll
+        for (int n = 0; n < N; ++n) o.v[n] = nr[k].v[n] + cn[k] * u[k].v[n];
+        row_store<VEC, G, K>(o, T.item + id[k].n * (int64_t)D, D, lig);
+        if (lig == 0) T.item_lin[id[k].n] = nl[k] + cn[k];
+      }
+      if (ud[k] && lig == 0) a.udup[id[k].u] = a.stamp;
+    }
+  }
+}
+
+template <int VEC, int G, int K, bool FULL>
+__global__ __launch_bounds__(TRS_BLOCK) void user_plain_update_kernel(const FastArgs a) {
+  constexpr int N = K * VEC;
+  constexpr int TPW = TRS_WAVE / G;
+  constexpr int U = 2;
+  const trs_tables& T = a.T;
+  const int D = T.D;
+  const int64_t B = a.B;
+  const int lane = threadIdx.x & 63;
+  const int lig = lane % G;
+  const int64_t wave = ((int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x) >> 6;
+  const int64_t nwave = ((int64_t)gridDim.x * TRS_BLOCK) >> 6;
+  const int64_t per_it = (int64_t)TPW * U;
+  const int64_t niter = (B + per_it - 1) / per_it;
+  for (int64_t it = wave; it < niter; it += nwave) {
+    UpdIds id[U];
+    int64_t t[U];
+    bool al[U];
+    float c[U], wl[U];
+    RowReg<VEC, K> g[U], w[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      t[k] = it * per_it + k * TPW + lane / G;
+      id[k] = upd_ids(a, t[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int64_t tc = id[k].live ? t[k] : 0;
+      c[k] = -a.lr * (a.gz[tc] + a.gz[B + tc]);
+      al[k] = id[k].live && a.udup[id[k].u] != a.stamp;
+      row_load<VEC, G, K, FULL>(g[k], a.du, tc, D, lig);
+      row_load<VEC, G, K, FULL>(w[k], T.user, al[k] ? id[k].u : 0, D, lig);
+      wl[k] = T.user_lin[al[k] ? id[k].u : 0];
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      if (!id[k].live) continue;
+      float* urow = T.user + id[k].u * (int64_t)D;
+      if (al[k]) {
+        RowReg<VEC, K> o;
+#pragma unroll
+        for (int n = 0; n < N; ++n) o.v[n] = w[k].v[n] + (-a.lr) * g[k].v[n];
+        row_store<VEC, G, K>(o, urow, D, lig);
+        if (lig == 0) T.user_lin[id[k].u] = wl[k] + c[k];
+      } else {  // duplicated user row (rare): float atomics, element by element
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) {
+          const int e = (kk * G + lig) * VEC;
+#pragma unroll
+          for (int q = 0; q < VEC; ++q)
+            if (e + q < D) atomicAdd(urow + e + q, -a.lr * g[k].v[kk * VEC + q]);
+        }
+        if (lig == 0) atomicAdd(T.user_lin + id[k].u, c[k]);
+      }
+    }
+  }
+}
+
+// K2 / K3 mapping: LPR lanes cover one row (4 B per lane: a D = 64 row is ONE 256-B wave-instruction, the full-rate
+// float-atomic shape); a wave works on U x (64 / LPR) triples per iteration with every load of the iteration issued
+// before the first store / atomic (no conditional block contains a load), KD = ceil(D / LPR) elements per lane.
+// MODE 0: every reference updates its item row with float atomics (no scratch).
+// MODE 1 (phase a): only the reference that OWNS its row (its K1 mark survived) updates it, with a plain whole-row
+//         read-modify-write — one owner per distinct row, so no two writers; also stamps duplicated user rows for K3.
+// MODE 2 (phase b, a later launch): the remaining references add with float atomics.
+// Splitting by ownership instead of "row has duplicates" moves one reference of every duplicated row (c2: 56 % of all
+// item references are owners) from the ~1.3 TB/s atomic path to plain stores.
+template <int LPR, int KD, int U, int MODE>
 __global__ __launch_bounds__(TRS_BLOCK) void item_update_kernel(const FastArgs a) {
   constexpr int EPW = TRS_WAVE / LPR;
   const trs_tables& T = a.T;
@@ -296,10 +414,11 @@ __global__ __launch_bounds__(TRS_BLOCK) void item_update_kernel(const FastArgs a
   const int64_t nwave = ((int64_t)gridDim.x * TRS_BLOCK) >> 6;
   const int64_t per_it = (int64_t)EPW * U;
   const int64_t niter = (B + per_it - 1) / per_it;
+  const uint64_t hi = (uint64_t)a.stamp << 32;
   for (int64_t it = wave; it < niter; it += nwave) {
     UpdIds id[U];
     float cp[U], cn[U], uv[U][KD], pv[U][KD], nv[U][KD], pl[U], nl[U];
-    bool pa[U], na[U];
+    bool po[U], no[U], ud[U];  // pos / neg reference owns its row; user row is duplicated
     int64_t t[U];
 #pragma unroll
     for (int k = 0; k < U; ++k) {
@@ -311,17 +430,25 @@ __global__ __launch_bounds__(TRS_BLOCK) void item_update_kernel(const FastArgs a
       const int64_t tc = id[k].live ? t[k] : 0;
       cp[k] = -a.lr * a.gz[tc];
       cn[k] = -a.lr * a.gz[B + tc];
-      pa[k] = DEDUP ? a.idup[id[k].p] != a.stamp : false;
-      na[k] = DEDUP ? a.idup[id[k].n] != a.stamp : false;
-      pl[k] = T.item_lin[id[k].p];
-      nl[k] = T.item_lin[id[k].n];
+      po[k] = no[k] = ud[k] = false;
+      if (MODE != 0) {
+        po[k] = a.iown[id[k].p] == (hi | (uint64_t)(uint32_t)(2 * tc));
+        no[k] = a.iown[id[k].n] == (hi | (uint64_t)(uint32_t)(2 * tc + 1));
+      }
+      if (MODE == 1) ud[k] = a.uown[id[k].u] != (hi | (uint64_t)(uint32_t)tc);
 #pragma unroll
       for (int q = 0; q < KD; ++q) {
         const int d = q * LPR + lir;
         const int dc = d < D ? d : 0;
-        uv[k][q] = T.user[id[k].u * (int64_t)D + dc];
-        pv[k][q] = T.item[id[k].p * (int64_t)D + dc];
-        nv[k][q] = T.item[id[k].n * (int64_t)D + dc];
+        uv[k][q] = T.user[((MODE == 2 && po[k] && no[k]) ? 0 : id[k].u) * (int64_t)D + dc];
+        if (MODE == 1) {
+          pv[k][q] = T.item[id[k].p * (int64_t)D + dc];
+          nv[k][q] = T.item[id[k].n * (int64_t)D + dc];
+        }
+      }
+      if (MODE == 1) {
+        pl[k] = T.item_lin[id[k].p];
+        nl[k] = T.item_lin[id[k].n];
       }
     }
 #pragma unroll
@@ -333,13 +460,24 @@ __global__ __launch_bounds__(TRS_BLOCK) void item_update_kernel(const FastArgs a
       for (int q = 0; q < KD; ++q) {
         const int d = q * LPR + lir;
         if (d < D) {
-          if (pa[k]) prow[d] = pv[k][q] + cp[k] * uv[k][q]; else atomicAdd(prow + d, cp[k] * uv[k][q]);
-          if (na[k]) nrow[d] = nv[k][q] + cn[k] * uv[k][q]; else atomicAdd(nrow + d, cn[k] * uv[k][q]);
+          if (MODE == 1) {
+            if (po[k]) prow[d] = pv[k][q] + cp[k] * uv[k][q];
+            if (no[k]) nrow[d] = nv[k][q] + cn[k] * uv[k][q];
+          } else {
+            if (!po[k]) atomicAdd(prow + d, cp[k] * uv[k][q]);
+            if (!no[k]) atomicAdd(nrow + d, cn[k] * uv[k][q]);
+          }
         }
       }
       if (lir == 0) {
-        if (pa[k]) T.item_lin[id[k].p] = pl[k] + cp[k]; else atomicAdd(T.item_lin + id[k].p, cp[k]);
-        if (na[k]) T.item_lin[id[k].n] = nl[k] + cn[k]; else atomicAdd(T.item_lin + id[k].n, cn[k]);
+        if (MODE == 1) {
+          if (po[k]) T.item_lin[id[k].p] = pl[k] + cp[k];
+          if (no[k]) T.item_lin[id[k].n] = nl[k] + cn[k];
+          if (ud[k]) a.udup[id[k].u] = a.stamp;
+        } else {
+          if (!po[k]) atomicAdd(T.item_lin + id[k].p, cp[k]);
+          if (!no[k]) atomicAdd(T.item_lin + id[k].n, cn[k]);
+        }
       }
     }
   }
@@ -445,22 +583,62 @@ static int launch_fwd_stage(const FastArgs& a, hipStream_t s) {
   return TRS_E_ARG;
 }
 
-static int launch_updates(const FastArgs& a, hipStream_t s, hipEvent_t ev_k2, hipEvent_t ev_k3) {
+template <int WHICH>  // 0: item owners (K2a), 1: users (K3)
+static int launch_plain(const FastArgs& a, hipStream_t s) {
+  RowCfg c;
+  if (!pick_row_cfg(a.T.D, c)) {
+    trs_set_error("unsupported n_factors D=%d", a.T.D);
+    return TRS_E_ARG;
+  }
+  const int per = (TRS_WAVE / c.g) * 2;
+  const dim3 gr(trs_grid((a.B + per - 1) / per, TRS_BLOCK / TRS_WAVE)), bl(TRS_BLOCK);
+#define TRS_PL(V, GG, KK, FULL)                                                                        \
+  {                                                                                                    \
+    if (WHICH == 0) hipLaunchKernelGGL((item_owner_update_kernel<V, GG, KK, FULL>), gr, bl, 0, s, a);  \
+    else hipLaunchKernelGGL((user_plain_update_kernel<V, GG, KK, FULL>), gr, bl, 0, s, a);             \
+  }
+#define TRS_CASE(V, GG, KK)                                                                     \
+  if (c.vec == V && c.g == GG && c.k == KK) {                                                   \
+    if (V * GG * KK == a.T.D) TRS_PL(V, GG, KK, true) else TRS_PL(V, GG, KK, false)             \
+    TRS_CHECK_LAUNCH("plain update kernel");                                                    \
+    return TRS_OK;                                                                              \
+  }
+  TRS_CASE(4, 2, 1)
+  TRS_CASE(4, 4, 1)
+  TRS_CASE(4, 8, 1)
+  TRS_CASE(4, 16, 1)
+  TRS_CASE(4, 32, 1)
+  TRS_CASE(4, 64, 1)
+  TRS_CASE(4, 64, 2)
+  TRS_CASE(4, 64, 4)
+  TRS_CASE(1, 4, 1)
+  TRS_CASE(1, 16, 1)
+  TRS_CASE(1, 64, 1)
+  TRS_CASE(1, 64, 4)
+#undef TRS_CASE
+#undef TRS_PL
+  trs_set_error("internal: no kernel for D=%d", a.T.D);
+  return TRS_E_ARG;
+}
+
+static int launch_updates(const FastArgs& a, hipStream_t s, hipEvent_t ev_k3) {
   const int D = a.T.D;
   if (a.uown) {
-    hipLaunchKernelGGL(mark_dups_kernel, dim3(trs_grid(a.B, TRS_BLOCK)), dim3(TRS_BLOCK), 0, s, a);
-    TRS_CHECK_LAUNCH("mark_dups_kernel");
+    int rc = launch_plain<0>(a, s);  // K2a: owners, plain
+    if (rc) return rc;
   }
-  if (ev_k2) (void)hipEventRecord(ev_k2, s);
 #define TRS_UPD(L, KD, U)                                                                            \
   {                                                                                                  \
     constexpr int PER = (TRS_WAVE / L) * U;                                                          \
-    const int grid = trs_grid((a.B + PER - 1) / PER, TRS_BLOCK / TRS_WAVE);                          \
-    if (a.uown) hipLaunchKernelGGL((item_update_kernel<L, KD, U, true>), dim3(grid), dim3(TRS_BLOCK), 0, s, a);   \
-    else hipLaunchKernelGGL((item_update_kernel<L, KD, U, false>), dim3(grid), dim3(TRS_BLOCK), 0, s, a);        \
-    if (ev_k3) (void)hipEventRecord(ev_k3, s);                                                       \
-    if (a.uown) hipLaunchKernelGGL((user_update_kernel<L, KD, U, true>), dim3(grid), dim3(TRS_BLOCK), 0, s, a);   \
-    else hipLaunchKernelGGL((user_update_kernel<L, KD, U, false>), dim3(grid), dim3(TRS_BLOCK), 0, s, a);        \
+    const dim3 gr(trs_grid((a.B + PER - 1) / PER, TRS_BLOCK / TRS_WAVE)), bl(TRS_BLOCK);             \
+    if (a.uown) {                                                                                    \
+      hipLaunchKernelGGL((item_update_kernel<L, KD, U, 2>), gr, bl, 0, s, a);                        \
+      if (ev_k3) (void)hipEventRecord(ev_k3, s);                                                     \
+    } else {                                                                                         \
+      hipLaunchKernelGGL((item_update_kernel<L, KD, U, 0>), gr, bl, 0, s, a);                        \
+      if (ev_k3) (void)hipEventRecord(ev_k3, s);                                                     \
+      hipLaunchKernelGGL((user_update_kernel<L, KD, U, false>), gr, bl, 0, s, a);                    \
+    }                                                                                                \
   }
   if (D > 256) TRS_UPD(64, 16, 1)
   else if (D > 128) TRS_UPD(64, 4, 2)
@@ -473,6 +651,7 @@ static int launch_updates(const FastArgs& a, hipStream_t s, hipEvent_t ev_k2, hi
   else TRS_UPD(1, 1, 1)
 #undef TRS_UPD
   TRS_CHECK_LAUNCH("item/user_update_kernel");
+  if (a.uown) return launch_plain<1>(a, s);  // K3: users, plain (atomics for the few duplicated rows)
   return TRS_OK;
 }
 
@@ -545,7 +724,7 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
     int rc = net == TRS_NET_FM ? launch_fwd_stage<TRS_NET_FM>(a, s) : launch_fwd_stage<TRS_NET_LINEAR>(a, s);
     if (rc) return rc;
     if (ev) (void)hipEventRecord(ev[1], s);
-    rc = launch_updates(a, s, nullptr, ev ? ev[2] : nullptr);
+    rc = launch_updates(a, s, ev ? ev[2] : nullptr);
     if (rc) return rc;
     if (ev) (void)hipEventRecord(ev[3], s);
   }

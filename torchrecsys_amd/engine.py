@@ -142,7 +142,7 @@ class SparseScorerTrainer:
         ke = self.kernel_events
         for s in range(len(evs) // 4):
             ke.setdefault("fwd_stage_kernel", []).append((evs[4 * s], evs[4 * s + 1]))
-            ke.setdefault("item_update_kernel", []).append((evs[4 * s + 1], evs[4 * s + 2]))  # + mark_dups_kernel
+            ke.setdefault("item_update_kernel", []).append((evs[4 * s + 1], evs[4 * s + 2]))  # phases a + b
             ke.setdefault("user_update_kernel", []).append((evs[4 * s + 2], evs[4 * s + 3]))
 
     def fast_stream_steps(self, st, shuffle_key, sample_seed, first_pos, batch, n_steps, loss_sums):
