@@ -147,7 +147,9 @@ def main():
     }
     # ---- roofline of the dominant kernel: algorithmic bytes per launch / mean launch duration (HIP events) ----
     if events:
-        mean_ms = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in events.items()}
+        def _ms(rec):  # (TimingEvents, i, j) from the C step loop, or (torch start, torch end) from the generic path
+            return rec[0].elapsed_ms(rec[1], rec[2]) if len(rec) == 3 else rec[0].elapsed_time(rec[1])
+        mean_ms = {k: sum(_ms(r) for r in v) / len(v) for k, v in events.items()}
         dom = max(mean_ms, key=mean_ms.get)
         # algorithmic bytes per triple of each kernel (DESIGN.md "Kernels"): the forward+backward pass reads the ids and
         # the R rows (+1-wide terms) once: 16 + R(4D+4) + 8; the update pass writes the R rows once: 12 + R(4D+4)
@@ -156,9 +158,20 @@ def main():
                       # rows (+terms) and needs the user row; K3 writes the user row (+term)
                       "fwd_stage_kernel": 16 + R * (4 * D + 4) + 8, "item_update_kernel": 12 + 3 * (4 * D + 4),
                       "user_update_kernel": 4 + (4 * D + 4)}
+        # "item_update_kernel" = the two launches item_owner_update_kernel (plain) + item_update_kernel<.,2> (atomics)
         ach = per_triple[dom] * B / (mean_ms[dom] * 1e-3) / 1e9
+        # measured HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
+        # corrected as MI355X_MICROARCH.md prescribes); valid for the c2 workload on one GPU only
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if args.config == "c2" and os.path.exists(pmc_path):
+            pk = json.load(open(pmc_path))["kernels"]
+            parts = {"item_update_kernel": ("item_owner_update_kernel", "item_update_kernel"),
+                     "fwd_stage_kernel": ("fwd_stage_kernel",), "user_update_kernel": ("user_plain_update_kernel",)}
+            if all(q in pk for q in parts.get(dom, ("?",))):
+                traffic = sum(pk[q]["traffic_bytes_per_launch"] for q in parts[dom])
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                            "mean_launch_us": {k: 1e3 * v for k, v in mean_ms.items()},
                            "algorithmic_bytes_per_triple": per_triple[dom]}
     # ---- CPU baseline: the op-sequence port of the reference's fit() loop on this box's host cores ----

@@ -81,6 +81,12 @@ int trs_abi_version(void);
 /* 0 if the current HIP device is gfx950, TRS_E_DEVICE otherwise. */
 int trs_check_device(void);
 
+/* HIP timing events owned by the library (bench.py times the dominant kernel with them on the launch stream).
+ * create: n new events; elapsed_ms: host-side read after the stream was synchronised. */
+int trs_events_create(int32_t n, void** handles_out);
+int trs_events_destroy(int32_t n, void** handles);
+int trs_events_elapsed_ms(void* start, void* stop, float* ms_out);
+
 /* ------------------------------------------------------------------------- loader / sampler (a9, a10) */
 /* Counter-based dynamic negative sampler: neg[t] uniform over {0..n_items-1} \ {pos[t]} — the distribution of the
  * rejection loop at dataset/dataset.py:440-445 (reject only the row's own positive).  Stream: Philox4x32-10,
@@ -146,7 +152,7 @@ int trs_score_backward(int net, const trs_tables* tables, const trs_batch* batch
  * Same results as trs_score_fwd_bwd + trs_score_sgd_update (to summation order of duplicate rows).
  * scratch: NULL or trs_train_scratch_bytes(n_users, n_items, batch, D) bytes, zero-initialised once; first_stamp: step counter
  * of the first step, non-zero, strictly increasing over the life of the scratch (re-zero the scratch before it wraps).
- * events: NULL, or 4*n_steps hipEvent_t handles recorded at the K1 | K2a+K2b | K3 boundaries of every step (bench.py). */
+ * events: NULL, or 4*n_steps hipEvent_t handles recorded at the K1 | K2a+K2b | K3 boundaries of each step (a step whose handles are NULL is not timed) (bench.py). */
 int64_t trs_train_scratch_bytes(int64_t n_users, int64_t n_items, int64_t batch, int32_t D);
 int trs_train_steps_sgd(int net, const trs_tables* tables, const int32_t* stream_user_dev,
                         const int32_t* stream_item_dev, const int32_t* neg_static_dev, int64_t N,

@@ -59,6 +59,9 @@ PROTOTYPES = {
     "trs_last_error": (C.c_char_p, []),
     "trs_abi_version": (C.c_int, []),
     "trs_check_device": (C.c_int, []),
+    "trs_events_create": (C.c_int, [_i32, C.POINTER(C.c_void_p)]),
+    "trs_events_destroy": (C.c_int, [_i32, C.POINTER(C.c_void_p)]),
+    "trs_events_elapsed_ms": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
     "trs_sample_neg": (C.c_int, [_vp, C.c_int, _i64, _i64, _u64, _u64, _vp, _vp]),
     "trs_batch_prepare": (C.c_int, [_vp, _vp, _vp, _i64, _u64, _i64, _i64, _i64, _u64, _u64, _vp, _i32,
                                     _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -35,3 +35,34 @@ extern "C" int trs_check_device(void) {
   }
   return TRS_OK;
 }
+
+// ---- timing events for bench.py (HIP events on the stream the kernels are launched on) --------------------------
+extern "C" int trs_events_create(int32_t n, void** handles_out) {
+  TRS_REQUIRE(n >= 0 && (n == 0 || handles_out), "trs_events_create: bad arguments");
+  for (int32_t i = 0; i < n; ++i) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) {
+      trs_set_error("trs_events_create: hipEventCreate failed");
+      (void)hipGetLastError();
+      return TRS_E_LAUNCH;
+    }
+    handles_out[i] = (void*)e;
+  }
+  return TRS_OK;
+}
+
+extern "C" int trs_events_destroy(int32_t n, void** handles) {
+  for (int32_t i = 0; i < n; ++i)
+    if (handles && handles[i]) (void)hipEventDestroy((hipEvent_t)handles[i]);
+  return TRS_OK;
+}
+
+extern "C" int trs_events_elapsed_ms(void* start, void* stop, float* ms_out) {
+  TRS_REQUIRE(start && stop && ms_out, "trs_events_elapsed_ms: NULL argument");
+  if (hipEventElapsedTime(ms_out, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) {
+    trs_set_error("trs_events_elapsed_ms: events not complete (synchronise the stream first)");
+    (void)hipGetLastError();
+    return TRS_E_LAUNCH;
+  }
+  return TRS_OK;
+}

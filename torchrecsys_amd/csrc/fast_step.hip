@@ -719,7 +719,8 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
     a.sample_offset = (uint64_t)a.t0;
     a.loss_sum = loss_sums_dev + st;
     a.stamp = first_stamp + (uint32_t)st;
-    hipEvent_t* ev = events ? (hipEvent_t*)events + 4 * (int64_t)st : nullptr;  // K1 | K1b+K2 | K3 boundaries
+    hipEvent_t* ev = events ? (hipEvent_t*)events + 4 * (int64_t)st : nullptr;  // K1 | K2a+K2b | K3 boundaries
+    if (ev && !ev[0]) ev = nullptr;  // a step whose four handles are NULL is not timed (sampled timing)
     if (ev) (void)hipEventRecord(ev[0], s);
     int rc = net == TRS_NET_FM ? launch_fwd_stage<TRS_NET_FM>(a, s) : launch_fwd_stage<TRS_NET_LINEAR>(a, s);
     if (rc) return rc;

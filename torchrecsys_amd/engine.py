@@ -132,28 +132,35 @@ class SparseScorerTrainer:
         self.stamp += n
         return first
 
-    def _make_events(self, n_steps):
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(4 * n_steps)]
-        for e in evs:
-            e.record()  # creates the underlying hipEvent_t; re-recorded by the C step loop
-        return evs
+    EVENT_EVERY = 8  # bench timing samples one step in 8
 
-    def _collect_events(self, evs):
+    def _make_events(self, n_steps):
+        """Raw hipEvent_t handles, 4 per sampled step (None for the others), owned by an ops.TimingEvents."""
+        self._ev_count = getattr(self, "_ev_count", 0)
+        sampled = [s for s in range(n_steps) if (self._ev_count + s) % self.EVENT_EVERY == 0]
+        self._ev_count += n_steps
+        te = ops.TimingEvents(4 * len(sampled))
+        evs = [None] * (4 * n_steps)
+        for j, s in enumerate(sampled):
+            evs[4 * s:4 * s + 4] = [te.handles[4 * j + q] for q in range(4)]
+        return te, evs, len(sampled)
+
+    def _collect_events(self, te, n_sampled):
         ke = self.kernel_events
-        for s in range(len(evs) // 4):
-            ke.setdefault("fwd_stage_kernel", []).append((evs[4 * s], evs[4 * s + 1]))
-            ke.setdefault("item_update_kernel", []).append((evs[4 * s + 1], evs[4 * s + 2]))  # phases a + b
-            ke.setdefault("user_update_kernel", []).append((evs[4 * s + 2], evs[4 * s + 3]))
+        for j in range(n_sampled):
+            ke.setdefault("fwd_stage_kernel", []).append((te, 4 * j, 4 * j + 1))
+            ke.setdefault("item_update_kernel", []).append((te, 4 * j + 1, 4 * j + 2))  # phases a + b
+            ke.setdefault("user_update_kernel", []).append((te, 4 * j + 2, 4 * j + 3))
 
     def fast_stream_steps(self, st, shuffle_key, sample_seed, first_pos, batch, n_steps, loss_sums):
         """n_steps fused steps straight from the resident stream `st` (dict user/pos/neg int32); loss_sums: (n_steps,)
         view.  Only valid when self.fast_lr is not None and batch == capacity."""
-        evs = self._make_events(n_steps) if self.kernel_events is not None else None
+        te, evs, ns = self._make_events(n_steps) if self.kernel_events is not None else (None, None, 0)
         ops.train_steps_sgd(self.net.NET, self.net.tables(), st["user"], st["pos"], st["neg"], shuffle_key,
                             sample_seed, first_pos, batch, n_steps, self.fast_lr, *self.id_bufs, self.gz, self.du,
                             loss_sums, self.err, self.scratch, self._stamps(n_steps), evs)
-        if evs is not None:
-            self._collect_events(evs)
+        if te is not None:
+            self._collect_events(te, ns)
 
     def step(self, ids, loss_slot, auc_slot=None):
         """ids: dict user/pos/neg[/pos_meta/neg_meta] of GPU id tensors.  loss_slot: 1-element fp32 view that receives
@@ -161,12 +168,12 @@ class SparseScorerTrainer:
         B = ids["user"].shape[0]
         net = self.net
         if self.fast_lr is not None and auc_slot is None and ids["user"].dtype == torch.int32:
-            evs = self._make_events(1) if self.kernel_events is not None else None
+            te, evs, ns = self._make_events(1) if self.kernel_events is not None else (None, None, 0)
             ops.train_steps_sgd(net.NET, net.tables(), None, None, None, 0, 0, 0, B, 1, self.fast_lr, ids["user"],
                                 ids["pos"], ids["neg"], self.gz, self.du, loss_slot, self.err, self.scratch,
                                 self._stamps(1), evs)
-            if evs is not None:
-                self._collect_events(evs)
+            if te is not None:
+                self._collect_events(te, ns)
             return
         T = net.tables()
         Bt, keep = ops.make_batch(ids["user"], ids["pos"], ids["neg"], ids.get("pos_meta"), ids.get("neg_meta"),

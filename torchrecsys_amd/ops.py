@@ -116,6 +116,26 @@ def score_sgd_update(net, T, Bt, grad_rows, grad_lin, lr):
                                            float(lr), _stream()), "trs_score_sgd_update")
 
 
+class TimingEvents:
+    """n HIP events created by the library; elapsed(i, j) after the stream was synchronised."""
+
+    def __init__(self, n):
+        self.n = n
+        self.handles = (C.c_void_p * n)()
+        check(_lib.load().trs_events_create(n, self.handles), "trs_events_create")
+
+    def elapsed_ms(self, i, j):
+        out = C.c_float()
+        check(_lib.load().trs_events_elapsed_ms(self.handles[i], self.handles[j], C.byref(out)), "trs_events_elapsed_ms")
+        return out.value
+
+    def __del__(self):
+        try:
+            _lib.load().trs_events_destroy(self.n, self.handles)
+        except Exception:
+            pass
+
+
 def train_scratch(n_users, n_items, batch, D, device):
     """Zeroed scratch of trs_train_steps_sgd (ownership marks, duplicate stamps, item-bucket lists)."""
     nbytes = _lib.load().trs_train_scratch_bytes(int(n_users), int(n_items), int(batch), int(D))
@@ -129,7 +149,7 @@ def train_steps_sgd(net, T, stream_user, stream_item, neg_static, shuffle_key, s
     user/pos/neg_buf.  events: optional flat list of 4*n_steps torch.cuda.Event (already created by a record())."""
     ev = None
     if events is not None:
-        ev = (C.c_void_p * len(events))(*[e.cuda_event for e in events])
+        ev = (C.c_void_p * len(events))(*events)  # raw hipEvent_t handles (or None = step not timed)
     N = 0 if stream_user is None else stream_user.numel()
     check(_lib.load().trs_train_steps_sgd(NET_ID[net], C.byref(T), ptr(stream_user), ptr(stream_item), ptr(neg_static),
                                           N, int(shuffle_key), int(sample_seed), int(first_pos), int(batch),
