@@ -173,6 +173,26 @@ def test_g2_mlp_trainer_trajectories(name, M, oname):
 
 
 @pytest.mark.parametrize("name", SPARSE_NETS)
+def test_adam_on_sparse_tables_gets_lazy_adam_semantics(name):
+    """torch.optim.Adam (the README quick-start optimiser, which the reference cannot run on sparse gradients) follows
+    the SparseAdam trajectory of the golden run, with its moments in optimizer.state under Adam's key names."""
+    from torchrecsys_amd.engine import SparseScorerTrainer
+    g = load_golden(f"g2_{name}_M1_sparseadam.npz")
+    net, b = build_net(name, 1, g), golden_batch(g)
+    opt = torch.optim.Adam(list(net.parameters()), lr=0.01)
+    tr = SparseScorerTrainer(net, opt, 64)
+    assert tr.kind == "sparse_adam"
+    ids = dev_ids(net, b)
+    losses = torch.zeros(3, dtype=torch.float32, device=DEV)
+    for t in range(3):
+        tr.step(ids, losses[t:t + 1])
+        for k, v in sub(g, f"step{t}").items():
+            assert rel_err(net.state_dict()[k].cpu().numpy(), v) < 5 * TOL, (k, t)
+    st = opt.state[net.user.weight]
+    assert float(st["step"]) == 3.0 and set(st) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+@pytest.mark.parametrize("name", SPARSE_NETS)
 def test_generic_backward_path_with_any_optimizer(name):
     """TorchRecSys.forward + hinge_loss + TorchRecSys.backward (reference model.py:171-200) with SparseAdam."""
     from torchrecsys_amd.helper.loss import hinge_loss

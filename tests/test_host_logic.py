@@ -150,6 +150,8 @@ def test_optimizer_dispatch():
     assert classify_optimizer(torch.optim.SparseAdam(ps, lr=0.1), ps) == "sparse_adam"
     assert classify_optimizer(torch.optim.Adagrad(ps, lr=0.1), ps) == "adagrad"
     assert classify_optimizer(torch.optim.Adagrad(ps, lr=0.1, weight_decay=0.1), ps) == "generic"
+    assert classify_optimizer(torch.optim.Adam(ps, lr=0.1), ps) == "sparse_adam"  # lazy rows (torch's Adam cannot)
+    assert classify_optimizer(torch.optim.Adam(ps, lr=0.1, weight_decay=1e-5), ps) == "generic"
     assert classify_optimizer(torch.optim.RMSprop(ps, lr=0.1), ps) == "generic"
     assert classify_optimizer(torch.optim.SGD(ps[:1], lr=0.1), ps) == "generic"  # a parameter the optimiser lacks
 

@@ -35,6 +35,12 @@ def classify_optimizer(optimizer, params):
         return "sgd" if ok else "generic"
     if t is torch.optim.SparseAdam:
         return "sparse_adam" if all(not g.get("maximize", False) for g in groups) else "generic"
+    if t is torch.optim.Adam:
+        # torch.optim.Adam raises on sparse gradients, so the reference cannot run it on these tables at all (SURVEY
+        # §0.3, README quick-start).  Here it gets SparseAdam's lazy semantics (touched rows only) with Adam's own
+        # hyper-parameters; moments live in optimizer.state[p] under Adam's key names.
+        ok = all(g["weight_decay"] == 0 and not g.get("amsgrad", False) and not g.get("maximize", False) for g in groups)
+        return "sparse_adam" if ok else "generic"
     if t is torch.optim.Adagrad:
         ok = all(g["weight_decay"] == 0 and not g.get("maximize", False) for g in groups)
         return "adagrad" if ok else "generic"
@@ -64,7 +70,7 @@ def apply_rows(kind, optimizer, p, rs, idx, vals, ld=None):
     ops.rows_scatter_add(rs.acc, idx, vals, 1.0, ld=ld)
     if kind == "sparse_adam":
         if len(st) == 0:
-            st["step"] = 0
+            st["step"] = torch.tensor(0.0) if type(optimizer) is torch.optim.Adam else 0
             st["exp_avg"] = torch.zeros_like(p.data)
             st["exp_avg_sq"] = torch.zeros_like(p.data)
         st["step"] += 1

@@ -153,11 +153,7 @@ class MLPTrainer:
         self.net, self.opt = net, optimizer
         self.emb_params = net.embedding_params()
         self.dense_params = net.dense_params()
-        self.kind = classify_optimizer(optimizer, self.emb_params)
-        if type(optimizer) is torch.optim.Adam and all(_group_of(optimizer, p) is not None for p in self.emb_params):
-            # the reference cannot run Adam on sparse gradients at all; here: lazy (touched-rows-only)
-            # Adam on the tables — SparseAdam's semantics — and torch's dense Adam on fcs/bns/output_layer
-            self.kind = "sparse_adam"
+        self.kind = classify_optimizer(optimizer, self.emb_params)  # torch.optim.Adam -> lazy rows + dense Adam
         self.dev = self.emb_params[0].device
         self.bucket = tdist.FlatGradBucket(self.dense_params)
         self.err = net._err_flag()
@@ -202,22 +198,7 @@ class MLPTrainer:
                 self._rows(p, idx, dx0[:, f * D:], ld)
 
     def _rows(self, p, idx, vals, ld):
-        opt = self.opt
-        if self.kind == "sparse_adam" and type(opt) is torch.optim.Adam:
-            g = _group_of(opt, p)
-            st = opt.state[p]
-            rs = self.row_state[id(p)]
-            if len(st) == 0:
-                st["step"] = torch.tensor(0.0)
-                st["exp_avg"] = torch.zeros_like(p.data)
-                st["exp_avg_sq"] = torch.zeros_like(p.data)
-            st["step"] += 1
-            ops.rows_scatter_add(rs.acc, idx, vals, 1.0, ld=ld)
-            b1, b2 = g["betas"]
-            ops.rows_apply_sparse_adam(p.data, rs.acc, st["exp_avg"], st["exp_avg_sq"], rs.stamp, idx, rs.next_id(),
-                                       g["lr"], b1, b2, g["eps"], int(st["step"]))
-        else:
-            apply_rows(self.kind, opt, p, self.row_state[id(p)], idx, vals, ld)
+        apply_rows(self.kind, self.opt, p, self.row_state[id(p)], idx, vals, ld)
 
     def check_errors(self):
         self.net._check_err("fit")
