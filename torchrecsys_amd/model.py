@@ -18,6 +18,7 @@ import pandas as pd
 import torch
 import torch.profiler
 
+from . import dist as tdist
 from . import ops
 from .collaborative._scorer import check_err_flag
 from .collaborative.fm import FM
@@ -144,6 +145,8 @@ class TorchRecSys(torch.nn.Module):
         # parameters are created on the host from torch's CPU generator (bit-identical init), then live in HBM
         if torch.cuda.is_available():
             self.net = self.net.to(_device())
+            if tdist.world_info()[1] > 1:  # data parallel: every replica starts from rank 0's weights
+                tdist.broadcast_([p.data for p in self.net.parameters()] + [b for b in self.net.buffers()])
 
     # ------------------------------------------------------------------------------------------------ forward
     def forward(self, net, batch):
@@ -191,10 +194,24 @@ class TorchRecSys(torch.nn.Module):
         dt, dev = self._id_dtype(), _device()
         return {k: v.to(dt).contiguous().to(dev, non_blocking=True) for k, v in ep.items()}
 
+    def _rank_rows(self, data):
+        """This rank's contiguous shard of a split under data parallelism (the whole split in a single process)."""
+        rank, world = tdist.world_info()
+        if world == 1:
+            return data
+        key = id(data)
+        if self._dev_cache.get('shard_key') != key:
+            n = data['user_id'].shape[0]
+            s, e = tdist.shard_bounds(n, rank, world)
+            self._dev_cache['shard_key'] = key
+            self._dev_cache['shard'] = {k: v[s:e] for k, v in data.items()}
+        return self._dev_cache['shard']
+
     def _device_stream(self, which):
         """The train/test interaction stream resident in HBM as int32 (rng='device')."""
         if which not in self._dev_cache:
-            data = self.data_processor.train_data if which == 'train' else self.data_processor.test_data
+            data = self._rank_rows(self.data_processor.train_data if which == 'train'
+                                   else self.data_processor.test_data)
             dev = _device()
             d = {'user': data['user_id'].to(torch.int32).to(dev), 'pos': data['pos_item_id'].to(torch.int32).to(dev)}
             d['neg'] = data['neg_item_id'].to(torch.int32).to(dev) if 'neg_item_id' in data else None
@@ -222,8 +239,11 @@ class TorchRecSys(torch.nn.Module):
         """The step-level driver fit() is built on (bench.py times exactly this object)."""
         return FitRunner(self, optimizer, batch_size)
 
-    def fit(self, optimizer, epochs=10, batch_size=512, profile_epochs: int = 0):
-        """Fits the model (reference model.py:203-288).  Per step: [shuffle slice + negative sampling] -> fused
+    def fit(self, optimizer, epochs=10, batch_size=512, profile_epochs: int = 0, sync_tables_every: int = 1):
+        """Fits the model (reference model.py:203-288).  Under torch.distributed (one process per GPU) every rank trains
+        its contiguous shard of the training split with `batch_size` per rank; dense MLP gradients are all-reduced every
+        step, the replicated embedding tables are re-averaged every `sync_tables_every` epochs (0 = never), and the
+        printed loss is the mean over ranks.  Per step: [shuffle slice + negative sampling] -> fused
         gather + scoring + hinge + backward -> sparse-row optimiser update; the loss stays on the device and is
         read back once per epoch (the reference syncs every step, model.py:200)."""
         runner = self.make_runner(optimizer, batch_size)
@@ -239,6 +259,12 @@ class TorchRecSys(torch.nn.Module):
             runner.begin_epoch()
             runner.run_steps(runner.num_batches)
             avg_loss = runner.end_epoch()
+            world = tdist.world_info()[1]
+            if world > 1:
+                avg_loss = tdist.allreduce_scalar_sum([avg_loss], _device())[0] / world
+                if sync_tables_every and (epoch + 1) % sync_tables_every == 0:
+                    emb = self.net.embedding_params() if hasattr(self.net, 'embedding_params') else self.net.table_params()
+                    tdist.average_tables_([p.data for p in emb])
             if prof is not None:
                 prof.__exit__(None, None, None)
                 print("--- Profiler Results (First Epoch) ---")
@@ -250,11 +276,11 @@ class TorchRecSys(torch.nn.Module):
         """reference model.py:292-338: eval-mode scores of the test split, hinge loss and pairwise AUC per batch,
         unweighted means over batches, printed; returns None."""
         self.net = self.net.eval()
-        data = self.data_processor.test_data
-        n_test = data.get('user_id', torch.empty(0)).numel()
-        if n_test == 0:
+        if self.data_processor.test_data.get('user_id', torch.empty(0)).numel() == 0:
             print("|--- No test data to evaluate.")
             return
+        data = self._rank_rows(self.data_processor.test_data)
+        n_test = data['user_id'].numel()
         dev = _device()
         loader = FastDataLoader(data=data, batch_size=batch_size, shuffle=False,
                                 dynamic_neg_sampling=self.dynamic_neg_sampling, n_items=self.n_items,
@@ -285,9 +311,14 @@ class TorchRecSys(torch.nn.Module):
             results['loss'] = [float(np.float32(ls[b]) / np.float32(sizes[b])) for b in range(nb)]
         if 'auc' in eval_metrics:
             results['auc'] = [float(np.float32(ac[b]) / np.float32(sizes[b])) for b in range(nb)]
+        world = tdist.world_info()[1]
         for metric in eval_metrics:
             values = results.get(metric, [])
-            value = sum(values) / len(values) if values else 0
+            if world > 1:  # unweighted mean over all ranks' batches
+                tot, cnt = tdist.allreduce_scalar_sum([float(sum(values)), float(len(values))], dev)
+                value = tot / cnt if cnt else 0
+            else:
+                value = sum(values) / len(values) if values else 0
             print(f'|--- Testing {metric}: {value:.4f}')
 
     # ------------------------------------------------------------------------------------------------ predict
@@ -312,7 +343,7 @@ class FitRunner:
         self.m = model
         self.batch_size = batch_size
         self.dev = _device()
-        self.data = model.data_processor.train_data
+        self.data = model._rank_rows(model.data_processor.train_data)
         self.n_train = self.data['user_id'].shape[0]
         self.loader = FastDataLoader(data=self.data, batch_size=batch_size, shuffle=True,
                                      dynamic_neg_sampling=model.dynamic_neg_sampling, n_items=model.n_items,
@@ -337,7 +368,8 @@ class FitRunner:
         else:
             self.st = m._device_stream('train')
             ge = m._fit_epochs_done
-            self.shuffle_key, self.sample_seed = _mix64(m.seed, 2 * ge + 1), _mix64(m.seed, 2 * ge + 2)
+            seed = m.seed + 1000003 * tdist.world_info()[0]  # every rank draws its own negatives
+            self.shuffle_key, self.sample_seed = _mix64(seed, 2 * ge + 1), _mix64(seed, 2 * ge + 2)
 
     def run_steps(self, k):
         """Run the next k steps of the current epoch (stops at the epoch's end).  Returns the number of steps run."""
