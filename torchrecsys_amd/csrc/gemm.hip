@@ -32,9 +32,10 @@ struct GemmArgs {
   int64_t M, N, K;
   int64_t lda, ldb, ldc;
   float alpha, beta;
-  int64_t k_per_split;  // K range per blockIdx.z (multiple of BK)
-  float* slabs;         // (splits, M, N) partial products when gridDim.z > 1
+  int64_t k_per_split;  // K range per split (multiple of BK)
+  float* slabs;         // (splits, M, N) partial products when splits > 1
   int vecA, vecB;       // 16-byte global loads legal (alignment + leading dimension)
+  int gx, gy, splits;   // logical grid: gx column tiles x gy row tiles x splits, launched as one 1-D grid
 };
 
 // Global -> registers for one 128 x 32 operand tile.  KC: source is k-contiguous.
@@ -104,8 +105,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
   constexpr int LDA_S = img_ld(AKC), LDB_S = img_ld(BKC);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
-  const int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so dispatch id b
+  // is remapped to logical id (b % 8) * (n / 8) + b / 8: every XCD walks a contiguous range of logical tiles, and the
+  // gx column tiles that share one A row panel are fetched through one L2 instead of up to gx of them.
+  int64_t lid = blockIdx.x;
+  const int64_t nwg = gridDim.x;
+  if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);
+  const int bx = (int)(lid % g.gx);
+  const int by = (int)((lid / g.gx) % g.gy);
+  const int bz = (int)(lid / ((int64_t)g.gx * g.gy));
+  const int64_t m0 = (int64_t)by * BM, n0 = (int64_t)bx * BN;
+  const int64_t kbeg = (int64_t)bz * g.k_per_split;
   const int64_t kend = (kbeg + g.k_per_split < g.K) ? kbeg + g.k_per_split : g.K;
 
   f32x16 acc[2][2];
@@ -152,8 +162,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
   }
 
   // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-  const bool split = gridDim.z > 1;
-  float* out = split ? g.slabs + (int64_t)blockIdx.z * g.M * g.N : g.C;
+  const bool split = g.splits > 1;
+  float* out = split ? g.slabs + (int64_t)bz * g.M * g.N : g.C;
   const int64_t ldo = split ? g.N : g.ldc;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -196,10 +206,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 static int pick_splits(int64_t M, int64_t N, int64_t K) {
   const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   if (tiles >= 256 || K <= 4 * BK) return 1;
-  int64_t s = (512 + tiles - 1) / tiles;  // aim at ~2 workgroups per CU
+  int64_t s = 512 / tiles;  // tiles x splits <= 512 = one resident wave of workgroups (2 per CU): no tail round
   const int64_t kt = (K + BK - 1) / BK;
   if (s > kt / 4) s = kt / 4;  // at least 4 k-tiles per split
-  if (s > 128) s = 128;
+  if (s > 256) s = 256;
   return s < 1 ? 1 : (int)s;
 }
 
@@ -234,8 +244,9 @@ extern "C" int trs_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
   g.vecA = (((uintptr_t)A_dev & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
   g.vecB = (((uintptr_t)B_dev & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
   const int64_t gx = (N + BN - 1) / BN, gy = (M + BM - 1) / BM;
-  TRS_REQUIRE(gy <= 65535 && gx <= 65535, "trs_gemm_f32: problem too large for the launch grid");
-  dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)splits);
+  TRS_REQUIRE(gx * gy * splits < ((int64_t)1 << 31), "trs_gemm_f32: problem too large for the launch grid");
+  g.gx = (int)gx; g.gy = (int)gy; g.splits = splits;
+  dim3 grid((unsigned)(gx * gy * splits));
   hipStream_t s = (hipStream_t)stream;
   const bool akc = !transA, bkc = transB != 0;
   if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, s, g);

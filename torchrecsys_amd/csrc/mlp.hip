@@ -91,6 +91,17 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_stats_partial_kernel(const float
 
 // Chan et al. pairwise combination of the chunk partials in fp64 -> batch mean, biased variance; running statistics
 // update (momentum 0.1, unbiased variance) applied once per pass, positive pass first.
+// Block = 64 columns x 4 segments of the chunk list; the 4 partial (n, mean, M2) triples are merged in LDS.
+constexpr int FIN_COLS = 64, FIN_SEGS = TRS_BLOCK / FIN_COLS;
+
+__device__ __forceinline__ void chan_merge(double& n, double& mean, double& m2, double nb, double mb, double m2b) {
+  if (nb == 0.0) return;
+  const double tot = n + nb, delta = mb - mean;
+  mean += delta * nb / tot;
+  m2 += m2b + delta * delta * n * nb / tot;
+  n = tot;
+}
+
 __global__ __launch_bounds__(TRS_BLOCK) void bn_stats_final_kernel(const float* __restrict__ part,
                                                                   int64_t rows_per_pass, int H, int n_chunks,
                                                                   int passes, float momentum,
@@ -98,28 +109,33 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_stats_final_kernel(const float* 
                                                                   float* __restrict__ var_out,
                                                                   float* __restrict__ running_mean,
                                                                   float* __restrict__ running_var) {
-  const int col = blockIdx.x * TRS_BLOCK + threadIdx.x;
-  if (col >= H) return;
+  __shared__ double s_n[FIN_SEGS][FIN_COLS], s_mean[FIN_SEGS][FIN_COLS], s_m2[FIN_SEGS][FIN_COLS];
+  const int cl = threadIdx.x % FIN_COLS, seg = threadIdx.x / FIN_COLS;
+  const int col = blockIdx.x * FIN_COLS + cl;
   for (int pass = 0; pass < passes; ++pass) {
     double n = 0.0, mean = 0.0, m2 = 0.0;
-    for (int c = 0; c < n_chunks; ++c) {
-      const int64_t r0 = (int64_t)c * CHUNK_ROWS;
-      const double nb = (double)((r0 + CHUNK_ROWS < rows_per_pass ? r0 + CHUNK_ROWS : rows_per_pass) - r0);
-      const float* o = part + (((int64_t)pass * n_chunks + c) * 2) * H;
-      const double mb = o[col], m2b = o[H + col];
-      const double delta = mb - mean, tot = n + nb;
-      mean += delta * nb / tot;
-      m2 += m2b + delta * delta * n * nb / tot;
-      n = tot;
+    if (col < H) {
+      for (int c = seg; c < n_chunks; c += FIN_SEGS) {
+        const int64_t r0 = (int64_t)c * CHUNK_ROWS;
+        const double nb = (double)((r0 + CHUNK_ROWS < rows_per_pass ? r0 + CHUNK_ROWS : rows_per_pass) - r0);
+        const float* o = part + (((int64_t)pass * n_chunks + c) * 2) * H;
+        chan_merge(n, mean, m2, nb, (double)o[col], (double)o[H + col]);
+      }
     }
-    const float mu = (float)mean, var = (float)(m2 / n);
-    mean_out[pass * H + col] = mu;
-    var_out[pass * H + col] = var;
-    if (running_mean) {
-      const float unb = (float)(m2 / (n > 1.0 ? n - 1.0 : 1.0));
-      running_mean[col] = (1.0f - momentum) * running_mean[col] + momentum * mu;
-      running_var[col] = (1.0f - momentum) * running_var[col] + momentum * unb;
+    s_n[seg][cl] = n; s_mean[seg][cl] = mean; s_m2[seg][cl] = m2;
+    __syncthreads();
+    if (seg == 0 && col < H) {
+      for (int q = 1; q < FIN_SEGS; ++q) chan_merge(n, mean, m2, s_n[q][cl], s_mean[q][cl], s_m2[q][cl]);
+      const float mu = (float)mean, var = (float)(m2 / n);
+      mean_out[pass * H + col] = mu;
+      var_out[pass * H + col] = var;
+      if (running_mean) {
+        const float unb = (float)(m2 / (n > 1.0 ? n - 1.0 : 1.0));
+        running_mean[col] = (1.0f - momentum) * running_mean[col] + momentum * mu;
+        running_var[col] = (1.0f - momentum) * running_var[col] + momentum * unb;
+      }
     }
+    __syncthreads();
   }
 }
 
@@ -217,28 +233,40 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_reduce_kernel(const BnBwdArg
   o[a.H + col] = s2;
 }
 
-// sums (passes,2,H) = sum over chunks (fp64 accumulate); dgamma = sum over passes of s2, dbeta = of s1
+// sums (passes,2,H) = sum over chunks (fp64 accumulate); dgamma = sum over passes of s2, dbeta = of s1.
+// Block = 64 columns x 4 chunk-segments, merged in LDS in segment order (fixed order: reproducible).
 __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_final_kernel(const float* __restrict__ part, int H, int n_chunks,
                                                                 int passes, float* __restrict__ sums,
                                                                 float* __restrict__ dgamma,
                                                                 float* __restrict__ dbeta) {
-  const int col = blockIdx.x * TRS_BLOCK + threadIdx.x;
-  if (col >= H) return;
+  __shared__ double s_1[FIN_SEGS][FIN_COLS], s_2[FIN_SEGS][FIN_COLS];
+  const int cl = threadIdx.x % FIN_COLS, seg = threadIdx.x / FIN_COLS;
+  const int col = blockIdx.x * FIN_COLS + cl;
   double g = 0.0, b = 0.0;
   for (int pass = 0; pass < passes; ++pass) {
     double s1 = 0.0, s2 = 0.0;
-    for (int c = 0; c < n_chunks; ++c) {
-      const float* o = part + (((int64_t)pass * n_chunks + c) * 2) * H;
-      s1 += o[col];
-      s2 += o[H + col];
+    if (col < H) {
+      for (int c = seg; c < n_chunks; c += FIN_SEGS) {
+        const float* o = part + (((int64_t)pass * n_chunks + c) * 2) * H;
+        s1 += o[col];
+        s2 += o[H + col];
+      }
     }
-    sums[(pass * 2 + 0) * H + col] = (float)s1;
-    sums[(pass * 2 + 1) * H + col] = (float)s2;
-    b += s1;
-    g += s2;
+    s_1[seg][cl] = s1; s_2[seg][cl] = s2;
+    __syncthreads();
+    if (seg == 0 && col < H) {
+      for (int q = 1; q < FIN_SEGS; ++q) { s1 += s_1[q][cl]; s2 += s_2[q][cl]; }
+      sums[(pass * 2 + 0) * H + col] = (float)s1;
+      sums[(pass * 2 + 1) * H + col] = (float)s2;
+      b += s1;
+      g += s2;
+    }
+    __syncthreads();
   }
-  if (dgamma) dgamma[col] = (float)g;
-  if (dbeta) dbeta[col] = (float)b;
+  if (seg == 0 && col < H) {
+    if (dgamma) dgamma[col] = (float)g;
+    if (dbeta) dbeta[col] = (float)b;
+  }
 }
 
 __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_apply_kernel(const BnBwdArgs a) {
@@ -294,15 +322,23 @@ __global__ __launch_bounds__(TRS_BLOCK) void colsum_partial_kernel(const float* 
 
 __global__ __launch_bounds__(TRS_BLOCK) void colsum_final_kernel(const float* __restrict__ part, int H, int n_chunks,
                                                                 int passes, float* __restrict__ out) {
-  const int col = blockIdx.x * TRS_BLOCK + threadIdx.x;
-  if (col >= H) return;
+  __shared__ double s_s[FIN_SEGS][FIN_COLS];
+  const int cl = threadIdx.x % FIN_COLS, seg = threadIdx.x / FIN_COLS;
+  const int col = blockIdx.x * FIN_COLS + cl;
   double tot = 0.0;
-  for (int p = 0; p < passes; ++p) {
+  for (int p = 0; p < passes; ++p) {  // per pass first: identical summation structure in both passes (exact cancellation)
     double s = 0.0;
-    for (int c = 0; c < n_chunks; ++c) s += part[((int64_t)p * n_chunks + c) * H + col];
-    tot += s;
+    if (col < H)
+      for (int c = seg; c < n_chunks; c += FIN_SEGS) s += part[((int64_t)p * n_chunks + c) * H + col];
+    s_s[seg][cl] = s;
+    __syncthreads();
+    if (seg == 0) {
+      for (int q = 1; q < FIN_SEGS; ++q) s += s_s[q][cl];
+      tot += s;
+    }
+    __syncthreads();
   }
-  out[col] = (float)tot;
+  if (seg == 0 && col < H) out[col] = (float)tot;
 }
 
 // ------------------------------------------------------------------------------------------- output layer H -> 1
@@ -373,7 +409,7 @@ extern "C" int trs_bn_batch_stats(const float* y_dev, int64_t rows_per_pass, int
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(gx, nc, passes), dim3(TRS_BLOCK), 0, s, y_dev, rows_per_pass, H, ld,
                      nc, workspace_dev);
   TRS_CHECK_LAUNCH("bn_stats_partial_kernel");
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(gx), dim3(TRS_BLOCK), 0, s, workspace_dev, rows_per_pass, H, nc, passes,
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((H + FIN_COLS - 1) / FIN_COLS), dim3(TRS_BLOCK), 0, s, workspace_dev, rows_per_pass, H, nc, passes,
                      momentum, mean_out_dev, var_out_dev, running_mean_dev, running_var_dev);
   TRS_CHECK_LAUNCH("bn_stats_final_kernel");
   return TRS_OK;
@@ -414,7 +450,7 @@ extern "C" int trs_bn_relu_backward(const float* y_dev, const float* dx_dev, int
   if (use_bn) {
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(gx, nc, passes), dim3(TRS_BLOCK), 0, s, a);
     TRS_CHECK_LAUNCH("bn_bwd_reduce_kernel");
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(gx), dim3(TRS_BLOCK), 0, s, workspace_dev, H, nc, passes, sums,
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((H + FIN_COLS - 1) / FIN_COLS), dim3(TRS_BLOCK), 0, s, workspace_dev, H, nc, passes, sums,
                        dgamma_dev, dbeta_dev);
     TRS_CHECK_LAUNCH("bn_bwd_final_kernel");
   }
@@ -438,7 +474,7 @@ extern "C" int trs_colsum(const float* x_dev, int64_t rows_per_pass, int32_t pas
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(gx, nc, passes), dim3(TRS_BLOCK), 0, s, x_dev, rows_per_pass, H, ld,
                      row_weight_dev, nc, workspace_dev);
   TRS_CHECK_LAUNCH("colsum_partial_kernel");
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(gx), dim3(TRS_BLOCK), 0, s, workspace_dev, H, nc, passes, out_dev);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((H + FIN_COLS - 1) / FIN_COLS), dim3(TRS_BLOCK), 0, s, workspace_dev, H, nc, passes, out_dev);
   TRS_CHECK_LAUNCH("colsum_final_kernel");
   return TRS_OK;
 }
