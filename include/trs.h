@@ -142,8 +142,8 @@ int trs_score_backward(int net, const trs_tables* tables, const trs_batch* batch
  * torch.optim.SGD(momentum=0, weight_decay=0).  Step s covers epoch positions [first_pos + s*batch, +batch).
  *   K1  forward + hinge + backward-to-scores at the PRE-update tables (software-pipelined row gathers); derives the
  *       batch from the resident stream (same shuffle / sampler as trs_batch_prepare, sample_offset = epoch position)
- *       when stream_user is non-NULL and writes it to user/pos/neg_buf (int32, (batch,)); otherwise reads the ids from
- *       those buffers (n_steps <= 1).  Stages gz (2,batch) and the user-row gradient du (batch,D);
+ *       when stream_user is non-NULL and writes it to user/pos/neg_buf (int32, (batch,)); otherwise reads the ids of
+ *       step s from user/pos/neg_buf[s*batch ...] (an epoch slice prepared by the host: the bit-exact reference streams).  Stages gz (2,batch) and the user-row gradient du (batch,D);
  *       loss_sums[s] += sum of hinge terms.
  *   K2  item[pos] -= lr*gz+ * user[u], item[neg] -= lr*gz- * user[u] (+ 1-wide item terms) from the unmodified user rows:
  *       K2a the one reference per distinct row whose K1 ownership mark survived, by plain read-modify-write; K2b the
@@ -227,6 +227,13 @@ int64_t trs_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int trs_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A_dev,
                  int64_t lda, const float* B_dev, int64_t ldb, float beta, float* C_dev, int64_t ldc,
                  const float* bias_dev, void* workspace_dev, int64_t workspace_bytes, void* stream);
+
+/* Same interface and storage (fp32 in, fp32 out); the operands are rounded to bf16 (round-to-nearest-even) as they are
+ * staged and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation — the `use_amp=True` mode (the reference's
+ * CUDA-only fp16 autocast, model.py:86-88,280, becomes bf16 inputs / fp32 accumulate: no loss scaling needed). */
+int trs_gemm_bf16(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A_dev,
+                  int64_t lda, const float* B_dev, int64_t ldb, float beta, float* C_dev, int64_t ldc,
+                  const float* bias_dev, void* workspace_dev, int64_t workspace_bytes, void* stream);
 
 /* Train-mode BatchNorm1d statistics of y (passes*rows_per_pass, H) per pass: mean_out/var_out (passes,H), biased
  * variance (chunked two-pass + Chan combination in fp64).  running_mean/var (H) non-NULL: updated once per pass in

@@ -458,3 +458,22 @@ def test_fast_sgd_steps_from_resident_stream():
     for k in p:
         assert rel_err(ta[k].cpu().numpy(), tb[k].cpu().numpy()) < 1e-6, k
     assert err.item() == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 384, 512), (1000, 130, 77), (37, 5, 3), (513, 257, 1029), (4096, 128, 384)])
+@pytest.mark.parametrize("tA,tB", [(0, 1), (0, 0), (1, 0), (1, 1)])
+def test_gemm_bf16_inputs_fp32_accumulate(M, N, K, tA, tB):
+    """bf16 GEMM == fp32 GEMM of the bf16-rounded operands (exact products, fp32 accumulation order aside)."""
+    ops = _ops()
+    rs = np.random.RandomState(M + N + K)
+    A = rs.normal(0, 1, (K, M) if tA else (M, K)).astype(np.float32)
+    Bm = rs.normal(0, 1, (N, K) if tB else (K, N)).astype(np.float32)
+    bias = rs.normal(0, 1, N).astype(np.float32)
+    tA_, tB_ = torch.from_numpy(A).to(DEV), torch.from_numpy(Bm).to(DEV)
+    Ar = tA_.to(torch.bfloat16).float().cpu().numpy().astype(np.float64)   # RNE rounding, as v_cvt_pk_bf16_f32
+    Br = tB_.to(torch.bfloat16).float().cpu().numpy().astype(np.float64)
+    ref = (Ar.T if tA else Ar) @ (Br.T if tB else Br) + bias
+    out = ops.gemm(tA, tB, tA_, tB_, bias=torch.from_numpy(bias).to(DEV), bf16=True)
+    assert rel_err(out.cpu().numpy(), ref) < 3e-6
+    full = (A.T if tA else A).astype(np.float64) @ (Bm.T if tB else Bm).astype(np.float64) + bias
+    assert rel_err(out.cpu().numpy(), full) < 2e-2  # bf16 operand rounding

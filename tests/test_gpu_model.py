@@ -299,3 +299,27 @@ def test_reference_api_invariants():
     bad = {"user_id": torch.tensor([0, n_u + 3]), "pos_item_id": torch.tensor([1, 2])}
     with pytest.raises(IndexError):
         model.net.forward(bad, "user_id", "pos_item_id")
+
+
+def test_mlp_bf16_amp_tracks_fp32():
+    """use_amp=True: bf16 GEMM inputs / fp32 accumulate (the reference's fp16 autocast is CUDA-only).  Scores and
+    gradients follow the fp32 path at bf16 tolerance; training reduces the loss."""
+    from torchrecsys_amd.helper.loss import hinge_loss
+    g = load_golden("g1_mlp_M1.npz")
+    b = golden_batch(g)
+    out = {}
+    for amp in (False, True):
+        net = build_net("mlp", 1, g)
+        net.use_bf16 = amp
+        net.train()
+        pos, neg = net.forward_pair(b)
+        loss = hinge_loss(pos, neg)
+        loss.backward()
+        out[amp] = (pos.detach().cpu().numpy(), loss.item(),
+                    {k: (p.grad.to_dense() if p.grad.is_sparse else p.grad).cpu().numpy() for k, p in net.named_parameters()})
+    assert rel_err(out[True][0], out[False][0]) < 3e-2
+    assert abs(out[True][1] - out[False][1]) < 2e-2
+    for k in ("user.weight", "fcs.0.weight", "output_layer.weight"):  # same direction (a few hinge flags may flip)
+        a, c = out[True][2][k].reshape(-1).astype(np.float64), out[False][2][k].reshape(-1).astype(np.float64)
+        assert a @ c / (np.linalg.norm(a) * np.linalg.norm(c)) > 0.97, k
+    assert not np.array_equal(out[True][0], out[False][0])  # the bf16 path really ran

@@ -5,11 +5,14 @@ import torch
 from torchrecsys_amd import ops
 dev = "cuda:0"
 R = 131072
+BF = bool(int(os.environ.get("BF16", "0")))
 def bench(name, tA, tB, A, B, n=10):
-    for _ in range(2): ops.gemm(tA, tB, A, B)
+    _g = ops.gemm
+    ops_gemm = lambda *a: _g(*a, bf16=BF)
+    for _ in range(2): ops_gemm(tA, tB, A, B)
     torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(n): out = ops.gemm(tA, tB, A, B)
+    for _ in range(n): out = ops_gemm(tA, tB, A, B)
     e1.record(); torch.cuda.synchronize()
     M, N = out.shape; K = A.shape[0] if tA else A.shape[1]
     ms = e0.elapsed_time(e1) / n

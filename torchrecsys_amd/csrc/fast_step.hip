@@ -685,9 +685,7 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
                 "trs_train_steps_sgd: steps [%lld, %lld) outside the stream of %lld rows", (long long)first_pos,
                 (long long)(first_pos + (int64_t)n_steps * batch), (long long)N);
     TRS_REQUIRE(neg_static_dev || tables->n_items >= 2, "trs_train_steps_sgd: dynamic sampling needs n_items >= 2");
-  } else {
-    TRS_REQUIRE(n_steps <= 1, "trs_train_steps_sgd: without a stream the id buffers hold exactly one batch");
-  }
+  }  // without a stream the id buffers hold n_steps consecutive batches (one epoch slice prepared by the host)
   hipStream_t s = (hipStream_t)stream;
   FastArgs a = {};
   a.T = *tables;
@@ -717,6 +715,11 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
   for (int32_t st = 0; st < n_steps; ++st) {
     a.t0 = first_pos + (int64_t)st * batch;
     a.sample_offset = (uint64_t)a.t0;
+    if (!from_stream) {  // step st reads its ids at [st*batch, (st+1)*batch) of the given arrays
+      a.user = user_buf_dev + (int64_t)st * batch;
+      a.pos = pos_buf_dev + (int64_t)st * batch;
+      a.neg = neg_buf_dev + (int64_t)st * batch;
+    }
     a.loss_sum = loss_sums_dev + st;
     a.stamp = first_stamp + (uint32_t)st;
     hipEvent_t* ev = events ? (hipEvent_t*)events + 4 * (int64_t)st : nullptr;  // K1 | K2a+K2b | K3 boundaries

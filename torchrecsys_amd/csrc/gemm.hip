@@ -98,6 +98,34 @@ __device__ __forceinline__ void tile_store(const float4 (&r)[4], float* __restri
   }
 }
 
+// epilogue shared by the fp32 and bf16 kernels: C/D map of the 32x32 MFMA (dtype-independent on gfx950):
+// col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&acc)[2][2], int64_t m0, int64_t n0,
+                                              int wm, int wn, int lr, int lk, int bz) {
+  const bool split = g.splits > 1;
+  float* out = split ? g.slabs + (int64_t)bz * g.M * g.N : g.C;
+  const int64_t ldo = split ? g.N : g.ldc;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t col = n0 + wn * 64 + j * 32 + lr;
+      if (col >= g.N) continue;
+      const float bv = (!split && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (row >= g.M) continue;
+        float v = acc[i][j][r];
+        if (!split) {
+          v = g.alpha * v + bv;
+          if (g.beta != 0.f) v += g.beta * out[row * ldo + col];
+        }
+        out[row * ldo + col] = v;
+      }
+    }
+}
+
 template <bool AKC, bool BKC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float As[2][BK * LDS_LD];
@@ -161,29 +189,100 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     __syncthreads();
   }
 
-  // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-  const bool split = g.splits > 1;
-  float* out = split ? g.slabs + (int64_t)bz * g.M * g.N : g.C;
-  const int64_t ldo = split ? g.N : g.ldc;
+  gemm_epilogue(g, acc, m0, n0, wm, wn, lr, lk, bz);
+}
+
+// ---- bf16-input variant (use_amp): operands are read as fp32, rounded to bf16 (RNE, v_cvt_pk_bf16_f32) while they
+// are staged into LDS, multiplied on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate) and accumulated in fp32.
+// LDS images are [m|n][k] with k contiguous (a lane's fragment = 8 consecutive k = one ds_read_b128), rows padded to
+// 40 bf16 = 80 B so the 16 lanes of a ds_read_b128 group land on 16 distinct 16-B slots.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+constexpr int HROW = 40;  // bf16 elements per LDS row (BK = 32 + 8 pad)
+
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+  const __bf16 a = (__bf16)lo, b = (__bf16)hi;
+  return (uint32_t)__builtin_bit_cast(unsigned short, a) | ((uint32_t)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+template <bool KC>
+__device__ __forceinline__ void tile_store_bf16(const float4 (&r)[4], unsigned short* __restrict__ S, int tid) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int c = tid + 256 * it;
+    if (KC) {
+      const int row = c >> 3, k = (c & 7) << 2;
+      uint2 v = make_uint2(pack_bf16(r[it].x, r[it].y), pack_bf16(r[it].z, r[it].w));
+      *reinterpret_cast<uint2*>(&S[row * HROW + k]) = v;
+    } else {
+      const int k = c >> 5, row = (c & 31) << 2;
+      S[(row + 0) * HROW + k] = __builtin_bit_cast(unsigned short, (__bf16)r[it].x);
+      S[(row + 1) * HROW + k] = __builtin_bit_cast(unsigned short, (__bf16)r[it].y);
+      S[(row + 2) * HROW + k] = __builtin_bit_cast(unsigned short, (__bf16)r[it].z);
+      S[(row + 3) * HROW + k] = __builtin_bit_cast(unsigned short, (__bf16)r[it].w);
+    }
+  }
+}
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) unsigned short As[2][BM * HROW];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[2][BN * HROW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int64_t lid = blockIdx.x;
+  const int64_t nwg = gridDim.x;
+  if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);
+  const int bx = (int)(lid % g.gx);
+  const int by = (int)((lid / g.gx) % g.gy);
+  const int bz = (int)(lid / ((int64_t)g.gx * g.gy));
+  const int64_t m0 = (int64_t)by * BM, n0 = (int64_t)bx * BN;
+  const int64_t kbeg = (int64_t)bz * g.k_per_split;
+  const int64_t kend = (kbeg + g.k_per_split < g.K) ? kbeg + g.k_per_split : g.K;
+
+  f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int64_t col = n0 + wn * 64 + j * 32 + lr;
-      if (col >= g.N) continue;
-      const float bv = (!split && g.bias) ? g.bias[col] : 0.f;
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (row >= g.M) continue;
-        float v = acc[i][j][r];
-        if (!split) {
-          v = g.alpha * v + bv;
-          if (g.beta != 0.f) v += g.beta * out[row * ldo + col];
-        }
-        out[row * ldo + col] = v;
-      }
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[4], rb[4];
+  const int64_t nk = (kend - kbeg + BK - 1) / BK;
+  if (nk > 0) {
+    tile_load<AKC>(ra, g.A, g.lda, g.M, kend, m0, kbeg, g.vecA, tid);
+    tile_load<BKC>(rb, g.B, g.ldb, g.N, kend, n0, kbeg, g.vecB, tid);
+    tile_store_bf16<AKC>(ra, As[0], tid);
+    tile_store_bf16<BKC>(rb, Bs[0], tid);
+  }
+  __syncthreads();
+  const int lr = lane & 31, lk = lane >> 5;
+  for (int64_t kt = 0; kt < nk; ++kt) {
+    const int cur = (int)(kt & 1);
+    if (kt + 1 < nk) {
+      tile_load<AKC>(ra, g.A, g.lda, g.M, kend, m0, kbeg + (kt + 1) * BK, g.vecA, tid);
+      tile_load<BKC>(rb, g.B, g.ldb, g.N, kend, n0, kbeg + (kt + 1) * BK, g.vecB, tid);
     }
+    const unsigned short* as = As[cur] + (wm * 64 + lr) * HROW + lk * 8;
+    const unsigned short* bs = Bs[cur] + (wn * 64 + lr) * HROW + lk * 8;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(as + ks * 16);
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(as + 32 * HROW + ks * 16);
+      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(bs + ks * 16);
+      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(bs + 32 * HROW + ks * 16);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      tile_store_bf16<AKC>(ra, As[cur ^ 1], tid);
+      tile_store_bf16<BKC>(rb, Bs[cur ^ 1], tid);
+    }
+    __syncthreads();
+  }
+  gemm_epilogue(g, acc, m0, n0, wm, wn, lr, lk, bz);
 }
 
 // C = alpha * sum_z slabs[z] + beta * C (+ bias): the launch-boundary reduce of the split-K partial slabs, fixed
@@ -221,10 +320,9 @@ extern "C" int64_t trs_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K)
   return s > 1 ? (int64_t)s * M * N * 4 : 0;
 }
 
-extern "C" int trs_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
-                            const float* A_dev, int64_t lda, const float* B_dev, int64_t ldb, float beta,
-                            float* C_dev, int64_t ldc, const float* bias_dev, void* workspace_dev,
-                            int64_t workspace_bytes, void* stream) {
+static int gemm_impl(bool bf16, int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+                     const float* A_dev, int64_t lda, const float* B_dev, int64_t ldb, float beta, float* C_dev,
+                     int64_t ldc, const float* bias_dev, void* workspace_dev, int64_t workspace_bytes, void* stream) {
   TRS_REQUIRE(M >= 0 && N >= 0 && K >= 0, "trs_gemm_f32: negative dimension");
   if (M == 0 || N == 0) return TRS_OK;
   TRS_REQUIRE(K > 0, "trs_gemm_f32: K must be positive");
@@ -249,15 +347,38 @@ extern "C" int trs_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
   dim3 grid((unsigned)(gx * gy * splits));
   hipStream_t s = (hipStream_t)stream;
   const bool akc = !transA, bkc = transB != 0;
-  if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, s, g);
-  else if (akc && !bkc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, s, g);
-  else if (!akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, s, g);
-  else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, s, g);
-  TRS_CHECK_LAUNCH("gemm_f32_kernel");
+  if (bf16) {
+    if (akc && bkc) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, dim3(256), 0, s, g);
+    else if (akc && !bkc) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, dim3(256), 0, s, g);
+    else if (!akc && bkc) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, dim3(256), 0, s, g);
+  } else {
+    if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, s, g);
+    else if (akc && !bkc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, s, g);
+    else if (!akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, s, g);
+  }
+  TRS_CHECK_LAUNCH("gemm kernel");
   if (splits > 1) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(trs_grid(M * N, 256)), dim3(256), 0, s, g.slabs, splits, M, N,
                        C_dev, ldc, alpha, beta, bias_dev);
     TRS_CHECK_LAUNCH("splitk_reduce_kernel");
   }
   return TRS_OK;
+}
+
+extern "C" int trs_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+                            const float* A_dev, int64_t lda, const float* B_dev, int64_t ldb, float beta,
+                            float* C_dev, int64_t ldc, const float* bias_dev, void* workspace_dev,
+                            int64_t workspace_bytes, void* stream) {
+  return gemm_impl(false, transA, transB, M, N, K, alpha, A_dev, lda, B_dev, ldb, beta, C_dev, ldc, bias_dev,
+                   workspace_dev, workspace_bytes, stream);
+}
+
+extern "C" int trs_gemm_bf16(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+                             const float* A_dev, int64_t lda, const float* B_dev, int64_t ldb, float beta,
+                             float* C_dev, int64_t ldc, const float* bias_dev, void* workspace_dev,
+                             int64_t workspace_bytes, void* stream) {
+  return gemm_impl(true, transA, transB, M, N, K, alpha, A_dev, lda, B_dev, ldb, beta, C_dev, ldc, bias_dev,
+                   workspace_dev, workspace_bytes, stream);
 }

@@ -168,6 +168,17 @@ class SparseScorerTrainer:
         if te is not None:
             self._collect_events(te, ns)
 
+    def fast_array_steps(self, ep, first, batch, n_steps, loss_sums):
+        """n_steps fused steps over consecutive batches of host-prepared epoch id arrays `ep` (dict user/pos/neg int32,
+        epoch order) starting at row `first`."""
+        te, evs, ns = self._make_events(n_steps) if self.kernel_events is not None else (None, None, 0)
+        e = first + n_steps * batch
+        ops.train_steps_sgd(self.net.NET, self.net.tables(), None, None, None, 0, 0, 0, batch, n_steps, self.fast_lr,
+                            ep["user"][first:e], ep["pos"][first:e], ep["neg"][first:e], self.gz, self.du, loss_sums,
+                            self.err, self.scratch, self._stamps(n_steps), evs)
+        if te is not None:
+            self._collect_events(te, ns)
+
     def step(self, ids, loss_slot, auc_slot=None):
         """ids: dict user/pos/neg[/pos_meta/neg_meta] of GPU id tensors.  loss_slot: 1-element fp32 view that receives
         the SUM of the batch's hinge terms (caller divides by B)."""

@@ -47,7 +47,7 @@ class MLPCompute:
         ctx = {"ids": ids, "B": B, "passes": passes, "x": [x], "y": [], "mean": [], "var": [], "training": training}
         for l in range(L):
             fc = net.fcs[l]
-            y = ops.gemm(False, True, x, fc.weight.data, bias=fc.bias.data)
+            y = ops.gemm(False, True, x, fc.weight.data, bias=fc.bias.data, bf16=net.use_bf16)
             ctx["y"].append(y)
             mean = var = gamma = beta = None
             stat_passes = 1
@@ -105,9 +105,9 @@ class MLPCompute:
                                      BN_EPS, dy, slot(bn.weight), slot(bn.bias))
             else:
                 ops.bn_relu_backward(y, dx, B, passes, False, None, None, None, None, BN_EPS, dy, None, None)
-            ops.gemm(True, False, dy, ctx["x"][l], out=slot(fc.weight))          # dW = dy^T x   (split-K)
+            ops.gemm(True, False, dy, ctx["x"][l], out=slot(fc.weight), bf16=net.use_bf16)  # dW = dy^T x (split-K)
             ops.colsum(dy, slot(fc.bias), passes=passes)                                           # db = column sums of dy
-            dx = ops.gemm(False, False, dy, fc.weight.data)                         # dx = dy W
+            dx = ops.gemm(False, False, dy, fc.weight.data, bf16=net.use_bf16)      # dx = dy W
         return grads, dx
 
 

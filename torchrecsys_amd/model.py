@@ -375,14 +375,19 @@ class FitRunner:
         """Run the next k steps of the current epoch (stops at the epoch's end).  Returns the number of steps run."""
         m, B = self.m, self.batch_size
         done = 0
-        fast = getattr(self.trainer, "fast_lr", None) is not None and m.rng == 'device'
-        if fast:  # whole batches straight from the resident stream, step loop in C (csrc/fast_step.hip)
-            full = self.n_train // B
+        fast = getattr(self.trainer, "fast_lr", None) is not None
+        if fast and m.rng == 'reference':
+            fast = self.ep['user'].dtype == torch.int32
+        if fast:  # whole batches, step loop in C (csrc/fast_step.hip): from the resident stream, or from the epoch's
+            full = self.n_train // B  # host-prepared id arrays (bit-exact reference batches)
             while done < k and self.next_batch < full:
                 n = min(k - done, full - self.next_batch, 64)
                 b = self.next_batch
-                self.trainer.fast_stream_steps(self.st, self.shuffle_key, self.sample_seed, b * B, B, n,
-                                               self.loss_sums[b:b + n])
+                if m.rng == 'device':
+                    self.trainer.fast_stream_steps(self.st, self.shuffle_key, self.sample_seed, b * B, B, n,
+                                                   self.loss_sums[b:b + n])
+                else:
+                    self.trainer.fast_array_steps(self.ep, b * B, B, n, self.loss_sums[b:b + n])
                 self.next_batch += n
                 done += n
         while done < k and self.next_batch < self.num_batches:

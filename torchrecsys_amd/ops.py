@@ -257,8 +257,9 @@ def _workspace(dev, nbytes):
     return buf
 
 
-def gemm(transA, transB, A, B, out=None, bias=None, alpha=1.0, beta=0.0):
-    """out(M,N) = alpha * op(A) op(B) + beta * out (+ bias); fp32 MFMA.  A, B, out: 2-D fp32 GPU tensors whose last
+def gemm(transA, transB, A, B, out=None, bias=None, alpha=1.0, beta=0.0, bf16=False):
+    """out(M,N) = alpha * op(A) op(B) + beta * out (+ bias); fp32 MFMA, or bf16-rounded operands with fp32
+    accumulation when bf16=True.  A, B, out: 2-D fp32 GPU tensors whose last
     dimension is contiguous (row stride = leading dimension)."""
     lib = _lib.load()
     M, K = (A.shape[1], A.shape[0]) if transA else (A.shape[0], A.shape[1])
@@ -272,8 +273,9 @@ def gemm(transA, transB, A, B, out=None, bias=None, alpha=1.0, beta=0.0):
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
     wsb = lib.trs_gemm_f32_workspace_bytes(M, N, K)
     ws = _workspace(A.device, wsb) if wsb else None
-    check(lib.trs_gemm_f32(int(transA), int(transB), M, N, K, float(alpha), ptr(A), A.stride(0), ptr(B), B.stride(0),
-                           float(beta), ptr(out), out.stride(0), ptr(bias), ptr(ws), wsb, _stream()), "trs_gemm_f32")
+    fn = lib.trs_gemm_bf16 if bf16 else lib.trs_gemm_f32
+    check(fn(int(transA), int(transB), M, N, K, float(alpha), ptr(A), A.stride(0), ptr(B), B.stride(0),
+             float(beta), ptr(out), out.stride(0), ptr(bias), ptr(ws), wsb, _stream()), "trs_gemm")
     return out
 
 
