@@ -226,14 +226,19 @@ int trs_mlp_gather_concat(const trs_tables* tables, const trs_batch* batch, int3
 int64_t trs_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int trs_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A_dev,
                  int64_t lda, const float* B_dev, int64_t ldb, float beta, float* C_dev, int64_t ldc,
-                 const float* bias_dev, void* workspace_dev, int64_t workspace_bytes, void* stream);
+                 const float* bias_dev, float* bn_part_dev, void* workspace_dev, int64_t workspace_bytes,
+                 void* stream);
+/* bn_part_dev (optional, forward GEMMs): fused BatchNorm batch statistics of the output — per 128-row tile t and
+ * column the mean and the sum of squared deviations from it, written to bn_part[(t*2 + {0,1})*N + col]; combine with
+ * trs_bn_stats_finalize(chunk_rows = 128).  Requires beta == 0; disables split-K. */
 
 /* Same interface and storage (fp32 in, fp32 out); the operands are rounded to bf16 (round-to-nearest-even) as they are
  * staged and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation — the `use_amp=True` mode (the reference's
  * CUDA-only fp16 autocast, model.py:86-88,280, becomes bf16 inputs / fp32 accumulate: no loss scaling needed). */
 int trs_gemm_bf16(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float* A_dev,
                   int64_t lda, const float* B_dev, int64_t ldb, float beta, float* C_dev, int64_t ldc,
-                  const float* bias_dev, void* workspace_dev, int64_t workspace_bytes, void* stream);
+                  const float* bias_dev, float* bn_part_dev, void* workspace_dev, int64_t workspace_bytes,
+                  void* stream);
 
 /* Train-mode BatchNorm1d statistics of y (passes*rows_per_pass, H) per pass: mean_out/var_out (passes,H), biased
  * variance (chunked two-pass + Chan combination in fp64).  running_mean/var (H) non-NULL: updated once per pass in
@@ -243,6 +248,12 @@ int64_t trs_bn_workspace_floats(int64_t rows_per_pass, int32_t H, int32_t passes
 int trs_bn_batch_stats(const float* y_dev, int64_t rows_per_pass, int32_t H, int64_t ld, int32_t passes,
                        float momentum, float* mean_out_dev, float* var_out_dev, float* running_mean_dev,
                        float* running_var_dev, float* workspace_dev, void* stream);
+
+/* Second half of trs_bn_batch_stats alone: combine chunk partials (pass, chunk, {mean, M2}, H) of `chunk_rows` rows each
+ * (as trs_gemm_* writes them with chunk_rows = 128) into mean/var and update the running statistics. */
+int trs_bn_stats_finalize(const float* part_dev, int64_t rows_per_pass, int32_t chunk_rows, int32_t H, int32_t passes,
+                          float momentum, float* mean_out_dev, float* var_out_dev, float* running_mean_dev,
+                          float* running_var_dev, void* stream);
 
 /* out = relu(((y - mean) / sqrt(var + eps)) * gamma + beta)  (use_bn = 0: out = relu(y)); statistics indexed per
  * pass when stat_passes == passes, shared when stat_passes == 1 (eval mode: running statistics).

@@ -477,3 +477,30 @@ def test_gemm_bf16_inputs_fp32_accumulate(M, N, K, tA, tB):
     assert rel_err(out.cpu().numpy(), ref) < 3e-6
     full = (A.T if tA else A).astype(np.float64) @ (Bm.T if tB else Bm).astype(np.float64) + bias
     assert rel_err(out.cpu().numpy(), full) < 2e-2  # bf16 operand rounding
+
+
+@pytest.mark.parametrize("B,passes,K,H", [(256, 2, 40, 96), (1000, 1, 77, 130), (128, 2, 384, 512), (333, 1, 16, 7)])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_gemm_fused_bn_statistics(B, passes, K, H, bf16):
+    """BatchNorm batch statistics from the GEMM epilogue (+ finalize) == the stand-alone statistics kernels."""
+    ops = _ops()
+    rs = np.random.RandomState(B + H)
+    rows = B * passes
+    x = torch.from_numpy(rs.normal(0, 1, (rows, K)).astype(np.float32)).to(DEV)
+    W = torch.from_numpy(rs.normal(0, 1, (H, K)).astype(np.float32)).to(DEV)
+    bias = torch.from_numpy(rs.normal(0, 3, H).astype(np.float32)).to(DEV)
+    n_tiles = (rows + 127) // 128
+    part = torch.empty((n_tiles, 2, H), device=DEV)
+    y = ops.gemm(False, True, x, W, bias=bias, bf16=bf16, bn_part=part)
+    y_plain = ops.gemm(False, True, x, W, bias=bias, bf16=bf16)
+    assert rel_err(y.cpu().numpy(), y_plain.cpu().numpy()) < 1e-6  # (the plain call may split K: other summation order)
+    m1, v1 = torch.empty((passes, H), device=DEV), torch.empty((passes, H), device=DEV)
+    m2, v2 = torch.empty((passes, H), device=DEV), torch.empty((passes, H), device=DEV)
+    rm1, rv1 = torch.zeros(H, device=DEV), torch.ones(H, device=DEV)
+    rm2, rv2 = torch.zeros(H, device=DEV), torch.ones(H, device=DEV)
+    ops.bn_stats_finalize(part, B, 128, H, passes, 0.1, m1, v1, rm1, rv1)
+    ops.bn_batch_stats(y, B, passes, 0.1, m2, v2, rm2, rv2)
+    y64 = y.cpu().numpy().astype(np.float64).reshape(passes, B, H)
+    assert rel_err(m1.cpu().numpy(), y64.mean(axis=1)) < 1e-6 and rel_err(v1.cpu().numpy(), y64.var(axis=1)) < 2e-6
+    assert rel_err(m1.cpu().numpy(), m2.cpu().numpy()) < 1e-6 and rel_err(v1.cpu().numpy(), v2.cpu().numpy()) < 2e-6
+    assert rel_err(rm1.cpu().numpy(), rm2.cpu().numpy()) < 1e-6 and rel_err(rv1.cpu().numpy(), rv2.cpu().numpy()) < 2e-6

@@ -84,9 +84,10 @@ PROTOTYPES = {
     "trs_mlp_gather_concat": (C.c_int, [_T, _Bp, _i32, _vp, _i64, _vp]),
     "trs_gemm_f32_workspace_bytes": (C.c_int64, [_i64, _i64, _i64]),
     "trs_gemm_f32": (C.c_int, [C.c_int, C.c_int, _i64, _i64, _i64, _f, _vp, _i64, _vp, _i64, _f, _vp, _i64, _vp, _vp,
-                               _i64, _vp]),
+                               _vp, _i64, _vp]),
     "trs_gemm_bf16": (C.c_int, [C.c_int, C.c_int, _i64, _i64, _i64, _f, _vp, _i64, _vp, _i64, _f, _vp, _i64, _vp, _vp,
-                                _i64, _vp]),
+                                _vp, _i64, _vp]),
+    "trs_bn_stats_finalize": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _f, _vp, _vp, _vp, _vp, _vp]),
     "trs_bn_workspace_floats": (C.c_int64, [_i64, _i32, _i32]),
     "trs_bn_batch_stats": (C.c_int, [_vp, _i64, _i32, _i64, _i32, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "trs_bn_relu_forward": (C.c_int, [_vp, _i64, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _f, _vp, _i64, _vp]),

@@ -36,6 +36,10 @@ struct GemmArgs {
   float* slabs;         // (splits, M, N) partial products when splits > 1
   int vecA, vecB;       // 16-byte global loads legal (alignment + leading dimension)
   int gx, gy, splits;   // logical grid: gx column tiles x gy row tiles x splits, launched as one 1-D grid
+  // fused BatchNorm batch statistics of the output (forward GEMMs of the MLP): per 128-row tile and column the mean
+  // and the sum of squared deviations from that mean, laid out (row tile, 2, N) — the chunk partials that
+  // trs_bn_stats_finalize combines (Chan).  NULL = off.  Requires splits == 1.
+  float* bn_part;
 };
 
 // Global -> registers for one 128 x 32 operand tile.  KC: source is k-contiguous.
@@ -126,6 +130,53 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
     }
 }
 
+// Per-tile column statistics of the values the epilogue stores (alpha*acc + bias): each column of the 128-row tile is
+// spread over 2 waves (wm) x 2 lane halves x 32 accumulator registers; sums meet through a lane-half shuffle and LDS.
+__device__ __forceinline__ void gemm_tile_bn_stats(const GemmArgs& g, const f32x16 (&acc)[2][2], float* __restrict__ lds,
+                                                   int64_t m0, int64_t n0, int wm, int wn, int lr, int lk, int by) {
+  const int64_t rows_left = g.M - m0;
+  const float n_rows = (float)(rows_left < BM ? rows_left : BM);
+  float mean[2];
+  __syncthreads();  // the operand images are dead: reuse their LDS
+#pragma unroll
+  for (int phase = 0; phase < 2; ++phase) {  // 0: sums -> means, 1: squared deviations
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t col = n0 + wn * 64 + j * 32 + lr;
+      const float bv = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          if (row < g.M) {
+            const float v = g.alpha * acc[i][j][r] + bv;
+            if (phase == 0) s += v; else { const float d = v - mean[j]; s += d * d; }
+          }
+        }
+      s += __shfl_xor(s, 32, 64);
+      if (lk == 0) lds[((wn * 2 + j) * 32 + lr) * 2 + wm] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float tot = lds[((wn * 2 + j) * 32 + lr) * 2 + 0] + lds[((wn * 2 + j) * 32 + lr) * 2 + 1];
+      if (phase == 0) {
+        mean[j] = tot / n_rows;
+      } else if (wm == 0 && lk == 0) {
+        const int64_t col = n0 + wn * 64 + j * 32 + lr;
+        if (col < g.N) {
+          float* o = g.bn_part + (int64_t)by * 2 * g.N;
+          o[col] = mean[j];
+          o[g.N + col] = tot;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <bool AKC, bool BKC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float As[2][BK * LDS_LD];
@@ -190,6 +241,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
   }
 
   gemm_epilogue(g, acc, m0, n0, wm, wn, lr, lk, bz);
+  if (g.bn_part) gemm_tile_bn_stats(g, acc, &As[0][0], m0, n0, wm, wn, lr, lk, by);
 }
 
 // ---- bf16-input variant (use_amp): operands are read as fp32, rounded to bf16 (RNE, v_cvt_pk_bf16_f32) while they
@@ -283,6 +335,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
     __syncthreads();
   }
   gemm_epilogue(g, acc, m0, n0, wm, wn, lr, lk, bz);
+  if (g.bn_part) gemm_tile_bn_stats(g, acc, reinterpret_cast<float*>(&As[0][0]), m0, n0, wm, wn, lr, lk, by);
 }
 
 // C = alpha * sum_z slabs[z] + beta * C (+ bias): the launch-boundary reduce of the split-K partial slabs, fixed
@@ -322,13 +375,15 @@ extern "C" int64_t trs_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K)
 
 static int gemm_impl(bool bf16, int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
                      const float* A_dev, int64_t lda, const float* B_dev, int64_t ldb, float beta, float* C_dev,
-                     int64_t ldc, const float* bias_dev, void* workspace_dev, int64_t workspace_bytes, void* stream) {
+                     int64_t ldc, const float* bias_dev, float* bn_part_dev, void* workspace_dev,
+                     int64_t workspace_bytes, void* stream) {
   TRS_REQUIRE(M >= 0 && N >= 0 && K >= 0, "trs_gemm_f32: negative dimension");
   if (M == 0 || N == 0) return TRS_OK;
   TRS_REQUIRE(K > 0, "trs_gemm_f32: K must be positive");
   TRS_REQUIRE(A_dev && B_dev && C_dev, "trs_gemm_f32: NULL operand");
   TRS_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "trs_gemm_f32: leading dimension too small");
-  const int splits = pick_splits(M, N, K);
+  const int splits = bn_part_dev ? 1 : pick_splits(M, N, K);
+  TRS_REQUIRE(!bn_part_dev || beta == 0.f, "trs_gemm: fused BatchNorm statistics need beta == 0");
   TRS_REQUIRE(splits == 1 || (workspace_dev && workspace_bytes >= (int64_t)splits * M * N * 4),
               "trs_gemm_f32: workspace too small (%lld < %lld)", (long long)workspace_bytes,
               (long long)splits * M * N * 4);
@@ -339,6 +394,7 @@ static int gemm_impl(bool bf16, int transA, int transB, int64_t M, int64_t N, in
   const int64_t kt = (K + BK - 1) / BK;
   g.k_per_split = ((kt + splits - 1) / splits) * BK;
   g.slabs = (float*)workspace_dev;
+  g.bn_part = bn_part_dev;
   g.vecA = (((uintptr_t)A_dev & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
   g.vecB = (((uintptr_t)B_dev & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
   const int64_t gx = (N + BN - 1) / BN, gy = (M + BM - 1) / BM;
@@ -369,16 +425,16 @@ static int gemm_impl(bool bf16, int transA, int transB, int64_t M, int64_t N, in
 
 extern "C" int trs_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
                             const float* A_dev, int64_t lda, const float* B_dev, int64_t ldb, float beta,
-                            float* C_dev, int64_t ldc, const float* bias_dev, void* workspace_dev,
-                            int64_t workspace_bytes, void* stream) {
+                            float* C_dev, int64_t ldc, const float* bias_dev, float* bn_part_dev,
+                            void* workspace_dev, int64_t workspace_bytes, void* stream) {
   return gemm_impl(false, transA, transB, M, N, K, alpha, A_dev, lda, B_dev, ldb, beta, C_dev, ldc, bias_dev,
-                   workspace_dev, workspace_bytes, stream);
+                   bn_part_dev, workspace_dev, workspace_bytes, stream);
 }
 
 extern "C" int trs_gemm_bf16(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
                              const float* A_dev, int64_t lda, const float* B_dev, int64_t ldb, float beta,
-                             float* C_dev, int64_t ldc, const float* bias_dev, void* workspace_dev,
-                             int64_t workspace_bytes, void* stream) {
+                             float* C_dev, int64_t ldc, const float* bias_dev, float* bn_part_dev,
+                             void* workspace_dev, int64_t workspace_bytes, void* stream) {
   return gemm_impl(true, transA, transB, M, N, K, alpha, A_dev, lda, B_dev, ldb, beta, C_dev, ldc, bias_dev,
-                   workspace_dev, workspace_bytes, stream);
+                   bn_part_dev, workspace_dev, workspace_bytes, stream);
 }

@@ -103,8 +103,8 @@ __device__ __forceinline__ void chan_merge(double& n, double& mean, double& m2, 
 }
 
 __global__ __launch_bounds__(TRS_BLOCK) void bn_stats_final_kernel(const float* __restrict__ part,
-                                                                  int64_t rows_per_pass, int H, int n_chunks,
-                                                                  int passes, float momentum,
+                                                                  int64_t rows_per_pass, int chunk_rows, int H,
+                                                                  int n_chunks, int passes, float momentum,
                                                                   float* __restrict__ mean_out,
                                                                   float* __restrict__ var_out,
                                                                   float* __restrict__ running_mean,
@@ -116,8 +116,8 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_stats_final_kernel(const float* 
     double n = 0.0, mean = 0.0, m2 = 0.0;
     if (col < H) {
       for (int c = seg; c < n_chunks; c += FIN_SEGS) {
-        const int64_t r0 = (int64_t)c * CHUNK_ROWS;
-        const double nb = (double)((r0 + CHUNK_ROWS < rows_per_pass ? r0 + CHUNK_ROWS : rows_per_pass) - r0);
+        const int64_t r0 = (int64_t)c * chunk_rows;
+        const double nb = (double)((r0 + chunk_rows < rows_per_pass ? r0 + chunk_rows : rows_per_pass) - r0);
         const float* o = part + (((int64_t)pass * n_chunks + c) * 2) * H;
         chan_merge(n, mean, m2, nb, (double)o[col], (double)o[H + col]);
       }
@@ -409,8 +409,25 @@ extern "C" int trs_bn_batch_stats(const float* y_dev, int64_t rows_per_pass, int
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(gx, nc, passes), dim3(TRS_BLOCK), 0, s, y_dev, rows_per_pass, H, ld,
                      nc, workspace_dev);
   TRS_CHECK_LAUNCH("bn_stats_partial_kernel");
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((H + FIN_COLS - 1) / FIN_COLS), dim3(TRS_BLOCK), 0, s, workspace_dev, rows_per_pass, H, nc, passes,
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((H + FIN_COLS - 1) / FIN_COLS), dim3(TRS_BLOCK), 0, s, workspace_dev, rows_per_pass, CHUNK_ROWS, H, nc, passes,
                      momentum, mean_out_dev, var_out_dev, running_mean_dev, running_var_dev);
+  TRS_CHECK_LAUNCH("bn_stats_final_kernel");
+  return TRS_OK;
+}
+
+extern "C" int trs_bn_stats_finalize(const float* part_dev, int64_t rows_per_pass, int32_t chunk_rows, int32_t H,
+                                     int32_t passes, float momentum, float* mean_out_dev, float* var_out_dev,
+                                     float* running_mean_dev, float* running_var_dev, void* stream) {
+  TRS_REQUIRE(part_dev && mean_out_dev && var_out_dev, "trs_bn_stats_finalize: NULL argument");
+  TRS_REQUIRE(rows_per_pass > 0 && chunk_rows > 0 && H > 0 && passes >= 1 && passes <= 2,
+              "trs_bn_stats_finalize: bad shape");
+  TRS_REQUIRE(passes == 1 || rows_per_pass % chunk_rows == 0,
+              "trs_bn_stats_finalize: a chunk must not straddle the two passes (rows_per_pass %% chunk_rows != 0)");
+  TRS_REQUIRE((running_mean_dev == nullptr) == (running_var_dev == nullptr), "trs_bn_stats_finalize: running stats");
+  const int nc = (int)((rows_per_pass + chunk_rows - 1) / chunk_rows);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((H + FIN_COLS - 1) / FIN_COLS), dim3(TRS_BLOCK), 0,
+                     (hipStream_t)stream, part_dev, rows_per_pass, chunk_rows, H, nc, passes, momentum, mean_out_dev,
+                     var_out_dev, running_mean_dev, running_var_dev);
   TRS_CHECK_LAUNCH("bn_stats_final_kernel");
   return TRS_OK;
 }

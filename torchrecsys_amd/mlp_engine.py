@@ -47,7 +47,14 @@ class MLPCompute:
         ctx = {"ids": ids, "B": B, "passes": passes, "x": [x], "y": [], "mean": [], "var": [], "training": training}
         for l in range(L):
             fc = net.fcs[l]
-            y = ops.gemm(False, True, x, fc.weight.data, bias=fc.bias.data, bf16=net.use_bf16)
+            # train-mode BN: the batch statistics come out of the GEMM epilogue (one partial per 128-row tile) when no
+            # tile straddles the two passes
+            fuse_stats = use_bn and training and (passes == 1 or B % ops.GEMM_TILE_ROWS == 0)
+            part = None
+            if fuse_stats:
+                n_tiles = (rows + ops.GEMM_TILE_ROWS - 1) // ops.GEMM_TILE_ROWS
+                part = torch.empty((n_tiles, 2, fc.out_features), dtype=torch.float32, device=dev)
+            y = ops.gemm(False, True, x, fc.weight.data, bias=fc.bias.data, bf16=net.use_bf16, bn_part=part)
             ctx["y"].append(y)
             mean = var = gamma = beta = None
             stat_passes = 1
@@ -58,7 +65,11 @@ class MLPCompute:
                     H = y.shape[1]
                     mean = torch.empty((passes, H), dtype=torch.float32, device=dev)
                     var = torch.empty((passes, H), dtype=torch.float32, device=dev)
-                    ops.bn_batch_stats(y, B, passes, BN_MOMENTUM, mean, var, bn.running_mean, bn.running_var)
+                    if fuse_stats:
+                        ops.bn_stats_finalize(part, B, ops.GEMM_TILE_ROWS, H, passes, BN_MOMENTUM, mean, var,
+                                              bn.running_mean, bn.running_var)
+                    else:
+                        ops.bn_batch_stats(y, B, passes, BN_MOMENTUM, mean, var, bn.running_mean, bn.running_var)
                     bn.num_batches_tracked += passes
                     stat_passes = passes
                 else:

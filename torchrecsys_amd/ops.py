@@ -257,7 +257,10 @@ def _workspace(dev, nbytes):
     return buf
 
 
-def gemm(transA, transB, A, B, out=None, bias=None, alpha=1.0, beta=0.0, bf16=False):
+GEMM_TILE_ROWS = 128  # rows per output tile = rows per fused-BN-statistics chunk
+
+
+def gemm(transA, transB, A, B, out=None, bias=None, alpha=1.0, beta=0.0, bf16=False, bn_part=None):
     """out(M,N) = alpha * op(A) op(B) + beta * out (+ bias); fp32 MFMA, or bf16-rounded operands with fp32
     accumulation when bf16=True.  A, B, out: 2-D fp32 GPU tensors whose last
     dimension is contiguous (row stride = leading dimension)."""
@@ -271,11 +274,11 @@ def gemm(transA, transB, A, B, out=None, bias=None, alpha=1.0, beta=0.0, bf16=Fa
             raise ValueError("gemm operands must be fp32 GPU tensors with a contiguous last dimension")
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
-    wsb = lib.trs_gemm_f32_workspace_bytes(M, N, K)
+    wsb = 0 if bn_part is not None else lib.trs_gemm_f32_workspace_bytes(M, N, K)
     ws = _workspace(A.device, wsb) if wsb else None
     fn = lib.trs_gemm_bf16 if bf16 else lib.trs_gemm_f32
     check(fn(int(transA), int(transB), M, N, K, float(alpha), ptr(A), A.stride(0), ptr(B), B.stride(0),
-             float(beta), ptr(out), out.stride(0), ptr(bias), ptr(ws), wsb, _stream()), "trs_gemm")
+             float(beta), ptr(out), out.stride(0), ptr(bias), ptr(bn_part), ptr(ws), wsb, _stream()), "trs_gemm")
     return out
 
 
@@ -286,6 +289,13 @@ def bn_batch_stats(y, rows_per_pass, passes, momentum, mean_out, var_out, runnin
     check(lib.trs_bn_batch_stats(ptr(y), rows_per_pass, H, y.stride(0), passes, float(momentum), ptr(mean_out),
                                  ptr(var_out), ptr(running_mean), ptr(running_var), ptr(ws), _stream()),
           "trs_bn_batch_stats")
+
+
+def bn_stats_finalize(part, rows_per_pass, chunk_rows, H, passes, momentum, mean_out, var_out, running_mean,
+                      running_var):
+    check(_lib.load().trs_bn_stats_finalize(ptr(part), rows_per_pass, chunk_rows, H, passes, float(momentum),
+                                            ptr(mean_out), ptr(var_out), ptr(running_mean), ptr(running_var), _stream()),
+          "trs_bn_stats_finalize")
 
 
 def bn_relu_forward(y, rows_per_pass, passes, use_bn, stat_passes, mean, var, gamma, beta, eps, out):
