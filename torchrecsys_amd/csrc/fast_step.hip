@@ -547,7 +547,12 @@ static int launch_fwd_stage(const FastArgs& a, hipStream_t s) {
   const int tpw = TRS_WAVE / c.g;
   // ~8 pipelined iterations per lane group: few enough workgroups that every wave overlaps its own loads with its
   // own reductions, enough (>= 2 per CU) to fill the chip
-  static const int iters = getenv("TRS_K1_ITERS") ? atoi(getenv("TRS_K1_ITERS")) : 8;  // tuning knob (scratch)
+  // measured at c2 (B = 65536, D = 64): 2 iterations 35 us, 4: 26, 6-8: 22-25, 16: 29.  Small batches keep >= 2
+  // iterations (the pipeline's minimum) but spread over as many workgroups as there is work for.
+  static const int iters_env = getenv("TRS_K1_ITERS") ? atoi(getenv("TRS_K1_ITERS")) : 0;  // tuning knob
+  int64_t iters = iters_env > 0 ? iters_env : (a.B + 512 * 4 * (int64_t)tpw - 1) / (512 * 4 * (int64_t)tpw);
+  if (iters < 2) iters = 2;
+  if (iters > 8 && iters_env <= 0) iters = 8;
   int64_t grid = ((a.B + tpw - 1) / tpw + 4 * iters - 1) / (4 * iters);
   if (grid < 1) grid = 1;
   if (grid > 4096) grid = 4096;

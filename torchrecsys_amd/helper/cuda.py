@@ -1,13 +1,23 @@
 # -*- coding: utf-8 -*-
-"""Device placement helpers (reference helper/cuda.py:3-16).
+"""Device placement policy of the path (the reference's helper/cuda.py:3-16 `.cuda()` / `.cpu()` shims).
 
-On this framework the compute device is always the MI355X: `gpu(x, True)` moves to it, `gpu(x, False)` leaves the
-object where it is (the reference's CPU mode has no equivalent here — scorers raise if asked to compute on CPU)."""
+In this framework the compute device is always the MI355X PyTorch-ROCm exposes as `cuda`; the flag only decides
+whether an object is moved there now.  `gpu(x, False)` returns `x` untouched (batches stay host tensors until a scorer
+uploads them; scorers refuse to compute on host tensors' device)."""
+import torch
+
+
+def _accelerator():
+    if not torch.cuda.is_available():
+        raise RuntimeError("no MI355X visible to PyTorch-ROCm: torchrecsys_amd has no CPU compute path")
+    return torch.device("cuda", torch.cuda.current_device())
 
 
 def gpu(tensor, gpu=False):
-    return tensor.cuda() if gpu else tensor
+    """Move `tensor` (or a module) to the accelerator when `gpu` is true."""
+    return tensor.to(_accelerator()) if gpu else tensor
 
 
 def cpu(tensor):
-    return tensor.cpu() if tensor.is_cuda else tensor
+    """Host copy of an accelerator tensor (identity for host tensors)."""
+    return tensor.to("cpu") if getattr(tensor, "is_cuda", False) else tensor
