@@ -142,7 +142,7 @@ int trs_score_backward(int net, const trs_tables* tables, const trs_batch* batch
  * torch.optim.SGD(momentum=0, weight_decay=0).  Step s covers epoch positions [first_pos + s*batch, +batch).
  *   K1  forward + hinge + backward-to-scores at the PRE-update tables (software-pipelined row gathers); derives the
  *       batch from the resident stream (same shuffle / sampler as trs_batch_prepare, sample_offset = epoch position)
- *       when stream_user is non-NULL and writes it to user/pos/neg_buf (int32, (batch,)); otherwise reads the ids of
+ *       when stream_ui (the stream as interleaved int32 pairs {user, item}, (N,2)) is non-NULL and writes it to user/pos/neg_buf (int32, (batch,)); otherwise reads the ids of
  *       step s from user/pos/neg_buf[s*batch ...] (an epoch slice prepared by the host: the bit-exact reference streams).  Stages gz (2,batch) and the user-row gradient du (batch,D);
  *       loss_sums[s] += sum of hinge terms.
  *   K2  item[pos] -= lr*gz+ * user[u], item[neg] -= lr*gz- * user[u] (+ 1-wide item terms) from the unmodified user rows:
@@ -154,8 +154,8 @@ int trs_score_backward(int net, const trs_tables* tables, const trs_batch* batch
  * of the first step, non-zero, strictly increasing over the life of the scratch (re-zero the scratch before it wraps).
  * events: NULL, or 4*n_steps hipEvent_t handles recorded at the K1 | K2a+K2b | K3 boundaries of each step (a step whose handles are NULL is not timed) (bench.py). */
 int64_t trs_train_scratch_bytes(int64_t n_users, int64_t n_items, int64_t batch, int32_t D);
-int trs_train_steps_sgd(int net, const trs_tables* tables, const int32_t* stream_user_dev,
-                        const int32_t* stream_item_dev, const int32_t* neg_static_dev, int64_t N,
+int trs_train_steps_sgd(int net, const trs_tables* tables, const int32_t* stream_ui_dev,
+                        const int32_t* neg_static_dev, int64_t N,
                         uint64_t shuffle_key, uint64_t sample_seed, int64_t first_pos, int64_t batch, int32_t n_steps,
                         float lr, int32_t* user_buf_dev, int32_t* pos_buf_dev, int32_t* neg_buf_dev,
                         float* gz_buf_dev, float* du_buf_dev, float* loss_sums_dev, int32_t* err_flag_dev,

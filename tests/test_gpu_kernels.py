@@ -406,7 +406,7 @@ def test_fast_sgd_step_matches_oracle_and_generic_path(net, D):
     losses = torch.zeros(3, device=DEV)
     scratch = ops.train_scratch(90, 41, B, D, DEV) if D != 8 else None  # D == 8 exercises the all-atomic variant
     for step in range(3):
-        ops.train_steps_sgd(net, T, None, None, None, 0, 0, 0, B, 1, lr, ids["user_id"], ids["pos_item_id"],
+        ops.train_steps_sgd(net, T, None, None, 0, 0, 0, B, 1, lr, ids["user_id"], ids["pos_item_id"],
                             ids["neg_item_id"], gz, du, losses[step:step + 1], err, scratch, 1 + step)
         _, _, loss, grads = onets.train_forward_backward(net, ref, batch)
         ooptim.sgd_step(ref, grads, lr)
@@ -440,7 +440,7 @@ def test_fast_sgd_steps_from_resident_stream():
     gz, du = torch.empty((2, B), device=DEV), torch.empty((B, D), device=DEV)
     la = torch.zeros(n_steps, device=DEV)
     err = torch.zeros(1, dtype=torch.int32, device=DEV)
-    ops.train_steps_sgd("fm", Ta, dsu, dsi, None, key, seed_, 1024, B, n_steps, lr, *bufs, gz, du, la, err,
+    ops.train_steps_sgd("fm", Ta, ops.interleave_stream(dsu, dsi), None, key, seed_, 1024, B, n_steps, lr, *bufs, gz, du, la, err,
                         ops.train_scratch(NU, NI, B, D, DEV), 7)
     # generic: batch_prepare + fwd_bwd + sgd_update per step
     tb = {k: torch.from_numpy(v.copy()).to(DEV) for k, v in p.items()}

@@ -34,8 +34,7 @@ struct FastArgs {
   int32_t* err;
   // resident stream (from_stream != 0)
   int from_stream;
-  const int32_t* su;
-  const int32_t* si;
+  const int2* sui;  // (N) interleaved {user, item}: one 8-byte random read per triple instead of two 4-byte ones
   const int32_t* neg_static;
   int64_t N;
   uint64_t shuffle_key;
@@ -81,8 +80,9 @@ __device__ __forceinline__ RawIds issue_ids(const FastArgs& a, int64_t t) {
   r.v = 0;
   if (SRC != 0) {
     const int64_t p = trs_feistel_perm(a.t0 + tc, a.N, a.shuffle_key, a.hb);
-    r.u = a.su[p];
-    r.p = a.si[p];
+    const int2 ui = a.sui[p];
+    r.u = ui.x;
+    r.p = ui.y;
     if (SRC == 2) {
       r.n = a.neg_static[p];
     } else {
@@ -669,8 +669,8 @@ extern "C" int64_t trs_train_scratch_bytes(int64_t n_users, int64_t n_items, int
   return 12 * (n_users + n_items);  // uown, iown (8 B per row) + udup, idup (4 B per row)
 }
 
-extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int32_t* stream_user_dev,
-                                   const int32_t* stream_item_dev, const int32_t* neg_static_dev, int64_t N,
+extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int32_t* stream_ui_dev,
+                                   const int32_t* neg_static_dev, int64_t N,
                                    uint64_t shuffle_key, uint64_t sample_seed, int64_t first_pos, int64_t batch,
                                    int32_t n_steps, float lr, int32_t* user_buf_dev, int32_t* pos_buf_dev,
                                    int32_t* neg_buf_dev, float* gz_buf_dev, float* du_buf_dev, float* loss_sums_dev,
@@ -684,9 +684,9 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
               "trs_train_steps_sgd: NULL buffer");
   TRS_REQUIRE(!scratch_dev || (first_stamp != 0 && (uint64_t)first_stamp + (uint64_t)n_steps < 0xFFFFFFFFull),
               "trs_train_steps_sgd: stamps must be non-zero and must not wrap (zero the scratch and restart at 1)");
-  const bool from_stream = stream_user_dev != nullptr;
+  const bool from_stream = stream_ui_dev != nullptr;
   if (from_stream) {
-    TRS_REQUIRE(stream_item_dev && N > 0 && first_pos >= 0 && first_pos + (int64_t)n_steps * batch <= N,
+    TRS_REQUIRE(N > 0 && first_pos >= 0 && first_pos + (int64_t)n_steps * batch <= N,
                 "trs_train_steps_sgd: steps [%lld, %lld) outside the stream of %lld rows", (long long)first_pos,
                 (long long)(first_pos + (int64_t)n_steps * batch), (long long)N);
     TRS_REQUIRE(neg_static_dev || tables->n_items >= 2, "trs_train_steps_sgd: dynamic sampling needs n_items >= 2");
@@ -700,8 +700,7 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
   a.B = batch;
   a.err = err_flag_dev;
   a.from_stream = from_stream ? 1 : 0;
-  a.su = stream_user_dev;
-  a.si = stream_item_dev;
+  a.sui = (const int2*)stream_ui_dev;
   a.neg_static = neg_static_dev;
   a.N = N;
   a.shuffle_key = shuffle_key;

@@ -162,7 +162,9 @@ class SparseScorerTrainer:
         """n_steps fused steps straight from the resident stream `st` (dict user/pos/neg int32); loss_sums: (n_steps,)
         view.  Only valid when self.fast_lr is not None and batch == capacity."""
         te, evs, ns = self._make_events(n_steps) if self.kernel_events is not None else (None, None, 0)
-        ops.train_steps_sgd(self.net.NET, self.net.tables(), st["user"], st["pos"], st["neg"], shuffle_key,
+        if "ui" not in st:
+            st["ui"] = ops.interleave_stream(st["user"], st["pos"])
+        ops.train_steps_sgd(self.net.NET, self.net.tables(), st["ui"], st["neg"], shuffle_key,
                             sample_seed, first_pos, batch, n_steps, self.fast_lr, *self.id_bufs, self.gz, self.du,
                             loss_sums, self.err, self.scratch, self._stamps(n_steps), evs)
         if te is not None:
@@ -173,7 +175,7 @@ class SparseScorerTrainer:
         epoch order) starting at row `first`."""
         te, evs, ns = self._make_events(n_steps) if self.kernel_events is not None else (None, None, 0)
         e = first + n_steps * batch
-        ops.train_steps_sgd(self.net.NET, self.net.tables(), None, None, None, 0, 0, 0, batch, n_steps, self.fast_lr,
+        ops.train_steps_sgd(self.net.NET, self.net.tables(), None, None, 0, 0, 0, batch, n_steps, self.fast_lr,
                             ep["user"][first:e], ep["pos"][first:e], ep["neg"][first:e], self.gz, self.du, loss_sums,
                             self.err, self.scratch, self._stamps(n_steps), evs)
         if te is not None:
@@ -186,7 +188,7 @@ class SparseScorerTrainer:
         net = self.net
         if self.fast_lr is not None and auc_slot is None and ids["user"].dtype == torch.int32:
             te, evs, ns = self._make_events(1) if self.kernel_events is not None else (None, None, 0)
-            ops.train_steps_sgd(net.NET, net.tables(), None, None, None, 0, 0, 0, B, 1, self.fast_lr, ids["user"],
+            ops.train_steps_sgd(net.NET, net.tables(), None, None, 0, 0, 0, B, 1, self.fast_lr, ids["user"],
                                 ids["pos"], ids["neg"], self.gz, self.du, loss_slot, self.err, self.scratch,
                                 self._stamps(1), evs)
             if te is not None:

@@ -142,16 +142,21 @@ def train_scratch(n_users, n_items, batch, D, device):
     return torch.zeros(nbytes // 8 + 1, dtype=torch.int64, device=device)
 
 
-def train_steps_sgd(net, T, stream_user, stream_item, neg_static, shuffle_key, sample_seed, first_pos, batch, n_steps,
+def interleave_stream(stream_user, stream_item):
+    """(N,2) int32 {user, item} pairs: the layout trs_train_steps_sgd reads the resident stream in."""
+    return torch.stack([stream_user, stream_item], dim=1).contiguous()
+
+
+def train_steps_sgd(net, T, stream_ui, neg_static, shuffle_key, sample_seed, first_pos, batch, n_steps,
                     lr, user_buf, pos_buf, neg_buf, gz_buf, du_buf, loss_sums, err_flag, scratch=None, first_stamp=1,
                     events=None):
-    """n_steps fused SGD steps driven from C (trs_train_steps_sgd).  stream_user None: one step on the ids already in
+    """n_steps fused SGD steps driven from C (trs_train_steps_sgd).  stream_ui None: the steps' ids are already in
     user/pos/neg_buf.  events: optional flat list of 4*n_steps torch.cuda.Event (already created by a record())."""
     ev = None
     if events is not None:
         ev = (C.c_void_p * len(events))(*events)  # raw hipEvent_t handles (or None = step not timed)
-    N = 0 if stream_user is None else stream_user.numel()
-    check(_lib.load().trs_train_steps_sgd(NET_ID[net], C.byref(T), ptr(stream_user), ptr(stream_item), ptr(neg_static),
+    N = 0 if stream_ui is None else stream_ui.shape[0]
+    check(_lib.load().trs_train_steps_sgd(NET_ID[net], C.byref(T), ptr(stream_ui), ptr(neg_static),
                                           N, int(shuffle_key), int(sample_seed), int(first_pos), int(batch),
                                           int(n_steps), float(lr), ptr(user_buf), ptr(pos_buf), ptr(neg_buf),
                                           ptr(gz_buf), ptr(du_buf), ptr(loss_sums), ptr(err_flag), ptr(scratch),
