@@ -7,7 +7,8 @@
 
 A "step" is one pass of the training hot path over one batch of synthetic interactions already resident in HBM:
 epoch-shuffle slice + dynamic negative sampling -> fused embedding gather + FM pairwise scoring + hinge + backward ->
-sparse embedding-row SGD update.  Workload (BASELINE.json configs[1], SURVEY §8d "c2"): net_type='fm',
+sparse embedding-row SGD update.  In the dense regime the item references of every 256 batches are grouped by row once
+(trs_epoch_presort); that work runs INSIDE the timed region at its true rate (default 1024 timed steps = 4 slices).  Workload (BASELINE.json configs[1], SURVEY §8d "c2"): net_type='fm',
 1M users x 100K items x 100M interactions (80M train triples after the 0.8 split), dim=64, dynamic_neg_sampling=True,
 batch 65 536, torch.optim.SGD(lr=1e-2), fp32.  metric = training interactions/s (pos+neg) = 2 x triples/s.
 
@@ -58,8 +59,8 @@ def synth_stream(n_users, n_items, n, device, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=1024)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-kernel HIP event timing")
@@ -158,7 +159,8 @@ def main():
                       # rows (+terms) and needs the user row; K3 writes the user row (+term)
                       "fwd_stage_kernel": 16 + R * (4 * D + 4) + 8, "item_update_kernel": 12 + 3 * (4 * D + 4),
                       "user_update_kernel": 4 + (4 * D + 4)}
-        # "item_update_kernel" = the two launches item_owner_update_kernel (plain) + item_update_kernel<.,2> (atomics)
+        # "item_update_kernel" = sorted_item_update_kernel (presorted references), or the two launches
+        # item_owner_update_kernel (plain) + item_update_kernel<.,2> (atomics) when the presort is off
         ach = per_triple[dom] * B / (mean_ms[dom] * 1e-3) / 1e9
         # measured HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
         # corrected as MI355X_MICROARCH.md prescribes); valid for the c2 workload on one GPU only
@@ -166,7 +168,8 @@ def main():
         pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if args.config == "c2" and os.path.exists(pmc_path):
             pk = json.load(open(pmc_path))["kernels"]
-            parts = {"item_update_kernel": ("item_owner_update_kernel", "item_update_kernel"),
+            parts = {"item_update_kernel": ("sorted_item_update_kernel",) if "sorted_item_update_kernel" in pk
+                     else ("item_owner_update_kernel", "item_update_kernel"),
                      "fwd_stage_kernel": ("fwd_stage_kernel",), "user_update_kernel": ("user_plain_update_kernel",)}
             if all(q in pk for q in parts.get(dom, ("?",))):
                 traffic = sum(pk[q]["traffic_bytes_per_launch"] for q in parts[dom])

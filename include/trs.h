@@ -159,7 +159,24 @@ int trs_train_steps_sgd(int net, const trs_tables* tables, const int32_t* stream
                         uint64_t shuffle_key, uint64_t sample_seed, int64_t first_pos, int64_t batch, int32_t n_steps,
                         float lr, int32_t* user_buf_dev, int32_t* pos_buf_dev, int32_t* neg_buf_dev,
                         float* gz_buf_dev, float* du_buf_dev, float* loss_sums_dev, int32_t* err_flag_dev,
-                        void* scratch_dev, uint32_t first_stamp, void** events, void* stream);
+                        void* scratch_dev, uint32_t first_stamp, const void* sorted_keys_dev,
+                        const void* sorted_vals_dev, int32_t key_bytes, void** events, void* stream);
+
+/* Epoch-level grouping of the item references by row (dense regime: most item rows are referenced several times per
+ * step).  trs_epoch_presort covers n_batches whole batches starting at epoch position first_pos: it writes the triples'
+ * ids (generated from the resident stream exactly as trs_batch_prepare would, or taken as given when stream_ui is NULL)
+ * and the 2*batch references of every batch sorted by item row (rocprim radix sort; key = batch*2^bits(n_items) + item,
+ * payload = {user, (t<<1)|which}).  Passing the sorted arrays (offset to the first batch of the call) to
+ * trs_train_steps_sgd together with the id arrays replaces K2a/K2b by one atomic-free launch: each run of equal keys is
+ * summed by one lane group and applied with a plain whole-row read-modify-write (runs are cut every 64 references; cut
+ * pieces of hot rows use float atomics).  Buffers: keys/vals two halves each (sizes from trs_epoch_presort_sizes). */
+int trs_epoch_presort_sizes(int64_t n_batches, int64_t batch, int64_t n_items, int64_t* key_bytes_out,
+                            int64_t* keys_total_bytes_out, int64_t* vals_total_bytes_out, int64_t* temp_bytes_out);
+int trs_epoch_presort(const int32_t* stream_ui_dev, const int32_t* neg_static_dev, int64_t N, uint64_t shuffle_key,
+                      uint64_t sample_seed, int64_t first_pos, int64_t n_batches, int64_t batch, int64_t n_users,
+                      int64_t n_items, int32_t* user_dev, int32_t* pos_dev, int32_t* neg_dev, void* keys_dev,
+                      void* vals_dev, void* temp_dev, int64_t temp_bytes, int32_t* err_flag_dev,
+                      void** sorted_keys_out, void** sorted_vals_out, void* stream);
 
 /* ---------------------------------------------------------------- sparse row optimisers (a7, App. A.5) */
 /* table[idx[t]] += alpha * vals[t]  for t < n, rows of D floats, vals row t at vals + t*ld.  Float atomics, one

@@ -504,3 +504,70 @@ def test_gemm_fused_bn_statistics(B, passes, K, H, bf16):
     assert rel_err(m1.cpu().numpy(), y64.mean(axis=1)) < 1e-6 and rel_err(v1.cpu().numpy(), y64.var(axis=1)) < 2e-6
     assert rel_err(m1.cpu().numpy(), m2.cpu().numpy()) < 1e-6 and rel_err(v1.cpu().numpy(), v2.cpu().numpy()) < 2e-6
     assert rel_err(rm1.cpu().numpy(), rm2.cpu().numpy()) < 1e-6 and rel_err(rv1.cpu().numpy(), rv2.cpu().numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("net,D,skew", [("fm", 64, False), ("fm", 64, True), ("fm", 16, True), ("linear", 32, True),
+                                        ("fm", 80, False), ("fm", 10, True)])
+def test_presorted_item_update_matches_oracle(net, D, skew):
+    """trs_epoch_presort + the atomic-free per-run item update: 3 batches in one C call == oracle SGD steps.
+    `skew`: one hot item takes 40 % of the references (runs cut at 64, pieces added atomically)."""
+    ops = _ops()
+    rs = np.random.RandomState(D + skew)
+    NU, NI, B, nb, lr = 300, 57, 512, 3, 0.05
+    p, _, _ = make_case(net, D, 0, 8, NU=NU, NI=NI, seed=2)
+    u = rs.randint(0, NU, nb * B)
+    i = rs.randint(0, NI, nb * B)
+    j = rs.randint(0, NI, nb * B)
+    if skew:
+        i[rs.rand(nb * B) < 0.4] = 7
+        j[rs.rand(nb * B) < 0.4] = 7
+    lin = ("user_bias.weight", "item_bias.weight") if net == "linear" else ("linear_user.weight", "linear_item.weight")
+    t = {k: torch.from_numpy(v.copy()).to(DEV) for k, v in p.items()}
+    T, keep = ops.make_tables(t["user.weight"], t["item.weight"], t[lin[0]], t[lin[1]])
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ps = ops.EpochPresort(nb, B, NU, NI, DEV)
+    given = [torch.from_numpy(a.astype(np.int32)).to(DEV) for a in (u, i, j)]
+    ps.run(None, None, 0, 0, 0, err, given_ids=given)
+    ids, sk, sv = ps.step_args(0)
+    gz, du = torch.empty((2, B), device=DEV), torch.empty((B, D), device=DEV)
+    losses = torch.zeros(nb, device=DEV)
+    ops.train_steps_sgd(net, T, None, None, 0, 0, 0, B, nb, lr, *ids, gz, du, losses, err,
+                        ops.train_scratch(NU, NI, B, D, DEV), 1, None, sk, sv, ps.key_bytes)
+    torch.cuda.synchronize()
+    ref = {k: v.copy() for k, v in p.items()}
+    for b in range(nb):
+        batch = {"user_id": u[b * B:(b + 1) * B], "pos_item_id": i[b * B:(b + 1) * B], "neg_item_id": j[b * B:(b + 1) * B]}
+        _, _, loss, grads = onets.train_forward_backward(net, ref, batch)
+        ooptim.sgd_step(ref, grads, lr)
+        assert abs(losses[b].item() / B - float(loss)) <= TOL * max(abs(float(loss)), 1e-3)
+    for k, v in ref.items():
+        assert rel_err(t[k].cpu().numpy(), v) < TOL, k
+    assert err.item() == 0
+
+
+def test_presort_generates_the_same_batches_as_batch_prepare():
+    ops = _ops()
+    rs = np.random.RandomState(1)
+    N, NU, NI, B, nb = 6000, 400, 91, 256, 4
+    su = torch.from_numpy(rs.randint(0, NU, N).astype(np.int32)).to(DEV)
+    si = torch.from_numpy(rs.randint(0, NI, N).astype(np.int32)).to(DEV)
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ps = ops.EpochPresort(nb, B, NU, NI, DEV)
+    key, seed_ = 0xC0FFEE1234, 99
+    ps.run(ops.interleave_stream(su, si), None, key, seed_, 512, err)
+    torch.cuda.synchronize()
+    for b in range(nb):
+        out = ops.batch_prepare(su, si, None, key, 512 + b * B, B, NI, seed_, 512 + b * B)
+        for k, arr in zip(("user", "pos", "neg"), ps.ids):
+            assert torch.equal(arr[b * B:(b + 1) * B], out[k]), (k, b)
+    # sorted references: per batch ascending item rows, a permutation of the batch's 2B references
+    n = 2 * nb * B
+    kt = torch.uint32 if ps.key_bytes == 4 else torch.int64
+    keys = ps.keys.view(kt)[n:].cpu().numpy().astype(np.int64)
+    bits = int(np.ceil(np.log2(NI)))
+    assert (np.diff(keys) >= 0).all()
+    for b in range(nb):
+        items = keys[2 * b * B:2 * (b + 1) * B] & ((1 << bits) - 1)
+        assert ((keys[2 * b * B:2 * (b + 1) * B] >> bits) == b).all()
+        exp = np.sort(np.concatenate([ps.ids[1][b * B:(b + 1) * B].cpu().numpy(), ps.ids[2][b * B:(b + 1) * B].cpu().numpy()]))
+        assert np.array_equal(items, exp)

@@ -205,8 +205,10 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
         if (live && a.uown) {
           const uint64_t hi = (uint64_t)a.stamp << 32;
           a.uown[id.u] = hi | (uint64_t)(uint32_t)tt;
-          a.iown[id.p] = hi | (uint64_t)(uint32_t)(2 * tt);
-          a.iown[id.n] = hi | (uint64_t)(uint32_t)(2 * tt + 1);
+          if (a.iown) {  // wave-uniform; not needed when the item references were presorted (presort.hip)
+            a.iown[id.p] = hi | (uint64_t)(uint32_t)(2 * tt);
+            a.iown[id.n] = hi | (uint64_t)(uint32_t)(2 * tt + 1);
+          }
         }
       }
     }
@@ -664,6 +666,12 @@ static int launch_updates(const FastArgs& a, hipStream_t s, hipEvent_t ev_k3) {
 
 using namespace trs;
 
+// presort.hip
+int trs_launch_sorted_item_update(const trs_tables* tables, const void* keys_step, const void* vals_step, int key_bytes,
+                                  int64_t batch, int64_t item_bits, const float* gz, float lr, uint64_t* uown,
+                                  uint32_t* udup, uint32_t stamp, hipStream_t s);
+int trs_item_bits_for(int64_t n_items);
+
 extern "C" int64_t trs_train_scratch_bytes(int64_t n_users, int64_t n_items, int64_t batch, int32_t D) {
   if (n_users <= 0 || n_items <= 0 || batch <= 0 || D <= 0) return 0;
   return 12 * (n_users + n_items);  // uown, iown (8 B per row) + udup, idup (4 B per row)
@@ -674,8 +682,9 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
                                    uint64_t shuffle_key, uint64_t sample_seed, int64_t first_pos, int64_t batch,
                                    int32_t n_steps, float lr, int32_t* user_buf_dev, int32_t* pos_buf_dev,
                                    int32_t* neg_buf_dev, float* gz_buf_dev, float* du_buf_dev, float* loss_sums_dev,
-                                   int32_t* err_flag_dev, void* scratch_dev, uint32_t first_stamp, void** events,
-                                   void* stream) {
+                                   int32_t* err_flag_dev, void* scratch_dev, uint32_t first_stamp,
+                                   const void* sorted_keys_dev, const void* sorted_vals_dev, int32_t key_bytes,
+                                   void** events, void* stream) {
   TRS_REQUIRE(net == TRS_NET_LINEAR || net == TRS_NET_FM, "trs_train_steps_sgd: bad net");
   TRS_REQUIRE(tables && tables->M == 0, "trs_train_steps_sgd: only scorers without metadata (M == 0)");
   TRS_REQUIRE(tables->user && tables->item && tables->user_lin && tables->item_lin, "trs_train_steps_sgd: NULL table");
@@ -685,6 +694,11 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
   TRS_REQUIRE(!scratch_dev || (first_stamp != 0 && (uint64_t)first_stamp + (uint64_t)n_steps < 0xFFFFFFFFull),
               "trs_train_steps_sgd: stamps must be non-zero and must not wrap (zero the scratch and restart at 1)");
   const bool from_stream = stream_ui_dev != nullptr;
+  const bool sorted = sorted_keys_dev != nullptr;
+  if (sorted) {
+    TRS_REQUIRE(!from_stream && scratch_dev && sorted_vals_dev && (key_bytes == 4 || key_bytes == 8),
+                "trs_train_steps_sgd: the presorted mode needs the epoch's id arrays, scratch and sorted references");
+  }
   if (from_stream) {
     TRS_REQUIRE(N > 0 && first_pos >= 0 && first_pos + (int64_t)n_steps * batch <= N,
                 "trs_train_steps_sgd: steps [%lld, %lld) outside the stream of %lld rows", (long long)first_pos,
@@ -715,7 +729,9 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
     a.iown = a.uown + tables->n_users;
     a.udup = (uint32_t*)(a.iown + tables->n_items);
     a.idup = a.udup + tables->n_users;
+    if (sorted) a.iown = nullptr;  // K1 marks users only
   }
+  const int item_bits = trs_item_bits_for(tables->n_items);
   for (int32_t st = 0; st < n_steps; ++st) {
     a.t0 = first_pos + (int64_t)st * batch;
     a.sample_offset = (uint64_t)a.t0;
@@ -732,7 +748,17 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
     int rc = net == TRS_NET_FM ? launch_fwd_stage<TRS_NET_FM>(a, s) : launch_fwd_stage<TRS_NET_LINEAR>(a, s);
     if (rc) return rc;
     if (ev) (void)hipEventRecord(ev[1], s);
-    rc = launch_updates(a, s, ev ? ev[2] : nullptr);
+    if (sorted) {  // K2: per-run owner update from the presorted references, then K3
+      const char* ks = (const char*)sorted_keys_dev + (int64_t)st * 2 * batch * key_bytes;
+      const char* vs = (const char*)sorted_vals_dev + (int64_t)st * 2 * batch * 8;
+      rc = trs_launch_sorted_item_update(tables, ks, vs, key_bytes, batch, item_bits, a.gz, a.lr, a.uown, a.udup,
+                                         a.stamp, s);
+      if (rc) return rc;
+      if (ev) (void)hipEventRecord(ev[2], s);
+      rc = launch_plain<1>(a, s);
+    } else {
+      rc = launch_updates(a, s, ev ? ev[2] : nullptr);
+    }
     if (rc) return rc;
     if (ev) (void)hipEventRecord(ev[3], s);
   }

@@ -1,0 +1,334 @@
+// presort.hip — epoch-level grouping of item references by row, and the atomic-free item update that uses it.
+//
+// In the dense regime (c2: 131 072 item references over 100 000 rows per step) most item rows are referenced several
+// times per step, and summing those references with memory-side float atomics (~1.3 TB/s chip-wide) is the wall of the
+// step.  The references of a whole epoch are known when the epoch starts (the shuffle is a keyed bijection of the
+// position, the negative a counter-based draw), so they are grouped ONCE per epoch:
+//   epoch_refs_kernel   every position q of the epoch -> its triple (u, i, j) [written out: K1 then reads contiguous ids
+//                       instead of deriving them] and two references  key = batch * 2^item_bits + item,
+//                       payload = {user, (t << 1) | which};
+//   rocprim radix sort  by key over the item_bits + batch_bits low bits: per batch, references sorted by item row.
+// Per step, sorted_item_update_kernel gives every run of equal keys to ONE lane group: it sums c * u over the run
+// (c = -lr * gz of the reference, u = the still-unmodified user row) in registers and applies it with a single plain
+// whole-row read-modify-write.  Runs are cut at 64-reference boundaries so a hot row (skewed data) is reduced by many
+// groups in parallel; only such cut runs fall back to float atomics (one add per 64 references instead of 64).
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "score_kernels.h"
+
+namespace trs {
+
+struct RefPayload {
+  int32_t user;
+  uint32_t tw;  // (t << 1) | which   (t = position inside the batch, which: 0 positive / 1 negative)
+};
+
+struct EpochArgs {
+  const int2* sui;  // resident stream {user, item} or NULL (ids given in user/pos/neg)
+  const int32_t* neg_static;
+  int64_t N;
+  uint64_t shuffle_key;
+  int hb;
+  uint64_t sample_seed;
+  int64_t first_pos;  // epoch position of the first triple
+  int64_t n_pos;      // triples covered (whole batches)
+  int64_t batch;
+  int64_t n_users, n_items;
+  int item_bits;
+  int32_t* user;  // (n_pos) in/out
+  int32_t* pos;
+  int32_t* neg;
+  void* keys;  // (2*n_pos) uint32 or uint64
+  RefPayload* vals;
+  int32_t* err;
+};
+
+template <typename KeyT, int SRC>
+__global__ __launch_bounds__(TRS_BLOCK) void epoch_refs_kernel(const EpochArgs a) {
+  const int64_t stride = (int64_t)gridDim.x * TRS_BLOCK;
+  KeyT* keys = reinterpret_cast<KeyT*>(a.keys);
+  for (int64_t q = (int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x; q < a.n_pos; q += stride) {
+    int64_t u, i, j;
+    if (SRC != 0) {
+      const int64_t p = trs_feistel_perm(a.first_pos + q, a.N, a.shuffle_key, a.hb);
+      const int2 ui = a.sui[p];
+      u = ui.x;
+      i = ui.y;
+      j = SRC == 2 ? (int64_t)a.neg_static[p]
+                   : trs_sample_one_neg(a.sample_seed, (uint64_t)(a.first_pos + q), i, a.n_items);
+    } else {
+      u = a.user[q];
+      i = a.pos[q];
+      j = a.neg[q];
+    }
+    bool ok = true;
+    if ((uint64_t)u >= (uint64_t)a.n_users) { ok = false; u = 0; }
+    if ((uint64_t)i >= (uint64_t)a.n_items) { ok = false; i = 0; }
+    if ((uint64_t)j >= (uint64_t)a.n_items) { ok = false; j = 0; }
+    if (!ok && a.err) atomicOr(a.err, 1);  // reported as IndexError at the end of the epoch
+    if (SRC != 0 || !ok) {
+      a.user[q] = (int32_t)u;
+      a.pos[q] = (int32_t)i;
+      a.neg[q] = (int32_t)j;
+    }
+    const int64_t b = q / a.batch;
+    const uint32_t t = (uint32_t)(q - b * a.batch);
+    keys[2 * q] = (KeyT)(((uint64_t)b << a.item_bits) | (uint64_t)i);
+    keys[2 * q + 1] = (KeyT)(((uint64_t)b << a.item_bits) | (uint64_t)j);
+    RefPayload v0 = {(int32_t)u, (t << 1)}, v1 = {(int32_t)u, (t << 1) | 1u};
+    a.vals[2 * q] = v0;
+    a.vals[2 * q + 1] = v1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- per-step update
+struct SortedArgs {
+  trs_tables T;
+  const void* keys;         // this step's 2B sorted keys
+  const RefPayload* vals;   // this step's 2B sorted payloads
+  int64_t B;
+  int item_bits;
+  const float* gz;          // (2,B)
+  float lr;
+  uint64_t* uown;
+  uint32_t* udup;
+  uint32_t stamp;
+};
+
+constexpr int RUN_CHUNK = 64;  // runs are cut at multiples of this many references
+
+template <typename KeyT, int VEC, int G, int K, bool FULL>
+__global__ __launch_bounds__(TRS_BLOCK) void sorted_item_update_kernel(const SortedArgs a) {
+  constexpr int N = K * VEC;
+  constexpr int TPW = TRS_WAVE / G;
+  const trs_tables& T = a.T;
+  const int D = T.D;
+  const int64_t n = 2 * a.B;
+  const KeyT* keys = reinterpret_cast<const KeyT*>(a.keys);
+  const KeyT row_mask = (KeyT)(((uint64_t)1 << a.item_bits) - 1);
+  const int lane = threadIdx.x & 63;
+  const int lig = lane % G;
+  const int64_t wave = ((int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x) >> 6;
+  const int64_t nwave = ((int64_t)gridDim.x * TRS_BLOCK) >> 6;
+  const uint64_t hi = (uint64_t)a.stamp << 32;
+  const int64_t niter = (n + TPW - 1) / TPW;
+  for (int64_t it = wave; it < niter; it += nwave) {
+    const int64_t i = it * TPW + lane / G;
+    const bool valid = i < n;
+    const int64_t ic = valid ? i : n - 1;
+    // everything the first element of a run needs is requested up front, unconditionally (a conditional block that
+    // contains a load would end in s_waitcnt vmcnt(0)); groups that turn out not to lead a run read row 0 instead
+    const KeyT key = keys[ic];
+    const KeyT prev = keys[ic > 0 ? ic - 1 : 0];
+    const RefPayload me = a.vals[ic];
+    const bool head = ic == 0 || prev != key;
+    const bool leader = valid && (head || (ic % RUN_CHUNK) == 0);
+    const uint64_t own = a.uown[me.user];
+    const float c0 = -a.lr * a.gz[(int64_t)(me.tw & 1u) * a.B + (me.tw >> 1)];
+    const int64_t row = (int64_t)(key & row_mask);
+    RowReg<VEC, K> u0, w;
+    row_load<VEC, G, K, FULL>(u0, T.user, leader ? me.user : 0, D, lig);
+    row_load<VEC, G, K, FULL>(w, T.item, leader ? row : 0, D, lig);
+    const float wl = T.item_lin[leader ? row : 0];
+    // the positive reference of a triple also checks whether its user row has other references in this step (K3)
+    if (valid && (me.tw & 1u) == 0 && lig == 0 && own != (hi | (uint64_t)(me.tw >> 1))) a.udup[me.user] = a.stamp;
+    if (!leader) continue;
+    const int64_t chunk_end = (ic / RUN_CHUNK + 1) * RUN_CHUNK < n ? (ic / RUN_CHUNK + 1) * RUN_CHUNK : n;
+    RowReg<VEC, K> acc;
+#pragma unroll
+    for (int q = 0; q < N; ++q) acc.v[q] = c0 * u0.v[q];
+    float lin = c0;
+    int64_t j = ic + 1;
+    while (j < chunk_end && keys[j] == key) {  // further references of the same row (short: 1.3 per row at c2)
+      const RefPayload pl = a.vals[j];
+      const float c = -a.lr * a.gz[(int64_t)(pl.tw & 1u) * a.B + (pl.tw >> 1)];
+      RowReg<VEC, K> u;
+      row_load<VEC, G, K, FULL>(u, T.user, pl.user, D, lig);
+#pragma unroll
+      for (int q = 0; q < N; ++q) acc.v[q] += c * u.v[q];
+      lin += c;
+      ++j;
+    }
+    // the run is the whole segment iff it starts at a head and did not stop at a chunk boundary inside the segment
+    const bool cut_tail = j == chunk_end && j < n && keys[j] == key;
+    float* irow = T.item + row * (int64_t)D;
+    if (head && !cut_tail) {
+#pragma unroll
+      for (int q = 0; q < N; ++q) w.v[q] += acc.v[q];
+      row_store<VEC, G, K>(w, irow, D, lig);
+      if (lig == 0) T.item_lin[row] = wl + lin;
+    } else {  // a cut piece of a long segment (hot row): several groups add into the row
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) {
+        const int e = (kk * G + lig) * VEC;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q)
+          if (e + q < D) atomicAdd(irow + e + q, acc.v[kk * VEC + q]);
+      }
+      if (lig == 0) atomicAdd(T.item_lin + row, lin);
+    }
+  }
+}
+
+static int bits_for(int64_t n) {
+  int b = 1;
+  while (b < 63 && ((int64_t)1 << b) < n) ++b;
+  return b;
+}
+
+}  // namespace trs
+
+using namespace trs;
+
+// Sizes (bytes) a caller must provide for an epoch slice of n_batches whole batches:
+//   ids: 3 x n_pos int32 (user, pos, neg)   keys: 2 x (2 n_pos) keys   vals: 2 x (2 n_pos) x 8   temp: rocprim scratch
+extern "C" int trs_epoch_presort_sizes(int64_t n_batches, int64_t batch, int64_t n_items, int64_t* key_bytes_out,
+                                       int64_t* keys_total_bytes_out, int64_t* vals_total_bytes_out,
+                                       int64_t* temp_bytes_out) {
+  TRS_REQUIRE(n_batches > 0 && batch > 0 && n_items > 0, "trs_epoch_presort_sizes: bad arguments");
+  TRS_REQUIRE(key_bytes_out && keys_total_bytes_out && vals_total_bytes_out && temp_bytes_out,
+              "trs_epoch_presort_sizes: NULL output");
+  const int bits = bits_for(n_items) + bits_for(n_batches);
+  TRS_REQUIRE(bits <= 62, "trs_epoch_presort_sizes: key does not fit 62 bits");
+  const int kb = bits <= 32 ? 4 : 8;
+  const size_t n = (size_t)(2 * n_batches * batch);
+  size_t temp = 0;
+  hipError_t e;
+  if (kb == 4)
+    e = rocprim::radix_sort_pairs(nullptr, temp, (uint32_t*)nullptr, (uint32_t*)nullptr, (RefPayload*)nullptr,
+                                  (RefPayload*)nullptr, n, 0u, (unsigned)bits, (hipStream_t)0);
+  else
+    e = rocprim::radix_sort_pairs(nullptr, temp, (uint64_t*)nullptr, (uint64_t*)nullptr, (RefPayload*)nullptr,
+                                  (RefPayload*)nullptr, n, 0u, (unsigned)bits, (hipStream_t)0);
+  TRS_REQUIRE(e == hipSuccess, "trs_epoch_presort_sizes: rocprim size query failed");
+  *key_bytes_out = kb;
+  *keys_total_bytes_out = 2 * (int64_t)n * kb;
+  *vals_total_bytes_out = 2 * (int64_t)n * (int64_t)sizeof(RefPayload);
+  *temp_bytes_out = (int64_t)temp + 256;
+  return TRS_OK;
+}
+
+// Builds the epoch slice: ids (user/pos/neg, n_pos each; generated when stream_ui is non-NULL, else taken as given and
+// only clamped) and the item references sorted per batch by item row.  keys_dev / vals_dev hold two halves each (input |
+// sorted output); *sorted_keys_out / *sorted_vals_out receive the device addresses of the sorted halves.
+extern "C" int trs_epoch_presort(const int32_t* stream_ui_dev, const int32_t* neg_static_dev, int64_t N,
+                                 uint64_t shuffle_key, uint64_t sample_seed, int64_t first_pos, int64_t n_batches,
+                                 int64_t batch, int64_t n_users, int64_t n_items, int32_t* user_dev, int32_t* pos_dev,
+                                 int32_t* neg_dev, void* keys_dev, void* vals_dev, void* temp_dev, int64_t temp_bytes,
+                                 int32_t* err_flag_dev, void** sorted_keys_out, void** sorted_vals_out, void* stream) {
+  TRS_REQUIRE(n_batches > 0 && batch > 0 && n_users > 0 && n_items > 0, "trs_epoch_presort: bad sizes");
+  TRS_REQUIRE(user_dev && pos_dev && neg_dev && keys_dev && vals_dev && temp_dev, "trs_epoch_presort: NULL buffer");
+  TRS_REQUIRE(sorted_keys_out && sorted_vals_out, "trs_epoch_presort: NULL output");
+  const int64_t n_pos = n_batches * batch;
+  if (stream_ui_dev)
+    TRS_REQUIRE(N > 0 && first_pos >= 0 && first_pos + n_pos <= N, "trs_epoch_presort: slice outside the stream");
+  EpochArgs a = {};
+  a.sui = (const int2*)stream_ui_dev;
+  a.neg_static = neg_static_dev;
+  a.N = N;
+  a.shuffle_key = shuffle_key;
+  a.hb = stream_ui_dev ? trs_feistel_half_bits(N) : 0;
+  a.sample_seed = sample_seed;
+  a.first_pos = first_pos;
+  a.n_pos = n_pos;
+  a.batch = batch;
+  a.n_users = n_users;
+  a.n_items = n_items;
+  a.item_bits = bits_for(n_items);
+  a.user = user_dev;
+  a.pos = pos_dev;
+  a.neg = neg_dev;
+  a.keys = keys_dev;
+  a.vals = (RefPayload*)vals_dev;
+  a.err = err_flag_dev;
+  const int bits = a.item_bits + bits_for(n_batches);
+  TRS_REQUIRE(bits <= 62, "trs_epoch_presort: key does not fit 62 bits");
+  const bool k32 = bits <= 32;
+  const int src = !stream_ui_dev ? 0 : (neg_static_dev ? 2 : 1);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 gr(trs_grid(n_pos, TRS_BLOCK)), bl(TRS_BLOCK);
+#define TRS_EP(KT)                                                                      \
+  {                                                                                     \
+    if (src == 0) hipLaunchKernelGGL((epoch_refs_kernel<KT, 0>), gr, bl, 0, s, a);       \
+    else if (src == 1) hipLaunchKernelGGL((epoch_refs_kernel<KT, 1>), gr, bl, 0, s, a);  \
+    else hipLaunchKernelGGL((epoch_refs_kernel<KT, 2>), gr, bl, 0, s, a);                \
+  }
+  if (k32) TRS_EP(uint32_t) else TRS_EP(uint64_t)
+#undef TRS_EP
+  TRS_CHECK_LAUNCH("epoch_refs_kernel");
+  const size_t n = (size_t)(2 * n_pos);
+  size_t temp = (size_t)temp_bytes;
+  RefPayload* vin = (RefPayload*)vals_dev;
+  RefPayload* vout = vin + n;
+  hipError_t e;
+  if (k32) {
+    uint32_t* kin = (uint32_t*)keys_dev;
+    e = rocprim::radix_sort_pairs(temp_dev, temp, kin, kin + n, vin, vout, n, 0u, (unsigned)bits, s);
+    *sorted_keys_out = (void*)(kin + n);
+  } else {
+    uint64_t* kin = (uint64_t*)keys_dev;
+    e = rocprim::radix_sort_pairs(temp_dev, temp, kin, kin + n, vin, vout, n, 0u, (unsigned)bits, s);
+    *sorted_keys_out = (void*)(kin + n);
+  }
+  *sorted_vals_out = (void*)vout;
+  if (e != hipSuccess) {
+    trs_set_error("trs_epoch_presort: rocprim::radix_sort_pairs failed: %s", hipGetErrorString(e));
+    return TRS_E_LAUNCH;
+  }
+  return TRS_OK;
+}
+
+// One launch of the sorted item update for a step (used by trs_train_steps_sgd's sorted mode).
+int trs_launch_sorted_item_update(const trs_tables* tables, const void* keys_step, const void* vals_step, int key_bytes,
+                                  int64_t batch, int64_t n_batches_bits_items, const float* gz, float lr,
+                                  uint64_t* uown, uint32_t* udup, uint32_t stamp, hipStream_t s) {
+  SortedArgs a = {};
+  a.T = *tables;
+  a.keys = keys_step;
+  a.vals = (const RefPayload*)vals_step;
+  a.B = batch;
+  a.item_bits = (int)n_batches_bits_items;
+  a.gz = gz;
+  a.lr = lr;
+  a.uown = uown;
+  a.udup = udup;
+  a.stamp = stamp;
+  RowCfg c;
+  if (!pick_row_cfg(tables->D, c)) {
+    trs_set_error("unsupported n_factors D=%d", tables->D);
+    return TRS_E_ARG;
+  }
+  const int tpw = TRS_WAVE / c.g;
+  const dim3 gr(trs_grid((2 * batch + tpw - 1) / tpw, TRS_BLOCK / TRS_WAVE)), bl(TRS_BLOCK);
+#define TRS_SL(V, GG, KK, FULL)                                                                              \
+  {                                                                                                          \
+    if (key_bytes == 4) hipLaunchKernelGGL((sorted_item_update_kernel<uint32_t, V, GG, KK, FULL>), gr, bl, 0, s, a); \
+    else hipLaunchKernelGGL((sorted_item_update_kernel<uint64_t, V, GG, KK, FULL>), gr, bl, 0, s, a);         \
+  }
+#define TRS_CASE(V, GG, KK)                                                                  \
+  if (c.vec == V && c.g == GG && c.k == KK) {                                                \
+    if (V * GG * KK == tables->D) TRS_SL(V, GG, KK, true) else TRS_SL(V, GG, KK, false)      \
+    TRS_CHECK_LAUNCH("sorted_item_update_kernel");                                           \
+    return TRS_OK;                                                                           \
+  }
+  TRS_CASE(4, 2, 1)
+  TRS_CASE(4, 4, 1)
+  TRS_CASE(4, 8, 1)
+  TRS_CASE(4, 16, 1)
+  TRS_CASE(4, 32, 1)
+  TRS_CASE(4, 64, 1)
+  TRS_CASE(4, 64, 2)
+  TRS_CASE(4, 64, 4)
+  TRS_CASE(1, 4, 1)
+  TRS_CASE(1, 16, 1)
+  TRS_CASE(1, 64, 1)
+  TRS_CASE(1, 64, 4)
+#undef TRS_CASE
+#undef TRS_SL
+  trs_set_error("internal: no kernel for D=%d", tables->D);
+  return TRS_E_ARG;
+}
+
+int trs_item_bits_for(int64_t n_items) { return bits_for(n_items); }

@@ -170,6 +170,46 @@ class SparseScorerTrainer:
         if te is not None:
             self._collect_events(te, ns)
 
+    # ---- presorted item references (csrc/presort.hip): dense regime only ------------------------------------------
+    SLICE_BATCHES = 256  # batches grouped per presort call (bounds the buffers: 2*256*B references)
+
+    def wants_presort(self, batch):
+        """Most item rows get several references per step when 2B is a sizeable fraction of n_items: then grouping the
+        references by row once per epoch slice removes the float atomics from the item update."""
+        n_items = self.params[1].shape[0]
+        if self.fast_lr is None or 2 * batch < 0.25 * n_items:
+            return False
+        need = ops.EpochPresort.bytes_needed(self.SLICE_BATCHES, batch, n_items)
+        free, _ = torch.cuda.mem_get_info(self.dev)
+        return need < 0.3 * free
+
+    def presort_slice(self, n_batches, batch, st=None, shuffle_key=0, sample_seed=0, first_pos=0, given_ids=None):
+        """Group the item references of the next `n_batches` whole batches (device stream `st`, or host-prepared ids)."""
+        ps = getattr(self, "_presort", None)
+        if ps is None or ps.batch != batch or ps.n_batches < n_batches:
+            ps = self._presort = ops.EpochPresort(max(n_batches, min(self.SLICE_BATCHES, n_batches)), batch,
+                                                  self.params[0].shape[0], self.params[1].shape[0], self.dev)
+        if ps.n_batches != n_batches:  # a shorter tail slice: same buffers, fewer batches
+            ps = ops.EpochPresort.__new__(ops.EpochPresort)
+            ps.__dict__.update(self._presort.__dict__)
+            ps.n_batches = n_batches
+        if st is not None:
+            if "ui" not in st:
+                st["ui"] = ops.interleave_stream(st["user"], st["pos"])
+            ps.run(st["ui"], st["neg"], shuffle_key, sample_seed, first_pos, self.err)
+        else:
+            ps.run(None, None, 0, 0, 0, self.err, given_ids=given_ids)
+        return ps
+
+    def fast_sorted_steps(self, ps, b_in_slice, batch, n_steps, loss_sums):
+        te, evs, ns = self._make_events(n_steps) if self.kernel_events is not None else (None, None, 0)
+        ids, sk, sv = ps.step_args(b_in_slice)
+        ops.train_steps_sgd(self.net.NET, self.net.tables(), None, None, 0, 0, 0, batch, n_steps, self.fast_lr, *ids,
+                            self.gz, self.du, loss_sums, self.err, self.scratch, self._stamps(n_steps), evs, sk, sv,
+                            ps.key_bytes)
+        if te is not None:
+            self._collect_events(te, ns)
+
     def fast_array_steps(self, ep, first, batch, n_steps, loss_sums):
         """n_steps fused steps over consecutive batches of host-prepared epoch id arrays `ep` (dict user/pos/neg int32,
         epoch order) starting at row `first`."""

@@ -360,6 +360,7 @@ class FitRunner:
         m = self.m
         self.loss_sums.zero_()
         self.next_batch = 0
+        self._slice = None
         if self.num_batches == 0:
             return
         if m.rng == 'reference':
@@ -380,10 +381,24 @@ class FitRunner:
             fast = self.ep['user'].dtype == torch.int32
         if fast:  # whole batches, step loop in C (csrc/fast_step.hip): from the resident stream, or from the epoch's
             full = self.n_train // B  # host-prepared id arrays (bit-exact reference batches)
+            presort = self.trainer.wants_presort(B)
             while done < k and self.next_batch < full:
                 n = min(k - done, full - self.next_batch, 64)
                 b = self.next_batch
-                if m.rng == 'device':
+                if presort:  # dense regime: item references grouped by row per slice of batches (csrc/presort.hip)
+                    sl = self.trainer.SLICE_BATCHES
+                    if self._slice is None or not (self._slice[0] <= b < self._slice[0] + self._slice[1].n_batches):
+                        s0, nb = (b // sl) * sl, min(sl, full - (b // sl) * sl)
+                        if m.rng == 'device':
+                            ps = self.trainer.presort_slice(nb, B, self.st, self.shuffle_key, self.sample_seed, s0 * B)
+                        else:
+                            ps = self.trainer.presort_slice(nb, B, given_ids=[self.ep[k_][s0 * B:(s0 + nb) * B]
+                                                                              for k_ in ('user', 'pos', 'neg')])
+                        self._slice = (s0, ps)
+                    s0, ps = self._slice
+                    n = min(n, s0 + ps.n_batches - b)
+                    self.trainer.fast_sorted_steps(ps, b - s0, B, n, self.loss_sums[b:b + n])
+                elif m.rng == 'device':
                     self.trainer.fast_stream_steps(self.st, self.shuffle_key, self.sample_seed, b * B, B, n,
                                                    self.loss_sums[b:b + n])
                 else:

@@ -147,9 +147,56 @@ def interleave_stream(stream_user, stream_item):
     return torch.stack([stream_user, stream_item], dim=1).contiguous()
 
 
+class EpochPresort:
+    """Buffers + result of trs_epoch_presort for n_batches whole batches: id arrays and the item references of every
+    batch sorted by row.  `step_args(b)` gives what trs_train_steps_sgd needs to start at batch b of the slice."""
+
+    def __init__(self, n_batches, batch, n_users, n_items, device):
+        lib = _lib.load()
+        kb, ktot, vtot, tmp = (C.c_int64() for _ in range(4))
+        check(lib.trs_epoch_presort_sizes(n_batches, batch, n_items, C.byref(kb), C.byref(ktot), C.byref(vtot),
+                                          C.byref(tmp)), "trs_epoch_presort_sizes")
+        self.n_batches, self.batch, self.n_users, self.n_items = n_batches, batch, n_users, n_items
+        self.key_bytes = kb.value
+        n_pos = n_batches * batch
+        self.ids = [torch.empty(n_pos, dtype=torch.int32, device=device) for _ in range(3)]
+        self.keys = torch.empty(ktot.value, dtype=torch.uint8, device=device)
+        self.vals = torch.empty(vtot.value, dtype=torch.uint8, device=device)
+        self.temp = torch.empty(tmp.value, dtype=torch.uint8, device=device)
+        self.temp_bytes = tmp.value
+        self.sorted_keys = self.sorted_vals = None
+
+    @staticmethod
+    def bytes_needed(n_batches, batch, n_items):
+        lib = _lib.load()
+        kb, ktot, vtot, tmp = (C.c_int64() for _ in range(4))
+        check(lib.trs_epoch_presort_sizes(n_batches, batch, n_items, C.byref(kb), C.byref(ktot), C.byref(vtot),
+                                          C.byref(tmp)), "trs_epoch_presort_sizes")
+        return 12 * n_batches * batch + ktot.value + vtot.value + tmp.value
+
+    def run(self, stream_ui, neg_static, shuffle_key, sample_seed, first_pos, err_flag, given_ids=None):
+        """Generate (stream_ui given) or adopt (given_ids = (user, pos, neg) int32 tensors) the ids and sort the refs."""
+        if given_ids is not None:
+            for dst, src in zip(self.ids, given_ids):
+                dst.copy_(src[: dst.numel()])
+        sk, sv = C.c_void_p(), C.c_void_p()
+        N = 0 if stream_ui is None else stream_ui.shape[0]
+        check(_lib.load().trs_epoch_presort(ptr(stream_ui), ptr(neg_static), N, int(shuffle_key), int(sample_seed),
+                                            int(first_pos), self.n_batches, self.batch, self.n_users, self.n_items,
+                                            ptr(self.ids[0]), ptr(self.ids[1]), ptr(self.ids[2]), ptr(self.keys),
+                                            ptr(self.vals), ptr(self.temp), self.temp_bytes, ptr(err_flag),
+                                            C.byref(sk), C.byref(sv), _stream()), "trs_epoch_presort")
+        self.sorted_keys, self.sorted_vals = sk.value, sv.value
+
+    def step_args(self, b):
+        """(user, pos, neg id views, sorted keys address, sorted vals address) for the steps starting at batch b."""
+        o = b * self.batch
+        return ([t[o:] for t in self.ids], self.sorted_keys + 2 * o * self.key_bytes, self.sorted_vals + 2 * o * 8)
+
+
 def train_steps_sgd(net, T, stream_ui, neg_static, shuffle_key, sample_seed, first_pos, batch, n_steps,
                     lr, user_buf, pos_buf, neg_buf, gz_buf, du_buf, loss_sums, err_flag, scratch=None, first_stamp=1,
-                    events=None):
+                    events=None, sorted_keys=None, sorted_vals=None, key_bytes=0):
     """n_steps fused SGD steps driven from C (trs_train_steps_sgd).  stream_ui None: the steps' ids are already in
     user/pos/neg_buf.  events: optional flat list of 4*n_steps torch.cuda.Event (already created by a record())."""
     ev = None
@@ -160,7 +207,8 @@ def train_steps_sgd(net, T, stream_ui, neg_static, shuffle_key, sample_seed, fir
                                           N, int(shuffle_key), int(sample_seed), int(first_pos), int(batch),
                                           int(n_steps), float(lr), ptr(user_buf), ptr(pos_buf), ptr(neg_buf),
                                           ptr(gz_buf), ptr(du_buf), ptr(loss_sums), ptr(err_flag), ptr(scratch),
-                                          int(first_stamp), ev, _stream()), "trs_train_steps_sgd")
+                                          int(first_stamp), sorted_keys, sorted_vals, int(key_bytes), ev, _stream()),
+          "trs_train_steps_sgd")
 
 
 def rows_scatter_add(table, idx, vals, alpha, ld=None, err_flag=None):
