@@ -160,7 +160,9 @@ int trs_train_steps_sgd(int net, const trs_tables* tables, const int32_t* stream
                         float lr, int32_t* user_buf_dev, int32_t* pos_buf_dev, int32_t* neg_buf_dev,
                         float* gz_buf_dev, float* du_buf_dev, float* loss_sums_dev, int32_t* err_flag_dev,
                         void* scratch_dev, uint32_t first_stamp, const void* sorted_keys_dev,
-                        const void* sorted_vals_dev, int32_t key_bytes, void** events, void* stream);
+                        const void* sorted_vals_dev, int32_t key_bytes, const uint8_t* user_dup_flags_dev,
+                        float* ustage_buf_dev, const void* sorted_ukeys_dev, const void* sorted_uvals_dev,
+                        int32_t ukey_bytes, int64_t slice_pos0, void** events, void* stream);
 
 /* Epoch-level grouping of the item references by row (dense regime: most item rows are referenced several times per
  * step).  trs_epoch_presort covers n_batches whole batches starting at epoch position first_pos: it writes the triples'
@@ -170,6 +172,18 @@ int trs_train_steps_sgd(int net, const trs_tables* tables, const int32_t* stream
  * trs_train_steps_sgd together with the id arrays replaces K2a/K2b by one atomic-free launch: each run of equal keys is
  * summed by one lane group and applied with a plain whole-row read-modify-write (runs are cut every 64 references; cut
  * pieces of hot rows use float atomics).  Buffers: keys/vals two halves each (sizes from trs_epoch_presort_sizes). */
+/* Per-position flags of an epoch slice: 1 iff the triple's user is referenced by another triple of the same batch
+ * (sort of (batch, user) pairs).  Passing them (offset to the first batch) with a (batch,D) staging buffer to
+ * trs_train_steps_sgd in presorted mode lets K1 apply the user update itself for users referenced once in the batch
+ * (plain store; K1 then stages the OLD user row for the item update instead of the gradient) — K3 shrinks to the
+ * duplicated users: with the slice's sorted (batch,user) pairs (offset to the call's first batch; slice_pos0 = that
+ * batch's first position in the slice) each run of equal users is summed by one lane group and applied with one plain
+ * read-modify-write.  The step then contains no float atomic except for cut runs of hot item rows. */
+int trs_epoch_user_dups_sizes(int64_t n_batches, int64_t batch, int64_t n_users, int64_t* ukeys_bytes_out,
+                              int64_t* uvals_bytes_out, int64_t* temp_bytes_out);
+int trs_epoch_user_dups(const int32_t* user_dev, int64_t n_batches, int64_t batch, int64_t n_users, void* ukeys_dev,
+                        void* uvals_dev, void* temp_dev, int64_t temp_bytes, uint8_t* flags_out_dev,
+                        void** sorted_ukeys_out, void** sorted_uvals_out, int32_t* ukey_bytes_out, void* stream);
 int trs_epoch_presort_sizes(int64_t n_batches, int64_t batch, int64_t n_items, int64_t* key_bytes_out,
                             int64_t* keys_total_bytes_out, int64_t* vals_total_bytes_out, int64_t* temp_bytes_out);
 int trs_epoch_presort(const int32_t* stream_ui_dev, const int32_t* neg_static_dev, int64_t N, uint64_t shuffle_key,

@@ -508,7 +508,8 @@ def test_gemm_fused_bn_statistics(B, passes, K, H, bf16):
 
 @pytest.mark.parametrize("net,D,skew", [("fm", 64, False), ("fm", 64, True), ("fm", 16, True), ("linear", 32, True),
                                         ("fm", 80, False), ("fm", 10, True)])
-def test_presorted_item_update_matches_oracle(net, D, skew):
+@pytest.mark.parametrize("inline_user", [False, True])
+def test_presorted_item_update_matches_oracle(net, D, skew, inline_user):
     """trs_epoch_presort + the atomic-free per-run item update: 3 batches in one C call == oracle SGD steps.
     `skew`: one hot item takes 40 % of the references (runs cut at 64, pieces added atomically)."""
     ops = _ops()
@@ -528,11 +529,21 @@ def test_presorted_item_update_matches_oracle(net, D, skew):
     ps = ops.EpochPresort(nb, B, NU, NI, DEV)
     given = [torch.from_numpy(a.astype(np.int32)).to(DEV) for a in (u, i, j)]
     ps.run(None, None, 0, 0, 0, err, given_ids=given)
-    ids, sk, sv = ps.step_args(0)
+    ids, sk, sv, udup, usorted = ps.step_args(0)
     gz, du = torch.empty((2, B), device=DEV), torch.empty((B, D), device=DEV)
     losses = torch.zeros(nb, device=DEV)
-    ops.train_steps_sgd(net, T, None, None, 0, 0, 0, B, nb, lr, *ids, gz, du, losses, err,
-                        ops.train_scratch(NU, NI, B, D, DEV), 1, None, sk, sv, ps.key_bytes)
+    # user-duplicate flags of the slice == "another triple of the same batch has this user"
+    for b in range(nb):
+        ub = u[b * B:(b + 1) * B]
+        cnt = np.bincount(ub, minlength=NU)
+        assert np.array_equal(udup[b * B:(b + 1) * B].cpu().numpy(), (cnt[ub] > 1).astype(np.uint8))
+    if inline_user:
+        ops.train_steps_sgd(net, T, None, None, 0, 0, 0, B, nb, lr, *ids, gz, du, losses, err,
+                            ops.train_scratch(NU, NI, B, D, DEV), 1, None, sk, sv, ps.key_bytes, udup,
+                            torch.empty((B, D), device=DEV), usorted)
+    else:
+        ops.train_steps_sgd(net, T, None, None, 0, 0, 0, B, nb, lr, *ids, gz, du, losses, err,
+                            ops.train_scratch(NU, NI, B, D, DEV), 1, None, sk, sv, ps.key_bytes)
     torch.cuda.synchronize()
     ref = {k: v.copy() for k, v in p.items()}
     for b in range(nb):

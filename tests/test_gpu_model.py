@@ -270,6 +270,27 @@ def test_g4_end_to_end_fit_evaluate_predict(net_type, dyn):
 
 
 @pytest.mark.parametrize("net_type", SPARSE_NETS)
+@pytest.mark.parametrize("rng", ["reference", "device"])
+def test_presort_slices_prefetched_on_the_side_stream(net_type, rng, monkeypatch):
+    """Several presort slices per epoch (double-buffered, the next one sorted on a side stream while the current one's
+    steps run, short tail slice): same weights as with one slice per epoch."""
+    from torchrecsys_amd.engine import SparseScorerTrainer
+    g = load_golden(f"g4_{net_type}_dyn.npz")
+    kw = dict(rng="device", seed=5) if rng == "device" else {}
+    monkeypatch.setattr(SparseScorerTrainer, "SLICE_BATCHES", 4)
+    model, _, sliced, _, txt_s = run_model(net_type, True, g, **kw)
+    monkeypatch.setattr(SparseScorerTrainer, "SLICE_BATCHES", 256)
+    _, _, whole, _, txt_w = run_model(net_type, True, g, **kw)
+    ls, lw = ([float(x) for x in re.findall(r"Training Loss: ([0-9.]+)", t)] for t in (txt_s, txt_w))
+    assert len(ls) == 2 and ls == pytest.approx(lw, abs=1.01e-4)
+    for k, v in whole.items():
+        assert rel_err(sliced[k], v) < 1e-6, k  # cut hot-row runs use atomics: order-dependent rounding only
+    if rng == "reference":
+        for k, v in sub(g, "final").items():
+            assert rel_err(sliced[k], v) < 2e-5, k
+
+
+@pytest.mark.parametrize("net_type", SPARSE_NETS)
 def test_device_rng_mode_trains(net_type):
     """rng='device': on-GPU shuffle + sampler; not the reference's stream, but it must learn the same problem."""
     g = load_golden(f"g4_{net_type}_dyn.npz")

@@ -75,7 +75,11 @@ PROTOTYPES = {
     "trs_rows_apply_adagrad": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _i64, _i32, _f, _f, _vp]),
     "trs_train_scratch_bytes": (C.c_int64, [_i64, _i64, _i64, _i32]),
     "trs_train_steps_sgd": (C.c_int, [C.c_int, _T, _vp, _vp, _i64, _u64, _u64, _i64, _i64, _i32, _f, _vp, _vp, _vp,
-                                      _vp, _vp, _vp, _vp, _vp, C.c_uint32, _vp, _vp, _i32, _vp, _vp]),
+                                      _vp, _vp, _vp, _vp, _vp, C.c_uint32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32,
+                                      _i64, _vp, _vp]),
+    "trs_epoch_user_dups_sizes": (C.c_int, [_i64, _i64, _i64, c_int64_p, c_int64_p, c_int64_p]),
+    "trs_epoch_user_dups": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, C.POINTER(C.c_void_p),
+                                      C.POINTER(C.c_void_p), c_int32_p, _vp]),
     "trs_epoch_presort_sizes": (C.c_int, [_i64, _i64, _i64, c_int64_p, c_int64_p, c_int64_p, c_int64_p]),
     "trs_epoch_presort": (C.c_int, [_vp, _vp, _i64, _u64, _u64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _i64, _vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp]),

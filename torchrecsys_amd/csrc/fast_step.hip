@@ -54,17 +54,22 @@ struct FastArgs {
   uint32_t* udup;  // (n_users) == stamp: the row has more than one reference in this step
   uint32_t* idup;  // (n_items)
   uint32_t stamp;
+  // presorted mode with precomputed per-position user-duplicate flags (trs_epoch_presort): K1 applies the user update
+  // itself for users referenced once in the batch and stages the OLD user row for K2 instead of the gradient
+  const uint8_t* udup_pos;  // (B) 1: this triple's user has another reference in the batch; NULL: mode off
+  float* ustage;            // (B,D) pre-update user rows, read by the sorted item update
 };
 
 struct RawIds {   // loads issued, nothing consumed yet
   int32_t u, p, n;
+  uint8_t dup;
   int64_t v;      // SRC 1: uniform draw over n_items-1 values (the negative is v + (v >= pos))
   bool valid;
 };
 
 struct TripleIds {
   int32_t u, p, n;
-  bool valid, ok;
+  bool valid, ok, dup;
 };
 
 // SRC: 0 = ids given in user/pos/neg; 1 = resident stream + dynamic sampler; 2 = resident stream + static negatives.
@@ -72,7 +77,7 @@ struct TripleIds {
 // which would also drain the row gathers in flight.  issue_ids only ISSUES the loads (and does the id-independent
 // Philox arithmetic); finalize_ids consumes them one iteration later, so the wait it implies covers loads that are
 // older than every row gather still in flight (vmcnt is in-order).
-template <int SRC>
+template <int SRC, bool INL>
 __device__ __forceinline__ RawIds issue_ids(const FastArgs& a, int64_t t) {
   RawIds r;
   r.valid = t < a.B;
@@ -96,6 +101,8 @@ __device__ __forceinline__ RawIds issue_ids(const FastArgs& a, int64_t t) {
     r.p = a.pos[tc];
     r.n = a.neg[tc];
   }
+  r.dup = 1;
+  if (INL) r.dup = a.udup_pos[tc];
   return r;
 }
 
@@ -112,6 +119,7 @@ __device__ __forceinline__ TripleIds finalize_ids(const FastArgs& a, const RawId
   r.u = (int32_t)uid;
   r.p = (int32_t)pid;
   r.n = (int32_t)nid;
+  r.dup = w.dup != 0;
   return r;
 }
 
@@ -131,7 +139,10 @@ __device__ __forceinline__ void load_rows(TripleRows<VEC, K>& r, const trs_table
   r.nl = T.item_lin[id.n];
 }
 
-template <int NET, int VEC, int G, int K, int SRC, bool FULL>
+// INL (presorted mode with user-duplicate flags): the user update of a triple whose user is referenced once in the
+// batch is applied right here (the row is in registers and nobody else reads it this step); the OLD user row is staged
+// for K2 instead of the gradient; only duplicated users stage their gradient for the small atomic pass K3'.
+template <int NET, int VEC, int G, int K, int SRC, bool FULL, bool INL>
 __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) {
   constexpr int N = K * VEC;
   constexpr int TPW = TRS_WAVE / G;
@@ -193,7 +204,20 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
       RowReg<VEC, K> g;
 #pragma unroll
       for (int n = 0; n < N; ++n) g.v[n] = gp * r.pi.v[n] + gn * r.ni.v[n];
-      row_store<VEC, G, K>(g, a.du + tt * (int64_t)D, D, lig);
+      if (INL) {
+        row_store<VEC, G, K>(r.u, a.ustage + tt * (int64_t)D, D, lig);
+        if (id.dup || !live) {
+          row_store<VEC, G, K>(g, a.du + tt * (int64_t)D, D, lig);
+        } else {
+          RowReg<VEC, K> un;
+#pragma unroll
+          for (int n = 0; n < N; ++n) un.v[n] = r.u.v[n] + (-a.lr) * g.v[n];
+          row_store<VEC, G, K>(un, T.user + id.u * (int64_t)D, D, lig);
+          if (lig == 0) T.user_lin[id.u] = r.ul + (-a.lr) * (gp + gn);
+        }
+      } else {
+        row_store<VEC, G, K>(g, a.du + tt * (int64_t)D, D, lig);
+      }
       if (lig == 0) {
         a.gz[tt] = gp;
         a.gz[B + tt] = gn;
@@ -202,7 +226,7 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
           a.pos[tt] = id.p;
           a.neg[tt] = id.n;
         }
-        if (live && a.uown) {
+        if (!INL && live && a.uown) {
           const uint64_t hi = (uint64_t)a.stamp << 32;
           a.uown[id.u] = hi | (uint64_t)(uint32_t)tt;
           if (a.iown) {  // wave-uniform; not needed when the item references were presorted (presort.hip)
@@ -219,19 +243,19 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
   // phase the ids of k+2 are issued, the ids of k+1 consumed and its rows issued, then triple k is reduced.  Program
   // order = issue order, so each wait covers only loads older than everything that should stay in flight.
   const int64_t niter2 = (niter + 1) & ~(int64_t)1;  // even trip count: surplus phases run on clamped, invalid triples
-  RawIds wE = issue_ids<SRC>(a, t);
-  RawIds wO = issue_ids<SRC>(a, t + stride);
+  RawIds wE = issue_ids<SRC, INL>(a, t);
+  RawIds wO = issue_ids<SRC, INL>(a, t + stride);
   TripleIds idE = finalize_ids<SRC>(a, wE);
   TripleIds idO;
   TripleRows<VEC, K> rE, rO;
   load_rows<VEC, G, K, FULL>(rE, T, idE, lig);
   for (int64_t it = 0; it < niter2; it += 2) {
-    wE = issue_ids<SRC>(a, t + 2 * stride);
+    wE = issue_ids<SRC, INL>(a, t + 2 * stride);
     idO = finalize_ids<SRC>(a, wO);
     load_rows<VEC, G, K, FULL>(rO, T, idO, lig);
     reduce(rE, idE, t);
 
-    wO = issue_ids<SRC>(a, t + 3 * stride);
+    wO = issue_ids<SRC, INL>(a, t + 3 * stride);
     idE = finalize_ids<SRC>(a, wE);
     load_rows<VEC, G, K, FULL>(rE, T, idE, lig);
     reduce(rO, idO, t + stride);
@@ -392,6 +416,40 @@ __global__ __launch_bounds__(TRS_BLOCK) void user_plain_update_kernel(const Fast
         if (lig == 0) atomicAdd(T.user_lin + id[k].u, c[k]);
       }
     }
+  }
+}
+
+// K3' (presorted mode with user-duplicate flags): only triples whose user has other references in the batch still owe
+// their user update; they add their staged gradient with float atomics (c2: 6 % of the triples).
+template <int VEC, int G, int K, bool FULL>
+__global__ __launch_bounds__(TRS_BLOCK) void user_dup_update_kernel(const FastArgs a) {
+  constexpr int TPW = TRS_WAVE / G;
+  const trs_tables& T = a.T;
+  const int D = T.D;
+  const int64_t B = a.B;
+  const int lane = threadIdx.x & 63;
+  const int lig = lane % G;
+  const int64_t wave = ((int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x) >> 6;
+  const int64_t nwave = ((int64_t)gridDim.x * TRS_BLOCK) >> 6;
+  const int64_t niter = (B + TPW - 1) / TPW;
+  for (int64_t it = wave; it < niter; it += nwave) {
+    const int64_t t = it * TPW + lane / G;
+    const UpdIds id = upd_ids(a, t);
+    const int64_t tc = id.live ? t : 0;
+    const bool dup = id.live && a.udup_pos[tc] != 0;
+    const float c = -a.lr * (a.gz[tc] + a.gz[B + tc]);
+    RowReg<VEC, K> g;
+    row_load<VEC, G, K, FULL>(g, a.du, dup ? tc : 0, D, lig);
+    if (!dup) continue;
+    float* urow = T.user + id.u * (int64_t)D;
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) {
+      const int e = (kk * G + lig) * VEC;
+#pragma unroll
+      for (int q = 0; q < VEC; ++q)
+        if (e + q < D) atomicAdd(urow + e + q, -a.lr * g.v[kk * VEC + q]);
+    }
+    if (lig == 0) atomicAdd(T.user_lin + id.u, c);
   }
 }
 
@@ -562,9 +620,10 @@ static int launch_fwd_stage(const FastArgs& a, hipStream_t s) {
 #define TRS_LAUNCH(V, GG, KK, FULL)                                                                             \
   {                                                                                                             \
     const dim3 gr((unsigned)grid), bl(TRS_BLOCK);                                                               \
-    if (src == 0) hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL>), gr, bl, 0, s, a);              \
-    else if (src == 1) hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 1, FULL>), gr, bl, 0, s, a);         \
-    else hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 2, FULL>), gr, bl, 0, s, a);                       \
+    if (src == 0 && a.udup_pos) hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL, true>), gr, bl, 0, s, a); \
+    else if (src == 0) hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL, false>), gr, bl, 0, s, a);  \
+    else if (src == 1) hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 1, FULL, false>), gr, bl, 0, s, a);  \
+    else hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 2, FULL, false>), gr, bl, 0, s, a);                \
   }
 #define TRS_CASE(V, GG, KK)                                                                                     \
   if (c.vec == V && c.g == GG && c.k == KK) {                                                                   \
@@ -590,7 +649,7 @@ static int launch_fwd_stage(const FastArgs& a, hipStream_t s) {
   return TRS_E_ARG;
 }
 
-template <int WHICH>  // 0: item owners (K2a), 1: users (K3)
+template <int WHICH>  // 0: item owners (K2a), 1: users (K3), 2: duplicated users only (K3')
 static int launch_plain(const FastArgs& a, hipStream_t s) {
   RowCfg c;
   if (!pick_row_cfg(a.T.D, c)) {
@@ -602,7 +661,8 @@ static int launch_plain(const FastArgs& a, hipStream_t s) {
 #define TRS_PL(V, GG, KK, FULL)                                                                        \
   {                                                                                                    \
     if (WHICH == 0) hipLaunchKernelGGL((item_owner_update_kernel<V, GG, KK, FULL>), gr, bl, 0, s, a);  \
-    else hipLaunchKernelGGL((user_plain_update_kernel<V, GG, KK, FULL>), gr, bl, 0, s, a);             \
+    else if (WHICH == 1) hipLaunchKernelGGL((user_plain_update_kernel<V, GG, KK, FULL>), gr, bl, 0, s, a); \
+    else hipLaunchKernelGGL((user_dup_update_kernel<V, GG, KK, FULL>), gr, bl, 0, s, a);               \
   }
 #define TRS_CASE(V, GG, KK)                                                                     \
   if (c.vec == V && c.g == GG && c.k == KK) {                                                   \
@@ -669,8 +729,11 @@ using namespace trs;
 // presort.hip
 int trs_launch_sorted_item_update(const trs_tables* tables, const void* keys_step, const void* vals_step, int key_bytes,
                                   int64_t batch, int64_t item_bits, const float* gz, float lr, uint64_t* uown,
-                                  uint32_t* udup, uint32_t stamp, hipStream_t s);
+                                  uint32_t* udup, uint32_t stamp, const float* ustage, hipStream_t s);
 int trs_item_bits_for(int64_t n_items);
+int trs_launch_sorted_user_dup_update(const trs_tables* tables, const void* ukeys_step, const void* uvals_step,
+                                      int key_bytes, int64_t batch, int64_t q0, const float* du, const float* gz,
+                                      float lr, hipStream_t s);
 
 extern "C" int64_t trs_train_scratch_bytes(int64_t n_users, int64_t n_items, int64_t batch, int32_t D) {
   if (n_users <= 0 || n_items <= 0 || batch <= 0 || D <= 0) return 0;
@@ -684,7 +747,9 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
                                    int32_t* neg_buf_dev, float* gz_buf_dev, float* du_buf_dev, float* loss_sums_dev,
                                    int32_t* err_flag_dev, void* scratch_dev, uint32_t first_stamp,
                                    const void* sorted_keys_dev, const void* sorted_vals_dev, int32_t key_bytes,
-                                   void** events, void* stream) {
+                                   const uint8_t* user_dup_flags_dev, float* ustage_buf_dev,
+                                   const void* sorted_ukeys_dev, const void* sorted_uvals_dev, int32_t ukey_bytes,
+                                   int64_t slice_pos0, void** events, void* stream) {
   TRS_REQUIRE(net == TRS_NET_LINEAR || net == TRS_NET_FM, "trs_train_steps_sgd: bad net");
   TRS_REQUIRE(tables && tables->M == 0, "trs_train_steps_sgd: only scorers without metadata (M == 0)");
   TRS_REQUIRE(tables->user && tables->item && tables->user_lin && tables->item_lin, "trs_train_steps_sgd: NULL table");
@@ -695,9 +760,12 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
               "trs_train_steps_sgd: stamps must be non-zero and must not wrap (zero the scratch and restart at 1)");
   const bool from_stream = stream_ui_dev != nullptr;
   const bool sorted = sorted_keys_dev != nullptr;
+  const bool inl = sorted && user_dup_flags_dev != nullptr;
   if (sorted) {
     TRS_REQUIRE(!from_stream && scratch_dev && sorted_vals_dev && (key_bytes == 4 || key_bytes == 8),
                 "trs_train_steps_sgd: the presorted mode needs the epoch's id arrays, scratch and sorted references");
+    TRS_REQUIRE(!inl || (ustage_buf_dev && sorted_ukeys_dev && sorted_uvals_dev && (ukey_bytes == 4 || ukey_bytes == 8)),
+                "trs_train_steps_sgd: user-duplicate flags need the staging buffer and the slice's sorted (batch,user) pairs");
   }
   if (from_stream) {
     TRS_REQUIRE(N > 0 && first_pos >= 0 && first_pos + (int64_t)n_steps * batch <= N,
@@ -735,6 +803,10 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
   for (int32_t st = 0; st < n_steps; ++st) {
     a.t0 = first_pos + (int64_t)st * batch;
     a.sample_offset = (uint64_t)a.t0;
+    if (inl) {
+      a.udup_pos = user_dup_flags_dev + (int64_t)st * batch;
+      a.ustage = ustage_buf_dev;
+    }
     if (!from_stream) {  // step st reads its ids at [st*batch, (st+1)*batch) of the given arrays
       a.user = user_buf_dev + (int64_t)st * batch;
       a.pos = pos_buf_dev + (int64_t)st * batch;
@@ -751,11 +823,18 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
     if (sorted) {  // K2: per-run owner update from the presorted references, then K3
       const char* ks = (const char*)sorted_keys_dev + (int64_t)st * 2 * batch * key_bytes;
       const char* vs = (const char*)sorted_vals_dev + (int64_t)st * 2 * batch * 8;
-      rc = trs_launch_sorted_item_update(tables, ks, vs, key_bytes, batch, item_bits, a.gz, a.lr, a.uown, a.udup,
-                                         a.stamp, s);
+      rc = trs_launch_sorted_item_update(tables, ks, vs, key_bytes, batch, item_bits, a.gz, a.lr,
+                                         inl ? nullptr : a.uown, a.udup, a.stamp, inl ? a.ustage : nullptr, s);
       if (rc) return rc;
       if (ev) (void)hipEventRecord(ev[2], s);
-      rc = launch_plain<1>(a, s);
+      if (inl) {
+        const char* uk = (const char*)sorted_ukeys_dev + (int64_t)st * batch * ukey_bytes;
+        const char* uv = (const char*)sorted_uvals_dev + (int64_t)st * batch * 4;
+        rc = trs_launch_sorted_user_dup_update(tables, uk, uv, ukey_bytes, batch, slice_pos0 + (int64_t)st * batch,
+                                               a.du, a.gz, a.lr, s);
+      } else {
+        rc = launch_plain<1>(a, s);
+      }
     } else {
       rc = launch_updates(a, s, ev ? ev[2] : nullptr);
     }

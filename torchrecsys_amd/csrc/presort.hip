@@ -92,14 +92,17 @@ struct SortedArgs {
   int item_bits;
   const float* gz;          // (2,B)
   float lr;
-  uint64_t* uown;
+  uint64_t* uown;       // NULL: the user-duplicate stamps are not needed (flags were precomputed)
   uint32_t* udup;
   uint32_t stamp;
+  const float* ustage;  // (B,D) pre-update user rows staged by K1 (indexed by t), or NULL: read the user table
 };
 
 constexpr int RUN_CHUNK = 64;  // runs are cut at multiples of this many references
 
-template <typename KeyT, int VEC, int G, int K, bool FULL>
+// STAGED: user rows come from K1's staging buffer (row t of the batch; K1 has already updated the table rows of users
+// referenced once) and no duplicate stamping is needed.
+template <typename KeyT, int VEC, int G, int K, bool FULL, bool STAGED>
 __global__ __launch_bounds__(TRS_BLOCK) void sorted_item_update_kernel(const SortedArgs a) {
   constexpr int N = K * VEC;
   constexpr int TPW = TRS_WAVE / G;
@@ -125,15 +128,18 @@ __global__ __launch_bounds__(TRS_BLOCK) void sorted_item_update_kernel(const Sor
     const RefPayload me = a.vals[ic];
     const bool head = ic == 0 || prev != key;
     const bool leader = valid && (head || (ic % RUN_CHUNK) == 0);
-    const uint64_t own = a.uown[me.user];
+    uint64_t own = 0;
+    if (!STAGED) own = a.uown[me.user];
+    const float* ubase = STAGED ? a.ustage : T.user;
     const float c0 = -a.lr * a.gz[(int64_t)(me.tw & 1u) * a.B + (me.tw >> 1)];
     const int64_t row = (int64_t)(key & row_mask);
     RowReg<VEC, K> u0, w;
-    row_load<VEC, G, K, FULL>(u0, T.user, leader ? me.user : 0, D, lig);
+    row_load<VEC, G, K, FULL>(u0, ubase, leader ? (STAGED ? (int64_t)(me.tw >> 1) : (int64_t)me.user) : 0, D, lig);
     row_load<VEC, G, K, FULL>(w, T.item, leader ? row : 0, D, lig);
     const float wl = T.item_lin[leader ? row : 0];
     // the positive reference of a triple also checks whether its user row has other references in this step (K3)
-    if (valid && (me.tw & 1u) == 0 && lig == 0 && own != (hi | (uint64_t)(me.tw >> 1))) a.udup[me.user] = a.stamp;
+    if (!STAGED && valid && (me.tw & 1u) == 0 && lig == 0 && own != (hi | (uint64_t)(me.tw >> 1)))
+      a.udup[me.user] = a.stamp;
     if (!leader) continue;
     const int64_t chunk_end = (ic / RUN_CHUNK + 1) * RUN_CHUNK < n ? (ic / RUN_CHUNK + 1) * RUN_CHUNK : n;
     RowReg<VEC, K> acc;
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(TRS_BLOCK) void sorted_item_update_kernel(const Sor
       const RefPayload pl = a.vals[j];
       const float c = -a.lr * a.gz[(int64_t)(pl.tw & 1u) * a.B + (pl.tw >> 1)];
       RowReg<VEC, K> u;
-      row_load<VEC, G, K, FULL>(u, T.user, pl.user, D, lig);
+      row_load<VEC, G, K, FULL>(u, ubase, STAGED ? (int64_t)(pl.tw >> 1) : (int64_t)pl.user, D, lig);
 #pragma unroll
       for (int q = 0; q < N; ++q) acc.v[q] += c * u.v[q];
       lin += c;
@@ -168,6 +174,132 @@ __global__ __launch_bounds__(TRS_BLOCK) void sorted_item_update_kernel(const Sor
           if (e + q < D) atomicAdd(irow + e + q, acc.v[kk * VEC + q]);
       }
       if (lig == 0) atomicAdd(T.item_lin + row, lin);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- user duplicates
+// flags[q] = 1 iff the user of position q is referenced by another triple of the same batch (static for the epoch):
+// sort (batch * 2^user_bits + user, q) and compare neighbours.
+template <typename KeyT>
+__global__ __launch_bounds__(TRS_BLOCK) void user_keys_kernel(const int32_t* __restrict__ user, int64_t n_pos,
+                                                             int64_t batch, int user_bits, KeyT* __restrict__ keys,
+                                                             uint32_t* __restrict__ vals) {
+  const int64_t stride = (int64_t)gridDim.x * TRS_BLOCK;
+  for (int64_t q = (int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x; q < n_pos; q += stride) {
+    keys[q] = (KeyT)(((uint64_t)(q / batch) << user_bits) | (uint64_t)(uint32_t)user[q]);
+    vals[q] = (uint32_t)q;
+  }
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(TRS_BLOCK) void user_flags_kernel(const KeyT* __restrict__ keys,
+                                                              const uint32_t* __restrict__ vals, int64_t n_pos,
+                                                              uint8_t* __restrict__ flags) {
+  const int64_t stride = (int64_t)gridDim.x * TRS_BLOCK;
+  for (int64_t s = (int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x; s < n_pos; s += stride) {
+    const KeyT k = keys[s];
+    const bool dup = (s > 0 && keys[s - 1] == k) || (s + 1 < n_pos && keys[s + 1] == k);
+    flags[vals[s]] = dup ? 1 : 0;
+  }
+}
+
+// K3'' : user rows referenced by several triples of the batch.  The slice's (batch, user) sort puts them next to each
+// other: the first entry of a run of length > 1 sums the staged gradients of the run's triples and applies them with ONE
+// plain read-modify-write (K1 already updated every user referenced once).  No atomics: the step is reproducible.
+struct UserDupArgs {
+  trs_tables T;
+  const void* ukeys;      // this step's B sorted (batch, user) keys
+  const uint32_t* uvals;  // this step's B sorted positions (slice-relative q)
+  int64_t B;
+  int64_t q0;             // slice-relative position of the step's first triple
+  int user_bits;
+  const float* du;        // (B,D) staged user-row gradients (written by K1 for duplicated users)
+  const float* gz;        // (2,B)
+  float lr;
+};
+
+template <typename KeyT, int VEC, int G, int K, bool FULL>
+__global__ __launch_bounds__(TRS_BLOCK) void sorted_user_dup_update_kernel(const UserDupArgs a) {
+  constexpr int N = K * VEC;
+  constexpr int TPW = TRS_WAVE / G;
+  const trs_tables& T = a.T;
+  const int D = T.D;
+  const int64_t n = a.B;
+  const KeyT* keys = reinterpret_cast<const KeyT*>(a.ukeys);
+  const KeyT user_mask = (KeyT)(((uint64_t)1 << a.user_bits) - 1);
+  const int lane = threadIdx.x & 63;
+  const int lig = lane % G;
+  const int64_t wave = ((int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x) >> 6;
+  const int64_t nwave = ((int64_t)gridDim.x * TRS_BLOCK) >> 6;
+  const int gi = lane / G;
+  // detection: one lane per sorted entry (64 entries per wave), keys and positions in one round of loads; the few run
+  // leaders are then spread over the wave's TPW lane groups, which fetch the run's staged gradients and the user row
+  // in a second round (positions come from the detection lanes by shuffle, so nothing is loaded under a branch).
+  const int64_t niter = (n + TRS_WAVE - 1) / TRS_WAVE;
+  for (int64_t it = wave; it < niter; it += nwave) {
+    const int64_t i = it * TRS_WAVE + lane;
+    const bool valid = i < n;
+    const int64_t il = valid ? i : n - 1;
+    const KeyT k0 = keys[il];
+    const KeyT kp = keys[il > 0 ? il - 1 : 0];
+    const KeyT kn = keys[il + 1 < n ? il + 1 : il];
+    const int uv = (int)((int64_t)a.uvals[il] - a.q0);
+    const bool cont = valid && il > 0 && kp == k0;
+    const bool lead = valid && !cont && (il + 1 < n && kn == k0);
+    const uint64_t lmask = __ballot(lead);
+    const uint64_t cmask = __ballot(cont);
+    const int nlead = __popcll(lmask);
+    for (int r = 0; r * TPW < nlead; ++r) {
+      const int want = r * TPW + gi;
+      uint64_t m = lmask;
+      for (int q = 0; q < want && m; ++q) m &= m - 1;
+      const bool has = m != 0;
+      const int l = has ? __ffsll((unsigned long long)m) - 1 : 0;
+      // members of the run inside this wave: lane l and the cont lanes right after it
+      const uint64_t after = l < 63 ? (cmask >> (l + 1)) : 0ull;
+      const int in_wave = has ? 1 + (int)__ffsll((unsigned long long)~after) - 1 : 0;  // ~after != 0: shifted in zeros
+      int most = in_wave;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const int other = __shfl_xor(most, o, 64);
+        most = other > most ? other : most;
+      }
+      const int64_t key_lo = __shfl((int)(uint32_t)(k0 & (KeyT)0xffffffffu), l, 64);
+      const int64_t user = (int64_t)((uint32_t)key_lo) & (int64_t)user_mask;
+      RowReg<VEC, K> w, acc;
+      row_load<VEC, G, K, FULL>(w, T.user, user, D, lig);
+      const float wl = T.user_lin[user];
+#pragma unroll
+      for (int q = 0; q < N; ++q) acc.v[q] = 0.f;
+      float lin = 0.f;
+      for (int j = 0; j < most; ++j) {
+        const int src = l + j < 64 ? l + j : 63;
+        const int t = __shfl(uv, src, 64);
+        // bit mask, not a multiply: rows of du outside duplicate runs are never written and may hold anything
+        const uint32_t on = (has && j < in_wave) ? 0xffffffffu : 0u;
+        RowReg<VEC, K> g;
+        row_load<VEC, G, K, FULL>(g, a.du, (int64_t)t, D, lig);
+#pragma unroll
+        for (int q = 0; q < N; ++q) acc.v[q] += __uint_as_float(__float_as_uint(g.v[q]) & on);
+        lin += __uint_as_float(__float_as_uint(a.gz[t] + a.gz[a.B + t]) & on);
+      }
+      if (!has) continue;
+      if (l + in_wave == TRS_WAVE) {  // rare: the run goes on in the next 64 entries
+        const KeyT key = keys[it * TRS_WAVE + l];
+        for (int64_t j = (it + 1) * TRS_WAVE; j < n && keys[j] == key; ++j) {
+          const int64_t t = (int64_t)a.uvals[j] - a.q0;
+          RowReg<VEC, K> g;
+          row_load<VEC, G, K, FULL>(g, a.du, t, D, lig);
+#pragma unroll
+          for (int q = 0; q < N; ++q) acc.v[q] += g.v[q];
+          lin += a.gz[t] + a.gz[a.B + t];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < N; ++q) w.v[q] += (-a.lr) * acc.v[q];
+      row_store<VEC, G, K>(w, T.user + user * (int64_t)D, D, lig);
+      if (lig == 0) T.user_lin[user] = wl + (-a.lr) * lin;
     }
   }
 }
@@ -280,10 +412,78 @@ extern "C" int trs_epoch_presort(const int32_t* stream_ui_dev, const int32_t* ne
   return TRS_OK;
 }
 
+// User-duplicate flags of an epoch slice (n_pos = n_batches*batch positions; position q < 2^32).  ukeys: 2 x n_pos keys
+// (4 B when bits(n_users)+bits(n_batches) <= 32, else 8 B), uvals: 2 x n_pos uint32, temp: rocprim scratch.
+extern "C" int trs_epoch_user_dups_sizes(int64_t n_batches, int64_t batch, int64_t n_users, int64_t* ukeys_bytes_out,
+                                         int64_t* uvals_bytes_out, int64_t* temp_bytes_out) {
+  TRS_REQUIRE(n_batches > 0 && batch > 0 && n_users > 0 && ukeys_bytes_out && uvals_bytes_out && temp_bytes_out,
+              "trs_epoch_user_dups_sizes: bad arguments");
+  TRS_REQUIRE(n_batches * batch < ((int64_t)1 << 32), "trs_epoch_user_dups_sizes: slice too long");
+  const int bits = bits_for(n_users) + bits_for(n_batches);
+  const int kb = bits <= 32 ? 4 : 8;
+  const size_t n = (size_t)(n_batches * batch);
+  size_t temp = 0;
+  hipError_t e;
+  if (kb == 4)
+    e = rocprim::radix_sort_pairs(nullptr, temp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                  (uint32_t*)nullptr, n, 0u, (unsigned)bits, (hipStream_t)0);
+  else
+    e = rocprim::radix_sort_pairs(nullptr, temp, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
+                                  (uint32_t*)nullptr, n, 0u, (unsigned)bits, (hipStream_t)0);
+  TRS_REQUIRE(e == hipSuccess, "trs_epoch_user_dups_sizes: rocprim size query failed");
+  *ukeys_bytes_out = 2 * (int64_t)n * kb;
+  *uvals_bytes_out = 2 * (int64_t)n * 4;
+  *temp_bytes_out = (int64_t)temp + 256;
+  return TRS_OK;
+}
+
+extern "C" int trs_epoch_user_dups(const int32_t* user_dev, int64_t n_batches, int64_t batch, int64_t n_users,
+                                   void* ukeys_dev, void* uvals_dev, void* temp_dev, int64_t temp_bytes,
+                                   uint8_t* flags_out_dev, void** sorted_ukeys_out, void** sorted_uvals_out,
+                                   int32_t* ukey_bytes_out, void* stream) {
+  TRS_REQUIRE(user_dev && ukeys_dev && uvals_dev && temp_dev && flags_out_dev, "trs_epoch_user_dups: NULL buffer");
+  TRS_REQUIRE(n_batches > 0 && batch > 0 && n_users > 0 && n_batches * batch < ((int64_t)1 << 32),
+              "trs_epoch_user_dups: bad sizes");
+  const int64_t n_pos = n_batches * batch;
+  const int user_bits = bits_for(n_users);
+  const int bits = user_bits + bits_for(n_batches);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 gr(trs_grid(n_pos, TRS_BLOCK)), bl(TRS_BLOCK);
+  size_t temp = (size_t)temp_bytes;
+  uint32_t* vin = (uint32_t*)uvals_dev;
+  hipError_t e;
+  if (bits <= 32) {
+    uint32_t* kin = (uint32_t*)ukeys_dev;
+    hipLaunchKernelGGL((user_keys_kernel<uint32_t>), gr, bl, 0, s, user_dev, n_pos, batch, user_bits, kin, vin);
+    e = rocprim::radix_sort_pairs(temp_dev, temp, kin, kin + n_pos, vin, vin + n_pos, (size_t)n_pos, 0u,
+                                  (unsigned)bits, s);
+    if (e == hipSuccess)
+      hipLaunchKernelGGL((user_flags_kernel<uint32_t>), gr, bl, 0, s, kin + n_pos, vin + n_pos, n_pos, flags_out_dev);
+    if (sorted_ukeys_out) *sorted_ukeys_out = (void*)(kin + n_pos);
+    if (ukey_bytes_out) *ukey_bytes_out = 4;
+  } else {
+    uint64_t* kin = (uint64_t*)ukeys_dev;
+    hipLaunchKernelGGL((user_keys_kernel<uint64_t>), gr, bl, 0, s, user_dev, n_pos, batch, user_bits, kin, vin);
+    e = rocprim::radix_sort_pairs(temp_dev, temp, kin, kin + n_pos, vin, vin + n_pos, (size_t)n_pos, 0u,
+                                  (unsigned)bits, s);
+    if (e == hipSuccess)
+      hipLaunchKernelGGL((user_flags_kernel<uint64_t>), gr, bl, 0, s, kin + n_pos, vin + n_pos, n_pos, flags_out_dev);
+    if (sorted_ukeys_out) *sorted_ukeys_out = (void*)(kin + n_pos);
+    if (ukey_bytes_out) *ukey_bytes_out = 8;
+  }
+  if (sorted_uvals_out) *sorted_uvals_out = (void*)(vin + n_pos);
+  if (e != hipSuccess) {
+    trs_set_error("trs_epoch_user_dups: rocprim::radix_sort_pairs failed: %s", hipGetErrorString(e));
+    return TRS_E_LAUNCH;
+  }
+  TRS_CHECK_LAUNCH("user_keys/flags_kernel");
+  return TRS_OK;
+}
+
 // One launch of the sorted item update for a step (used by trs_train_steps_sgd's sorted mode).
 int trs_launch_sorted_item_update(const trs_tables* tables, const void* keys_step, const void* vals_step, int key_bytes,
                                   int64_t batch, int64_t n_batches_bits_items, const float* gz, float lr,
-                                  uint64_t* uown, uint32_t* udup, uint32_t stamp, hipStream_t s) {
+                                  uint64_t* uown, uint32_t* udup, uint32_t stamp, const float* ustage, hipStream_t s) {
   SortedArgs a = {};
   a.T = *tables;
   a.keys = keys_step;
@@ -295,6 +495,7 @@ int trs_launch_sorted_item_update(const trs_tables* tables, const void* keys_ste
   a.uown = uown;
   a.udup = udup;
   a.stamp = stamp;
+  a.ustage = ustage;
   RowCfg c;
   if (!pick_row_cfg(tables->D, c)) {
     trs_set_error("unsupported n_factors D=%d", tables->D);
@@ -302,10 +503,12 @@ int trs_launch_sorted_item_update(const trs_tables* tables, const void* keys_ste
   }
   const int tpw = TRS_WAVE / c.g;
   const dim3 gr(trs_grid((2 * batch + tpw - 1) / tpw, TRS_BLOCK / TRS_WAVE)), bl(TRS_BLOCK);
-#define TRS_SL(V, GG, KK, FULL)                                                                              \
-  {                                                                                                          \
-    if (key_bytes == 4) hipLaunchKernelGGL((sorted_item_update_kernel<uint32_t, V, GG, KK, FULL>), gr, bl, 0, s, a); \
-    else hipLaunchKernelGGL((sorted_item_update_kernel<uint64_t, V, GG, KK, FULL>), gr, bl, 0, s, a);         \
+#define TRS_SL(V, GG, KK, FULL)                                                                                      \
+  {                                                                                                                  \
+    if (key_bytes == 4 && ustage) hipLaunchKernelGGL((sorted_item_update_kernel<uint32_t, V, GG, KK, FULL, true>), gr, bl, 0, s, a); \
+    else if (key_bytes == 4) hipLaunchKernelGGL((sorted_item_update_kernel<uint32_t, V, GG, KK, FULL, false>), gr, bl, 0, s, a);     \
+    else if (ustage) hipLaunchKernelGGL((sorted_item_update_kernel<uint64_t, V, GG, KK, FULL, true>), gr, bl, 0, s, a);              \
+    else hipLaunchKernelGGL((sorted_item_update_kernel<uint64_t, V, GG, KK, FULL, false>), gr, bl, 0, s, a);                         \
   }
 #define TRS_CASE(V, GG, KK)                                                                  \
   if (c.vec == V && c.g == GG && c.k == KK) {                                                \
@@ -332,3 +535,51 @@ int trs_launch_sorted_item_update(const trs_tables* tables, const void* keys_ste
 }
 
 int trs_item_bits_for(int64_t n_items) { return bits_for(n_items); }
+
+int trs_launch_sorted_user_dup_update(const trs_tables* tables, const void* ukeys_step, const void* uvals_step,
+                                      int key_bytes, int64_t batch, int64_t q0, const float* du, const float* gz,
+                                      float lr, hipStream_t s) {
+  UserDupArgs a = {};
+  a.T = *tables;
+  a.ukeys = ukeys_step;
+  a.uvals = (const uint32_t*)uvals_step;
+  a.B = batch;
+  a.q0 = q0;
+  a.user_bits = bits_for(tables->n_users);
+  a.du = du;
+  a.gz = gz;
+  a.lr = lr;
+  RowCfg c;
+  if (!pick_row_cfg(tables->D, c)) {
+    trs_set_error("unsupported n_factors D=%d", tables->D);
+    return TRS_E_ARG;
+  }
+  const dim3 gr(trs_grid((batch + TRS_WAVE - 1) / TRS_WAVE, TRS_BLOCK / TRS_WAVE)), bl(TRS_BLOCK);
+#define TRS_UL(V, GG, KK, FULL)                                                                                  \
+  {                                                                                                              \
+    if (key_bytes == 4) hipLaunchKernelGGL((sorted_user_dup_update_kernel<uint32_t, V, GG, KK, FULL>), gr, bl, 0, s, a); \
+    else hipLaunchKernelGGL((sorted_user_dup_update_kernel<uint64_t, V, GG, KK, FULL>), gr, bl, 0, s, a);         \
+  }
+#define TRS_CASE(V, GG, KK)                                                                  \
+  if (c.vec == V && c.g == GG && c.k == KK) {                                                \
+    if (V * GG * KK == tables->D) TRS_UL(V, GG, KK, true) else TRS_UL(V, GG, KK, false)      \
+    TRS_CHECK_LAUNCH("sorted_user_dup_update_kernel");                                       \
+    return TRS_OK;                                                                           \
+  }
+  TRS_CASE(4, 2, 1)
+  TRS_CASE(4, 4, 1)
+  TRS_CASE(4, 8, 1)
+  TRS_CASE(4, 16, 1)
+  TRS_CASE(4, 32, 1)
+  TRS_CASE(4, 64, 1)
+  TRS_CASE(4, 64, 2)
+  TRS_CASE(4, 64, 4)
+  TRS_CASE(1, 4, 1)
+  TRS_CASE(1, 16, 1)
+  TRS_CASE(1, 64, 1)
+  TRS_CASE(1, 64, 4)
+#undef TRS_CASE
+#undef TRS_UL
+  trs_set_error("internal: no kernel for D=%d", tables->D);
+  return TRS_E_ARG;
+}

@@ -179,34 +179,79 @@ class SparseScorerTrainer:
         n_items = self.params[1].shape[0]
         if self.fast_lr is None or 2 * batch < 0.25 * n_items:
             return False
-        need = ops.EpochPresort.bytes_needed(self.SLICE_BATCHES, batch, n_items)
-        free, _ = torch.cuda.mem_get_info(self.dev)
-        return need < 0.3 * free
+        memo = self.__dict__.setdefault("_ps_fits", {})
+        if batch not in memo:  # decided once: two buffer sets (one being sorted while the other is read)
+            need = 2 * ops.EpochPresort.bytes_needed(self.SLICE_BATCHES, batch, n_items)
+            free, _ = torch.cuda.mem_get_info(self.dev)
+            memo[batch] = need < 0.3 * free
+        return memo[batch]
 
-    def presort_slice(self, n_batches, batch, st=None, shuffle_key=0, sample_seed=0, first_pos=0, given_ids=None):
-        """Group the item references of the next `n_batches` whole batches (device stream `st`, or host-prepared ids)."""
-        ps = getattr(self, "_presort", None)
+    def _presort_run(self, i, n_batches, batch, st, shuffle_key, sample_seed, first_pos, given_ids):
+        sets = self.__dict__.setdefault("_ps_sets", [None, None])
+        ps = sets[i]
         if ps is None or ps.batch != batch or ps.n_batches < n_batches:
-            ps = self._presort = ops.EpochPresort(max(n_batches, min(self.SLICE_BATCHES, n_batches)), batch,
-                                                  self.params[0].shape[0], self.params[1].shape[0], self.dev)
+            ps = sets[i] = ops.EpochPresort(max(n_batches, min(self.SLICE_BATCHES, n_batches)), batch,
+                                            self.params[0].shape[0], self.params[1].shape[0], self.dev)
         if ps.n_batches != n_batches:  # a shorter tail slice: same buffers, fewer batches
+            full = ps
             ps = ops.EpochPresort.__new__(ops.EpochPresort)
-            ps.__dict__.update(self._presort.__dict__)
+            ps.__dict__.update(full.__dict__)
             ps.n_batches = n_batches
         if st is not None:
-            if "ui" not in st:
-                st["ui"] = ops.interleave_stream(st["user"], st["pos"])
             ps.run(st["ui"], st["neg"], shuffle_key, sample_seed, first_pos, self.err)
         else:
             ps.run(None, None, 0, 0, 0, self.err, given_ids=given_ids)
         return ps
 
+    def presort_slice(self, n_batches, batch, st=None, shuffle_key=0, sample_seed=0, first_pos=0, given_ids=None,
+                      tag=None, prefetch=False):
+        """Group the item references of `n_batches` whole batches (device stream `st`, or host-prepared ids).
+
+        Two buffer sets: with prefetch=True the work is queued on a side HIP stream into the set the step kernels are
+        not reading (the sort is bandwidth work, the step kernels are latency-bound, so the two overlap) and is picked
+        up later by a call with the same `tag`."""
+        if st is not None and "ui" not in st:
+            st["ui"] = ops.interleave_stream(st["user"], st["pos"])
+        tags = self.__dict__.setdefault("_ps_tags", [None, None])
+        done = self.__dict__.setdefault("_ps_done", [None, None])
+        cur = getattr(self, "_ps_cur", 1)
+        main = torch.cuda.current_stream(self.dev)
+        if prefetch:
+            i = 1 - cur
+            if tag is not None and tags[i] == tag:
+                return None
+            if getattr(self, "_ps_stream", None) is None:
+                self._ps_stream = torch.cuda.Stream(self.dev)
+            side = self._ps_stream
+            side.wait_stream(main)  # the steps that read set i were queued before this point
+            with torch.cuda.stream(side):
+                ps = self._presort_run(i, n_batches, batch, st, shuffle_key, sample_seed, first_pos, given_ids)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            tags[i], done[i] = tag, (ps, ev)
+            return None
+        for i in (0, 1):
+            if tag is not None and tags[i] == tag and done[i] is not None:
+                ps, ev = done[i]
+                main.wait_event(ev)
+                self._ps_cur = i
+                return ps
+        i = 1 - cur
+        if getattr(self, "_ps_stream", None) is not None:
+            main.wait_stream(self._ps_stream)  # a prefetch may still be writing set i
+        ps = self._presort_run(i, n_batches, batch, st, shuffle_key, sample_seed, first_pos, given_ids)
+        tags[i], done[i] = tag, None
+        self._ps_cur = i
+        return ps
+
     def fast_sorted_steps(self, ps, b_in_slice, batch, n_steps, loss_sums):
         te, evs, ns = self._make_events(n_steps) if self.kernel_events is not None else (None, None, 0)
-        ids, sk, sv = ps.step_args(b_in_slice)
+        ids, sk, sv, udup, usorted = ps.step_args(b_in_slice)
+        if getattr(self, "ustage", None) is None:
+            self.ustage = torch.empty_like(self.du)  # pre-update user rows staged by K1 for the item update
         ops.train_steps_sgd(self.net.NET, self.net.tables(), None, None, 0, 0, 0, batch, n_steps, self.fast_lr, *ids,
                             self.gz, self.du, loss_sums, self.err, self.scratch, self._stamps(n_steps), evs, sk, sv,
-                            ps.key_bytes)
+                            ps.key_bytes, udup, self.ustage, usorted)
         if te is not None:
             self._collect_events(te, ns)
 

@@ -361,6 +361,7 @@ class FitRunner:
         self.loss_sums.zero_()
         self.next_batch = 0
         self._slice = None
+        self._epoch_no = getattr(self, "_epoch_no", 0) + 1
         if self.num_batches == 0:
             return
         if m.rng == 'reference':
@@ -371,6 +372,17 @@ class FitRunner:
             ge = m._fit_epochs_done
             seed = m.seed + 1000003 * tdist.world_info()[0]  # every rank draws its own negatives
             self.shuffle_key, self.sample_seed = _mix64(seed, 2 * ge + 1), _mix64(seed, 2 * ge + 2)
+
+    def _presort(self, s0, full, prefetch=False):
+        m, B, sl = self.m, self.batch_size, self.trainer.SLICE_BATCHES
+        nb = min(sl, full - s0)
+        tag = (self._epoch_no, s0, nb, B)
+        if m.rng == 'device':
+            return self.trainer.presort_slice(nb, B, self.st, self.shuffle_key, self.sample_seed, s0 * B, tag=tag,
+                                              prefetch=prefetch)
+        return self.trainer.presort_slice(nb, B, given_ids=[self.ep[k_][s0 * B:(s0 + nb) * B]
+                                                            for k_ in ('user', 'pos', 'neg')], tag=tag,
+                                          prefetch=prefetch)
 
     def run_steps(self, k):
         """Run the next k steps of the current epoch (stops at the epoch's end).  Returns the number of steps run."""
@@ -388,13 +400,10 @@ class FitRunner:
                 if presort:  # dense regime: item references grouped by row per slice of batches (csrc/presort.hip)
                     sl = self.trainer.SLICE_BATCHES
                     if self._slice is None or not (self._slice[0] <= b < self._slice[0] + self._slice[1].n_batches):
-                        s0, nb = (b // sl) * sl, min(sl, full - (b // sl) * sl)
-                        if m.rng == 'device':
-                            ps = self.trainer.presort_slice(nb, B, self.st, self.shuffle_key, self.sample_seed, s0 * B)
-                        else:
-                            ps = self.trainer.presort_slice(nb, B, given_ids=[self.ep[k_][s0 * B:(s0 + nb) * B]
-                                                                              for k_ in ('user', 'pos', 'neg')])
-                        self._slice = (s0, ps)
+                        s0 = (b // sl) * sl
+                        self._slice = (s0, self._presort(s0, full))
+                        if s0 + sl < full:  # next slice: sorted on a side stream while this slice's steps run
+                            self._presort(s0 + sl, full, prefetch=True)
                     s0, ps = self._slice
                     n = min(n, s0 + ps.n_batches - b)
                     self.trainer.fast_sorted_steps(ps, b - s0, B, n, self.loss_sums[b:b + n])

@@ -162,8 +162,14 @@ class EpochPresort:
         self.ids = [torch.empty(n_pos, dtype=torch.int32, device=device) for _ in range(3)]
         self.keys = torch.empty(ktot.value, dtype=torch.uint8, device=device)
         self.vals = torch.empty(vtot.value, dtype=torch.uint8, device=device)
-        self.temp = torch.empty(tmp.value, dtype=torch.uint8, device=device)
-        self.temp_bytes = tmp.value
+        uk, uv, ut = (C.c_int64() for _ in range(3))
+        check(lib.trs_epoch_user_dups_sizes(n_batches, batch, n_users, C.byref(uk), C.byref(uv), C.byref(ut)),
+              "trs_epoch_user_dups_sizes")
+        self.ukeys = torch.empty(uk.value, dtype=torch.uint8, device=device)
+        self.uvals = torch.empty(uv.value, dtype=torch.uint8, device=device)
+        self.temp_bytes = max(tmp.value, ut.value)
+        self.temp = torch.empty(self.temp_bytes, dtype=torch.uint8, device=device)
+        self.user_dup = torch.empty(n_pos, dtype=torch.uint8, device=device)  # 1: user has another reference in its batch
         self.sorted_keys = self.sorted_vals = None
 
     @staticmethod
@@ -172,13 +178,14 @@ class EpochPresort:
         kb, ktot, vtot, tmp = (C.c_int64() for _ in range(4))
         check(lib.trs_epoch_presort_sizes(n_batches, batch, n_items, C.byref(kb), C.byref(ktot), C.byref(vtot),
                                           C.byref(tmp)), "trs_epoch_presort_sizes")
-        return 12 * n_batches * batch + ktot.value + vtot.value + tmp.value
+        return 12 * n_batches * batch + ktot.value + vtot.value + tmp.value + 17 * n_batches * batch
 
     def run(self, stream_ui, neg_static, shuffle_key, sample_seed, first_pos, err_flag, given_ids=None):
         """Generate (stream_ui given) or adopt (given_ids = (user, pos, neg) int32 tensors) the ids and sort the refs."""
         if given_ids is not None:
+            n_pos = self.n_batches * self.batch  # may be a shorter tail slice in the same buffers
             for dst, src in zip(self.ids, given_ids):
-                dst.copy_(src[: dst.numel()])
+                dst[:n_pos].copy_(src[:n_pos])
         sk, sv = C.c_void_p(), C.c_void_p()
         N = 0 if stream_ui is None else stream_ui.shape[0]
         check(_lib.load().trs_epoch_presort(ptr(stream_ui), ptr(neg_static), N, int(shuffle_key), int(sample_seed),
@@ -187,16 +194,26 @@ class EpochPresort:
                                             ptr(self.vals), ptr(self.temp), self.temp_bytes, ptr(err_flag),
                                             C.byref(sk), C.byref(sv), _stream()), "trs_epoch_presort")
         self.sorted_keys, self.sorted_vals = sk.value, sv.value
+        uk, uv, ukb = C.c_void_p(), C.c_void_p(), C.c_int32()
+        check(_lib.load().trs_epoch_user_dups(ptr(self.ids[0]), self.n_batches, self.batch, self.n_users,
+                                              ptr(self.ukeys), ptr(self.uvals), ptr(self.temp), self.temp_bytes,
+                                              ptr(self.user_dup), C.byref(uk), C.byref(uv), C.byref(ukb), _stream()),
+              "trs_epoch_user_dups")
+        self.sorted_ukeys, self.sorted_uvals, self.ukey_bytes = uk.value, uv.value, ukb.value
 
     def step_args(self, b):
-        """(user, pos, neg id views, sorted keys address, sorted vals address) for the steps starting at batch b."""
+        """(user, pos, neg id views, sorted keys address, sorted vals address, user-duplicate flags view) for the steps
+        starting at batch b."""
         o = b * self.batch
-        return ([t[o:] for t in self.ids], self.sorted_keys + 2 * o * self.key_bytes, self.sorted_vals + 2 * o * 8)
+        return ([t[o:] for t in self.ids], self.sorted_keys + 2 * o * self.key_bytes, self.sorted_vals + 2 * o * 8,
+                self.user_dup[o:], (self.sorted_ukeys + o * self.ukey_bytes, self.sorted_uvals + o * 4,
+                                    self.ukey_bytes, o))
 
 
 def train_steps_sgd(net, T, stream_ui, neg_static, shuffle_key, sample_seed, first_pos, batch, n_steps,
                     lr, user_buf, pos_buf, neg_buf, gz_buf, du_buf, loss_sums, err_flag, scratch=None, first_stamp=1,
-                    events=None, sorted_keys=None, sorted_vals=None, key_bytes=0):
+                    events=None, sorted_keys=None, sorted_vals=None, key_bytes=0, user_dup=None, ustage=None,
+                    user_sorted=None):
     """n_steps fused SGD steps driven from C (trs_train_steps_sgd).  stream_ui None: the steps' ids are already in
     user/pos/neg_buf.  events: optional flat list of 4*n_steps torch.cuda.Event (already created by a record())."""
     ev = None
@@ -207,7 +224,8 @@ def train_steps_sgd(net, T, stream_ui, neg_static, shuffle_key, sample_seed, fir
                                           N, int(shuffle_key), int(sample_seed), int(first_pos), int(batch),
                                           int(n_steps), float(lr), ptr(user_buf), ptr(pos_buf), ptr(neg_buf),
                                           ptr(gz_buf), ptr(du_buf), ptr(loss_sums), ptr(err_flag), ptr(scratch),
-                                          int(first_stamp), sorted_keys, sorted_vals, int(key_bytes), ev, _stream()),
+                                          int(first_stamp), sorted_keys, sorted_vals, int(key_bytes), ptr(user_dup),
+                                          ptr(ustage), *(user_sorted or (None, None, 0, 0)), ev, _stream()),
           "trs_train_steps_sgd")
 
 
