@@ -92,51 +92,76 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_stats_partial_kernel(const float
 // Chan et al. pairwise combination of the chunk partials in fp64 -> batch mean, biased variance; running statistics
 // update (momentum 0.1, unbiased variance) applied once per pass, positive pass first.
 // Block = 64 columns x 4 segments of the chunk list; the 4 partial (n, mean, M2) triples are merged in LDS.
-constexpr int FIN_COLS = 64, FIN_SEGS = TRS_BLOCK / FIN_COLS;
-
-__device__ __forceinline__ void chan_merge(double& n, double& mean, double& m2, double nb, double mb, double m2b) {
-  if (nb == 0.0) return;
-  const double tot = n + nb, delta = mb - mean;
-  mean += delta * nb / tot;
-  m2 += m2b + delta * delta * n * nb / tot;
-  n = tot;
-}
+constexpr int FIN_COLS = 16, FIN_SEGS = TRS_BLOCK / FIN_COLS;  // narrow column slabs: H/16 workgroups, 16 segments each
 
 __global__ __launch_bounds__(TRS_BLOCK) void bn_stats_final_kernel(const float* __restrict__ part,
                                                                   int64_t rows_per_pass, int chunk_rows, int H,
-                                                                  int n_chunks, int passes, float momentum,
-                                                                  float* __restrict__ mean_out,
-                                                                  float* __restrict__ var_out,
-                                                                  float* __restrict__ running_mean,
-                                                                  float* __restrict__ running_var) {
-  __shared__ double s_n[FIN_SEGS][FIN_COLS], s_mean[FIN_SEGS][FIN_COLS], s_m2[FIN_SEGS][FIN_COLS];
+                                                                  int n_chunks, float* __restrict__ mean_out,
+                                                                  float* __restrict__ var_out) {
+  // Chan et al. combination of the per-chunk (mean, M2) pairs in fp64, written as two weighted sums so that no
+  // division sits in the loops: mean = sum(nb*mean_b)/N, then M2 = sum(M2_b + nb*(mean_b - mean)^2).
+  __shared__ double s_a[FIN_SEGS][FIN_COLS], s_b[FIN_SEGS][FIN_COLS];
+  __shared__ double s_mean[FIN_COLS];
   const int cl = threadIdx.x % FIN_COLS, seg = threadIdx.x / FIN_COLS;
   const int col = blockIdx.x * FIN_COLS + cl;
-  for (int pass = 0; pass < passes; ++pass) {
-    double n = 0.0, mean = 0.0, m2 = 0.0;
-    if (col < H) {
-      for (int c = seg; c < n_chunks; c += FIN_SEGS) {
-        const int64_t r0 = (int64_t)c * chunk_rows;
-        const double nb = (double)((r0 + chunk_rows < rows_per_pass ? r0 + chunk_rows : rows_per_pass) - r0);
-        const float* o = part + (((int64_t)pass * n_chunks + c) * 2) * H;
-        chan_merge(n, mean, m2, nb, (double)o[col], (double)o[H + col]);
-      }
+  const int pass = blockIdx.y;
+  const float* base = part + (int64_t)pass * n_chunks * 2 * H;
+  double s1 = 0.0, cnt = 0.0;
+  if (col < H) {
+    for (int c = seg; c < n_chunks; c += FIN_SEGS) {
+      const int64_t r0 = (int64_t)c * chunk_rows;
+      const double nb = (double)((r0 + chunk_rows < rows_per_pass ? r0 + chunk_rows : rows_per_pass) - r0);
+      s1 += nb * (double)base[(int64_t)c * 2 * H + col];
+      cnt += nb;
     }
-    s_n[seg][cl] = n; s_mean[seg][cl] = mean; s_m2[seg][cl] = m2;
-    __syncthreads();
-    if (seg == 0 && col < H) {
-      for (int q = 1; q < FIN_SEGS; ++q) chan_merge(n, mean, m2, s_n[q][cl], s_mean[q][cl], s_m2[q][cl]);
-      const float mu = (float)mean, var = (float)(m2 / n);
-      mean_out[pass * H + col] = mu;
-      var_out[pass * H + col] = var;
-      if (running_mean) {
-        const float unb = (float)(m2 / (n > 1.0 ? n - 1.0 : 1.0));
-        running_mean[col] = (1.0f - momentum) * running_mean[col] + momentum * mu;
-        running_var[col] = (1.0f - momentum) * running_var[col] + momentum * unb;
-      }
-    }
-    __syncthreads();
   }
+  s_a[seg][cl] = s1; s_b[seg][cl] = cnt;
+  __syncthreads();
+  if (seg == 0) {
+    for (int q = 1; q < FIN_SEGS; ++q) { s1 += s_a[q][cl]; cnt += s_b[q][cl]; }
+    s_mean[cl] = s1 / cnt;
+  }
+  __syncthreads();
+  const double mean = s_mean[cl];
+  const double n = (double)rows_per_pass;
+  double m2 = 0.0;
+  if (col < H) {
+    for (int c = seg; c < n_chunks; c += FIN_SEGS) {
+      const int64_t r0 = (int64_t)c * chunk_rows;
+      const double nb = (double)((r0 + chunk_rows < rows_per_pass ? r0 + chunk_rows : rows_per_pass) - r0);
+      const float* o = base + (int64_t)c * 2 * H;
+      const double d = (double)o[col] - mean;
+      m2 += (double)o[H + col] + nb * d * d;
+    }
+  }
+  __syncthreads();
+  s_a[seg][cl] = m2;
+  __syncthreads();
+  if (seg == 0 && col < H) {
+    for (int q = 1; q < FIN_SEGS; ++q) m2 += s_a[q][cl];
+    const float mu = (float)mean, var = (float)(m2 / n);
+    mean_out[pass * H + col] = mu;
+    var_out[pass * H + col] = var;
+  }
+}
+
+// running statistics: one momentum update per pass, in pass order (the reference's two net.forward calls, mlp.py:88-115)
+__global__ void bn_running_update_kernel(const float* __restrict__ mean, const float* __restrict__ var,
+                                         int64_t rows_per_pass, int H, int passes, float momentum,
+                                         float* __restrict__ running_mean, float* __restrict__ running_var) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= H) return;
+  const float n = (float)rows_per_pass;
+  float rm = running_mean[col], rv = running_var[col];
+  for (int pass = 0; pass < passes; ++pass) {
+    const float mu = mean[pass * H + col];
+    const double m2 = (double)var[pass * H + col] * (double)n;
+    const float unb = (float)(m2 / (n > 1.f ? (double)n - 1.0 : 1.0));
+    rm = (1.0f - momentum) * rm + momentum * mu;
+    rv = (1.0f - momentum) * rv + momentum * unb;
+  }
+  running_mean[col] = rm;
+  running_var[col] = rv;
 }
 
 // ------------------------------------------------------------------------------------------- BN + ReLU forward
@@ -369,6 +394,132 @@ __global__ __launch_bounds__(TRS_BLOCK) void outer_kernel(const float* __restric
   }
 }
 
+// ---- float4 variants of the chunk reductions (H % 4 == 0, 16-byte aligned rows).  A workgroup covers TPR*4 columns
+// with TPR threads and 256/TPR rows at a time; four row-steps are in flight per thread (unconditional loads), the row
+// lanes are merged in LDS in lane order.  Same chunking and order in both passes (exact pos/neg cancellation holds).
+struct V4Shape {
+  int tpr;  // threads per row (power of two <= 256)
+  int gx;   // workgroups across the columns
+};
+static V4Shape v4_shape(int H) {
+  const int c4 = H / 4;
+  int tpr = 1;
+  while (tpr < c4 && tpr < TRS_BLOCK) tpr <<= 1;
+  V4Shape v = {tpr, (c4 + tpr - 1) / tpr};
+  return v;
+}
+static bool v4_ok(const void* p, int H, int64_t ld) { return H % 4 == 0 && ld % 4 == 0 && ((uintptr_t)p & 15) == 0; }
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+__global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_reduce_v4_kernel(const BnBwdArgs a, int tpr) {
+  __shared__ float4 sh[2][TRS_BLOCK];
+  const int tc = threadIdx.x % tpr, rl = threadIdx.x / tpr, nrl = TRS_BLOCK / tpr;
+  const int col = (blockIdx.x * tpr + tc) * 4;
+  const int chunk = blockIdx.y, pass = blockIdx.z;
+  const bool live = col < a.H;
+  const int cc = live ? col : 0;
+  const int64_t r0 = (int64_t)chunk * CHUNK_ROWS;
+  const int64_t r1 = (r0 + CHUNK_ROWS < a.rows_per_pass) ? r0 + CHUNK_ROWS : a.rows_per_pass;
+  const int64_t base = (int64_t)pass * a.rows_per_pass;
+  float mu[4] = {0.f, 0.f, 0.f, 0.f}, is[4] = {1.f, 1.f, 1.f, 1.f}, ga[4] = {1.f, 1.f, 1.f, 1.f}, be[4] = {0.f, 0.f, 0.f, 0.f};
+  if (a.use_bn) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      mu[q] = a.mean[pass * a.H + cc + q];
+      is[q] = 1.0f / sqrtf(a.var[pass * a.H + cc + q] + a.eps);
+      ga[q] = a.gamma[cc + q];
+      be[q] = a.beta[cc + q];
+    }
+  }
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 4;
+  for (int64_t r = r0 + rl; r < r1; r += (int64_t)nrl * U) {
+    float4 yv[U], dv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t rr = r + (int64_t)u * nrl;
+      const int64_t rc = rr < r1 ? rr : r1 - 1;
+      yv[u] = ld4(a.y + (base + rc) * a.ld + cc);
+      dv[u] = ld4(a.dx + (base + rc) * a.ldd + cc);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool in = r + (int64_t)u * nrl < r1;
+      const float y4[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w}, d4[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float xhat = (y4[q] - mu[q]) * is[q];
+        const float yhat = a.use_bn ? xhat * ga[q] + be[q] : y4[q];
+        const float d = (in && yhat > 0.f) ? d4[q] : 0.f;
+        s1[q] += d;
+        s2[q] += d * xhat;
+      }
+    }
+  }
+  sh[0][threadIdx.x] = make_float4(s1[0], s1[1], s1[2], s1[3]);
+  sh[1][threadIdx.x] = make_float4(s2[0], s2[1], s2[2], s2[3]);
+  __syncthreads();
+  if (rl == 0 && live) {
+    float4 t1 = sh[0][tc], t2 = sh[1][tc];
+    for (int l = 1; l < nrl; ++l) {
+      const float4 o1 = sh[0][l * tpr + tc], o2 = sh[1][l * tpr + tc];
+      t1.x += o1.x; t1.y += o1.y; t1.z += o1.z; t1.w += o1.w;
+      t2.x += o2.x; t2.y += o2.y; t2.z += o2.z; t2.w += o2.w;
+    }
+    float* o = a.part + (((int64_t)pass * a.n_chunks + chunk) * 2) * a.H;
+    *reinterpret_cast<float4*>(o + col) = t1;
+    *reinterpret_cast<float4*>(o + a.H + col) = t2;
+  }
+}
+
+__global__ __launch_bounds__(TRS_BLOCK) void colsum_partial_v4_kernel(const float* __restrict__ x, int64_t rows_per_pass,
+                                                                     int H, int64_t ld, const float* __restrict__ w,
+                                                                     int n_chunks, float* __restrict__ part, int tpr) {
+  __shared__ float4 sh[TRS_BLOCK];
+  const int tc = threadIdx.x % tpr, rl = threadIdx.x / tpr, nrl = TRS_BLOCK / tpr;
+  const int col = (blockIdx.x * tpr + tc) * 4;
+  const int chunk = blockIdx.y, pass = blockIdx.z;
+  const bool live = col < H;
+  const int cc = live ? col : 0;
+  const int64_t base = (int64_t)pass * rows_per_pass;
+  const int64_t r0 = (int64_t)chunk * CHUNK_ROWS;
+  const int64_t r1 = (r0 + CHUNK_ROWS < rows_per_pass) ? r0 + CHUNK_ROWS : rows_per_pass;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 4;
+  for (int64_t r = r0 + rl; r < r1; r += (int64_t)nrl * U) {
+    float4 xv[U];
+    float wv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t rr = r + (int64_t)u * nrl;
+      const int64_t rc = rr < r1 ? rr : r1 - 1;
+      xv[u] = ld4(x + (base + rc) * ld + cc);
+      wv[u] = w ? w[base + rc] : 1.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (r + (int64_t)u * nrl < r1) {
+        if (w) {
+          s[0] += wv[u] * xv[u].x; s[1] += wv[u] * xv[u].y; s[2] += wv[u] * xv[u].z; s[3] += wv[u] * xv[u].w;
+        } else {
+          s[0] += xv[u].x; s[1] += xv[u].y; s[2] += xv[u].z; s[3] += xv[u].w;
+        }
+      }
+    }
+  }
+  sh[threadIdx.x] = make_float4(s[0], s[1], s[2], s[3]);
+  __syncthreads();
+  if (rl == 0 && live) {
+    float4 t = sh[tc];
+    for (int l = 1; l < nrl; ++l) {
+      const float4 o = sh[l * tpr + tc];
+      t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+    }
+    *reinterpret_cast<float4*>(part + ((int64_t)pass * n_chunks + chunk) * H + col) = t;
+  }
+}
+
 static int n_chunks_of(int64_t rows) { return (int)((rows + CHUNK_ROWS - 1) / CHUNK_ROWS); }
 
 }  // namespace
@@ -409,9 +560,14 @@ extern "C" int trs_bn_batch_stats(const float* y_dev, int64_t rows_per_pass, int
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(gx, nc, passes), dim3(TRS_BLOCK), 0, s, y_dev, rows_per_pass, H, ld,
                      nc, workspace_dev);
   TRS_CHECK_LAUNCH("bn_stats_partial_kernel");
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((H + FIN_COLS - 1) / FIN_COLS), dim3(TRS_BLOCK), 0, s, workspace_dev, rows_per_pass, CHUNK_ROWS, H, nc, passes,
-                     momentum, mean_out_dev, var_out_dev, running_mean_dev, running_var_dev);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((H + FIN_COLS - 1) / FIN_COLS, passes), dim3(TRS_BLOCK), 0, s,
+                     workspace_dev, rows_per_pass, CHUNK_ROWS, H, nc, mean_out_dev, var_out_dev);
   TRS_CHECK_LAUNCH("bn_stats_final_kernel");
+  if (running_mean_dev) {
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3((H + TRS_BLOCK - 1) / TRS_BLOCK), dim3(TRS_BLOCK), 0, s,
+                       mean_out_dev, var_out_dev, rows_per_pass, H, passes, momentum, running_mean_dev, running_var_dev);
+    TRS_CHECK_LAUNCH("bn_running_update_kernel");
+  }
   return TRS_OK;
 }
 
@@ -425,10 +581,15 @@ extern "C" int trs_bn_stats_finalize(const float* part_dev, int64_t rows_per_pas
               "trs_bn_stats_finalize: a chunk must not straddle the two passes (rows_per_pass %% chunk_rows != 0)");
   TRS_REQUIRE((running_mean_dev == nullptr) == (running_var_dev == nullptr), "trs_bn_stats_finalize: running stats");
   const int nc = (int)((rows_per_pass + chunk_rows - 1) / chunk_rows);
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((H + FIN_COLS - 1) / FIN_COLS), dim3(TRS_BLOCK), 0,
-                     (hipStream_t)stream, part_dev, rows_per_pass, chunk_rows, H, nc, passes, momentum, mean_out_dev,
-                     var_out_dev, running_mean_dev, running_var_dev);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((H + FIN_COLS - 1) / FIN_COLS, passes), dim3(TRS_BLOCK), 0,
+                     (hipStream_t)stream, part_dev, rows_per_pass, chunk_rows, H, nc, mean_out_dev, var_out_dev);
   TRS_CHECK_LAUNCH("bn_stats_final_kernel");
+  if (running_mean_dev) {
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3((H + TRS_BLOCK - 1) / TRS_BLOCK), dim3(TRS_BLOCK), 0,
+                       (hipStream_t)stream, mean_out_dev, var_out_dev, rows_per_pass, H, passes, momentum,
+                       running_mean_dev, running_var_dev);
+    TRS_CHECK_LAUNCH("bn_running_update_kernel");
+  }
   return TRS_OK;
 }
 
@@ -465,7 +626,12 @@ extern "C" int trs_bn_relu_backward(const float* y_dev, const float* dx_dev, int
   BnBwdArgs a = {y_dev, dx_dev, dy_dev, rows_per_pass, ld, ldd, H, passes, use_bn, nc, mean_dev, var_dev, gamma_dev,
                  beta_dev, eps, workspace_dev, sums};
   if (use_bn) {
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(gx, nc, passes), dim3(TRS_BLOCK), 0, s, a);
+    if (v4_ok(y_dev, H, ld) && v4_ok(dx_dev, H, ldd) && v4_ok(workspace_dev, H, 4)) {
+      const V4Shape v = v4_shape(H);
+      hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel, dim3(v.gx, nc, passes), dim3(TRS_BLOCK), 0, s, a, v.tpr);
+    } else {
+      hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(gx, nc, passes), dim3(TRS_BLOCK), 0, s, a);
+    }
     TRS_CHECK_LAUNCH("bn_bwd_reduce_kernel");
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((H + FIN_COLS - 1) / FIN_COLS), dim3(TRS_BLOCK), 0, s, workspace_dev, H, nc, passes, sums,
                        dgamma_dev, dbeta_dev);
@@ -488,8 +654,14 @@ extern "C" int trs_colsum(const float* x_dev, int64_t rows_per_pass, int32_t pas
   const int nc = n_chunks_of(rows_per_pass);
   const int gx = (H + TRS_BLOCK - 1) / TRS_BLOCK;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(gx, nc, passes), dim3(TRS_BLOCK), 0, s, x_dev, rows_per_pass, H, ld,
-                     row_weight_dev, nc, workspace_dev);
+  if (v4_ok(x_dev, H, ld) && v4_ok(workspace_dev, H, 4)) {
+    const V4Shape v = v4_shape(H);
+    hipLaunchKernelGGL(colsum_partial_v4_kernel, dim3(v.gx, nc, passes), dim3(TRS_BLOCK), 0, s, x_dev, rows_per_pass, H,
+                       ld, row_weight_dev, nc, workspace_dev, v.tpr);
+  } else {
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(gx, nc, passes), dim3(TRS_BLOCK), 0, s, x_dev, rows_per_pass, H, ld,
+                       row_weight_dev, nc, workspace_dev);
+  }
   TRS_CHECK_LAUNCH("colsum_partial_kernel");
   hipLaunchKernelGGL(colsum_final_kernel, dim3((H + FIN_COLS - 1) / FIN_COLS), dim3(TRS_BLOCK), 0, s, workspace_dev, H, nc, passes, out_dev);
   TRS_CHECK_LAUNCH("colsum_final_kernel");
