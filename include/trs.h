@@ -295,12 +295,14 @@ int trs_bn_relu_forward(const float* y_dev, int64_t rows_per_pass, int32_t passe
                         void* stream);
 
 /* Backward of relu(bn(y)) in train mode from dx = dL/d(out): dy (same shape), dgamma/dbeta (H) summed over both
- * passes.  use_bn = 0: dy = dx * [y > 0].  workspace: trs_bn_backward_workspace_floats(...) floats. */
+ * passes.  use_bn = 0: dy = dx * [y > 0].  dy_colsum_dev (H, may be NULL): column sums of dy = the gradient of the
+ * preceding Linear's bias, summed per pass first like trs_colsum.  workspace: trs_bn_backward_workspace_floats(...)
+ * floats. */
 int64_t trs_bn_backward_workspace_floats(int64_t rows_per_pass, int32_t H, int32_t passes);
 int trs_bn_relu_backward(const float* y_dev, const float* dx_dev, int64_t rows_per_pass, int32_t passes, int32_t H,
                          int64_t ld, int64_t ldd, int32_t use_bn, const float* mean_dev, const float* var_dev,
                          const float* gamma_dev, const float* beta_dev, float eps, float* dy_dev, float* dgamma_dev,
-                         float* dbeta_dev, float* workspace_dev, void* stream);
+                         float* dbeta_dev, float* dy_colsum_dev, float* workspace_dev, void* stream);
 
 /* out[h] = sum_r w[r] * x[r][h] over the passes*rows_per_pass rows (row_weight NULL: plain column sums): bias
  * gradients and the output layer's weight gradient.  Summed per pass first (identical chunking in both passes), so a

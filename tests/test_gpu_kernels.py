@@ -346,7 +346,10 @@ def test_bn_stats_forward_backward(B, H, passes):
     dx = rs.normal(0, 1, (rows, H)).astype(np.float32)
     tdx = torch.from_numpy(dx).to(DEV)
     dy, dg, db = torch.empty_like(ty), torch.empty(H, device=DEV), torch.empty(H, device=DEV)
-    ops.bn_relu_backward(ty, tdx, B, passes, True, mean, var, tg, tb, 1e-5, dy, dg, db)
+    dbias = torch.empty(H, device=DEV)
+    ops.bn_relu_backward(ty, tdx, B, passes, True, mean, var, tg, tb, 1e-5, dy, dg, db, dy_colsum=dbias)
+    # column sums of dy (the Linear bias gradient under BatchNorm) are rounding noise around an exact 0
+    assert np.abs(dbias.cpu().numpy() - dy.double().sum(0).cpu().numpy()).max() < 1e-4 * np.abs(dy.cpu().numpy()).max() * np.sqrt(rows)
     d = dx.astype(np.float64).reshape(passes, B, H) * (yhat > 0)
     s1, s2 = d.sum(axis=1, keepdims=True), (d * xhat).sum(axis=1, keepdims=True)
     ref_dy = gamma / np.sqrt(rvar[:, None, :] + 1e-5) * (d - s1 / B - xhat * s2 / B)
@@ -356,8 +359,13 @@ def test_bn_stats_forward_backward(B, H, passes):
     # no-BN variants
     ops.bn_relu_forward(ty, B, passes, False, 1, None, None, None, None, 1e-5, out)
     assert np.array_equal(out.cpu().numpy(), np.maximum(y, 0))
-    ops.bn_relu_backward(ty, tdx, B, passes, False, None, None, None, None, 1e-5, dy, None, None)
+    ops.bn_relu_backward(ty, tdx, B, passes, False, None, None, None, None, 1e-5, dy, None, None, dy_colsum=dbias)
     assert np.array_equal(dy.cpu().numpy(), dx * (y > 0))
+    assert rel_err(dbias.cpu().numpy(), (dx.astype(np.float64) * (y > 0)).sum(0)) < 2e-5
+    if passes == 2:  # negative pass = exact negation of the positive one: the bias gradient cancels to an exact 0
+        ty2, tdx2 = torch.cat([ty[:B], ty[:B]]), torch.cat([tdx[:B], -tdx[:B]])
+        ops.bn_relu_backward(ty2, tdx2, B, 2, False, None, None, None, None, 1e-5, dy, None, None, dy_colsum=dbias)
+        assert np.array_equal(dbias.cpu().numpy(), np.zeros(H, np.float32))
 
 
 def test_colsum_rowdot_outer_gather():

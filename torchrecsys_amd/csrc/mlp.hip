@@ -228,6 +228,7 @@ struct BnBwdArgs {
   float eps;
   float* part;
   const float* sums;  // (passes, 2, H) final s1, s2 (apply kernel)
+  float* cs_part;     // optional (passes, n_chunks, H): per-chunk column sums of dy (the layer's bias gradient)
 };
 
 __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
@@ -473,6 +474,115 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_reduce_v4_kernel(const BnBwd
   }
 }
 
+// out = relu(bn(y)): thread = 4 fixed columns (scale/shift folded once), rows streamed four at a time.
+__global__ __launch_bounds__(TRS_BLOCK) void bn_relu_fwd_v4_kernel(const BnFwdArgs a, int tpr) {
+  const int tc = threadIdx.x % tpr, rl = threadIdx.x / tpr, nrl = TRS_BLOCK / tpr;
+  const int col = (blockIdx.x * tpr + tc) * 4;
+  if (col >= a.H) return;
+  const int chunk = blockIdx.y, pass = blockIdx.z;
+  const int sp = a.stat_passes > 1 ? pass : 0;
+  const int64_t r0 = (int64_t)chunk * CHUNK_ROWS;
+  const int64_t r1 = (r0 + CHUNK_ROWS < a.rows_per_pass) ? r0 + CHUNK_ROWS : a.rows_per_pass;
+  const int64_t base = (int64_t)pass * a.rows_per_pass;
+  float mu[4], is[4], ga[4], be[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    mu[q] = a.use_bn ? a.mean[sp * a.H + col + q] : 0.f;
+    is[q] = a.use_bn ? 1.0f / sqrtf(a.var[sp * a.H + col + q] + a.eps) : 1.f;
+    ga[q] = a.use_bn ? a.gamma[col + q] : 1.f;
+    be[q] = a.use_bn ? a.beta[col + q] : 0.f;
+  }
+  constexpr int U = 4;
+  for (int64_t r = r0 + rl; r < r1; r += (int64_t)nrl * U) {
+    float4 yv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t rr = r + (int64_t)u * nrl;
+      yv[u] = ld4(a.y + (base + (rr < r1 ? rr : r1 - 1)) * a.ld + col);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t rr = r + (int64_t)u * nrl;
+      float v[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float x = a.use_bn ? ((v[q] - mu[q]) * is[q]) * ga[q] + be[q] : v[q];
+        v[q] = fmaxf(x, 0.f);
+      }
+      if (rr < r1) *reinterpret_cast<float4*>(a.out + (base + rr) * a.ldo + col) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+// dy from (y, dx, final sums) with the same thread-owns-columns layout; optionally the per-chunk column sums of dy.
+__global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_apply_v4_kernel(const BnBwdArgs a, int tpr) {
+  __shared__ float4 sh[TRS_BLOCK];
+  const int tc = threadIdx.x % tpr, rl = threadIdx.x / tpr, nrl = TRS_BLOCK / tpr;
+  const int col = (blockIdx.x * tpr + tc) * 4;
+  const int chunk = blockIdx.y, pass = blockIdx.z;
+  const bool live = col < a.H;
+  const int cc = live ? col : 0;
+  const int64_t r0 = (int64_t)chunk * CHUNK_ROWS;
+  const int64_t r1 = (r0 + CHUNK_ROWS < a.rows_per_pass) ? r0 + CHUNK_ROWS : a.rows_per_pass;
+  const int64_t base = (int64_t)pass * a.rows_per_pass;
+  const float invB = 1.0f / (float)a.rows_per_pass;
+  float mu[4], is[4], ga[4], be[4], m1[4], m2[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    mu[q] = a.use_bn ? a.mean[pass * a.H + cc + q] : 0.f;
+    is[q] = a.use_bn ? 1.0f / sqrtf(a.var[pass * a.H + cc + q] + a.eps) : 1.f;
+    ga[q] = a.use_bn ? a.gamma[cc + q] : 1.f;
+    be[q] = a.use_bn ? a.beta[cc + q] : 0.f;
+    m1[q] = a.use_bn ? a.sums[(pass * 2 + 0) * a.H + cc + q] * invB : 0.f;
+    m2[q] = a.use_bn ? a.sums[(pass * 2 + 1) * a.H + cc + q] * invB : 0.f;
+  }
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 4;
+  for (int64_t r = r0 + rl; r < r1; r += (int64_t)nrl * U) {
+    float4 yv[U], dv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t rr = r + (int64_t)u * nrl;
+      const int64_t rc = rr < r1 ? rr : r1 - 1;
+      yv[u] = ld4(a.y + (base + rc) * a.ld + cc);
+      dv[u] = ld4(a.dx + (base + rc) * a.ldd + cc);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t rr = r + (int64_t)u * nrl;
+      const float y4[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w}, d4[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
+      float o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (a.use_bn) {
+          const float xhat = (y4[q] - mu[q]) * is[q];
+          const float yhat = xhat * ga[q] + be[q];
+          const float d = yhat > 0.f ? d4[q] : 0.f;
+          o[q] = (ga[q] * is[q]) * (d - m1[q] - xhat * m2[q]);
+        } else {
+          o[q] = y4[q] > 0.f ? d4[q] : 0.f;
+        }
+      }
+      if (rr < r1 && live) {
+        *reinterpret_cast<float4*>(a.dy + (base + rr) * a.ldd + col) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cs[q] += o[q];
+      }
+    }
+  }
+  if (a.cs_part == nullptr) return;
+  sh[threadIdx.x] = make_float4(cs[0], cs[1], cs[2], cs[3]);
+  __syncthreads();
+  if (rl == 0 && live) {
+    float4 t = sh[tc];
+    for (int l = 1; l < nrl; ++l) {
+      const float4 o = sh[l * tpr + tc];
+      t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+    }
+    *reinterpret_cast<float4*>(a.cs_part + ((int64_t)pass * a.n_chunks + chunk) * a.H + col) = t;
+  }
+}
+
 __global__ __launch_bounds__(TRS_BLOCK) void colsum_partial_v4_kernel(const float* __restrict__ x, int64_t rows_per_pass,
                                                                      int H, int64_t ld, const float* __restrict__ w,
                                                                      int n_chunks, float* __restrict__ part, int tpr) {
@@ -604,8 +714,14 @@ extern "C" int trs_bn_relu_forward(const float* y_dev, int64_t rows_per_pass, in
   if (rows_per_pass == 0) return TRS_OK;
   BnFwdArgs a = {y_dev, out_dev, rows_per_pass, ld, ldo, H, passes, stat_passes, use_bn, mean_dev, var_dev, gamma_dev,
                  beta_dev, eps};
-  const int64_t total = rows_per_pass * passes * ((H + 3) / 4);
-  hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3(trs_grid(total, TRS_BLOCK)), dim3(TRS_BLOCK), 0, (hipStream_t)stream, a);
+  if (v4_ok(y_dev, H, ld) && v4_ok(out_dev, H, ldo)) {
+    const V4Shape v = v4_shape(H);
+    hipLaunchKernelGGL(bn_relu_fwd_v4_kernel, dim3(v.gx, n_chunks_of(rows_per_pass), passes), dim3(TRS_BLOCK), 0,
+                       (hipStream_t)stream, a, v.tpr);
+  } else {
+    const int64_t total = rows_per_pass * passes * ((H + 3) / 4);
+    hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3(trs_grid(total, TRS_BLOCK)), dim3(TRS_BLOCK), 0, (hipStream_t)stream, a);
+  }
   TRS_CHECK_LAUNCH("bn_relu_fwd_kernel");
   return TRS_OK;
 }
@@ -613,8 +729,8 @@ extern "C" int trs_bn_relu_forward(const float* y_dev, int64_t rows_per_pass, in
 extern "C" int trs_bn_relu_backward(const float* y_dev, const float* dx_dev, int64_t rows_per_pass, int32_t passes,
                                     int32_t H, int64_t ld, int64_t ldd, int32_t use_bn, const float* mean_dev,
                                     const float* var_dev, const float* gamma_dev, const float* beta_dev, float eps,
-                                    float* dy_dev, float* dgamma_dev, float* dbeta_dev, float* workspace_dev,
-                                    void* stream) {
+                                    float* dy_dev, float* dgamma_dev, float* dbeta_dev, float* dy_colsum_dev,
+                                    float* workspace_dev, void* stream) {
   TRS_REQUIRE(y_dev && dx_dev && dy_dev && workspace_dev, "trs_bn_relu_backward: NULL argument");
   TRS_REQUIRE(rows_per_pass > 0 && H > 0 && ld >= H && ldd >= H && passes >= 1 && passes <= 2,
               "trs_bn_relu_backward: bad shape");
@@ -623,8 +739,9 @@ extern "C" int trs_bn_relu_backward(const float* y_dev, const float* dx_dev, int
   const int gx = (H + TRS_BLOCK - 1) / TRS_BLOCK;
   hipStream_t s = (hipStream_t)stream;
   float* sums = workspace_dev + (int64_t)passes * nc * 2 * H;  // (passes,2,H) behind the partials
+  float* cs_part = sums + (int64_t)passes * 2 * H;             // (passes,nc,H) column-sum partials of dy
   BnBwdArgs a = {y_dev, dx_dev, dy_dev, rows_per_pass, ld, ldd, H, passes, use_bn, nc, mean_dev, var_dev, gamma_dev,
-                 beta_dev, eps, workspace_dev, sums};
+                 beta_dev, eps, workspace_dev, sums, dy_colsum_dev ? cs_part : nullptr};
   if (use_bn) {
     if (v4_ok(y_dev, H, ld) && v4_ok(dx_dev, H, ldd) && v4_ok(workspace_dev, H, 4)) {
       const V4Shape v = v4_shape(H);
@@ -637,14 +754,30 @@ extern "C" int trs_bn_relu_backward(const float* y_dev, const float* dx_dev, int
                        dgamma_dev, dbeta_dev);
     TRS_CHECK_LAUNCH("bn_bwd_final_kernel");
   }
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(trs_grid(rows_per_pass * passes * H, TRS_BLOCK)), dim3(TRS_BLOCK), 0, s,
-                     a);
-  TRS_CHECK_LAUNCH("bn_bwd_apply_kernel");
+  if (v4_ok(y_dev, H, ld) && v4_ok(dx_dev, H, ldd) && v4_ok(dy_dev, H, ldd) && v4_ok(workspace_dev, H, 4)) {
+    const V4Shape v = v4_shape(H);
+    hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3(v.gx, nc, passes), dim3(TRS_BLOCK), 0, s, a, v.tpr);
+    TRS_CHECK_LAUNCH("bn_bwd_apply_kernel");
+  } else {
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(trs_grid(rows_per_pass * passes * H, TRS_BLOCK)), dim3(TRS_BLOCK), 0,
+                       s, a);
+    TRS_CHECK_LAUNCH("bn_bwd_apply_kernel");
+    if (dy_colsum_dev) {
+      hipLaunchKernelGGL(colsum_partial_kernel, dim3(gx, nc, passes), dim3(TRS_BLOCK), 0, s, dy_dev, rows_per_pass, H,
+                         ldd, (const float*)nullptr, nc, cs_part);
+      TRS_CHECK_LAUNCH("colsum_partial_kernel");
+    }
+  }
+  if (dy_colsum_dev) {
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((H + FIN_COLS - 1) / FIN_COLS), dim3(TRS_BLOCK), 0, s, cs_part, H, nc,
+                       passes, dy_colsum_dev);
+    TRS_CHECK_LAUNCH("colsum_final_kernel");
+  }
   return TRS_OK;
 }
 
 extern "C" int64_t trs_bn_backward_workspace_floats(int64_t rows_per_pass, int32_t H, int32_t passes) {
-  return (int64_t)passes * n_chunks_of(rows_per_pass) * 2 * H + (int64_t)passes * 2 * H;
+  return (int64_t)passes * n_chunks_of(rows_per_pass) * 3 * H + (int64_t)passes * 2 * H;
 }
 
 extern "C" int trs_colsum(const float* x_dev, int64_t rows_per_pass, int32_t passes, int32_t H, int64_t ld,

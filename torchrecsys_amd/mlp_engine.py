@@ -113,11 +113,11 @@ class MLPCompute:
             if use_bn:
                 bn = net.bns[l]
                 ops.bn_relu_backward(y, dx, B, passes, True, ctx["mean"][l], ctx["var"][l], bn.weight.data, bn.bias.data,
-                                     BN_EPS, dy, slot(bn.weight), slot(bn.bias))
+                                     BN_EPS, dy, slot(bn.weight), slot(bn.bias), dy_colsum=slot(fc.bias))
             else:
-                ops.bn_relu_backward(y, dx, B, passes, False, None, None, None, None, BN_EPS, dy, None, None)
+                ops.bn_relu_backward(y, dx, B, passes, False, None, None, None, None, BN_EPS, dy, None, None,
+                                     dy_colsum=slot(fc.bias))          # db = column sums of dy, from the same kernel
             ops.gemm(True, False, dy, ctx["x"][l], out=slot(fc.weight), bf16=net.use_bf16)  # dW = dy^T x (split-K)
-            ops.colsum(dy, slot(fc.bias), passes=passes)                                           # db = column sums of dy
             dx = ops.gemm(False, False, dy, fc.weight.data, bf16=net.use_bf16)      # dx = dy W
         return grads, dx
 

@@ -376,13 +376,14 @@ def bn_relu_forward(y, rows_per_pass, passes, use_bn, stat_passes, mean, var, ga
                                           out.stride(0), _stream()), "trs_bn_relu_forward")
 
 
-def bn_relu_backward(y, dx, rows_per_pass, passes, use_bn, mean, var, gamma, beta, eps, dy, dgamma, dbeta):
+def bn_relu_backward(y, dx, rows_per_pass, passes, use_bn, mean, var, gamma, beta, eps, dy, dgamma, dbeta,
+                     dy_colsum=None):
     lib = _lib.load()
     H = y.shape[1]
     ws = _workspace(y.device, 4 * lib.trs_bn_backward_workspace_floats(rows_per_pass, H, passes))
     check(lib.trs_bn_relu_backward(ptr(y), ptr(dx), rows_per_pass, passes, H, y.stride(0), dx.stride(0), int(use_bn),
                                    ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps), ptr(dy), ptr(dgamma),
-                                   ptr(dbeta), ptr(ws), _stream()), "trs_bn_relu_backward")
+                                   ptr(dbeta), ptr(dy_colsum), ptr(ws), _stream()), "trs_bn_relu_backward")
 
 
 def colsum(x, out, row_weight=None, passes=1):
