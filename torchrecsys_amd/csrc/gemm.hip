@@ -23,6 +23,7 @@ constexpr int LDS_LD = 132;  // max of the two image strides below
 __host__ __device__ constexpr int img_ld(bool kcontig) { return kcontig ? 129 : 132; }
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 struct GemmArgs {
   const float* A;
@@ -83,6 +84,22 @@ __device__ __forceinline__ void tile_load(float4 (&r)[4], const float* __restric
   }
 }
 
+// Interior tiles (whole 128 x 32 tile in range, 16-byte loads legal): four unconditional float4 loads, nothing under a
+// branch, so the compiler can leave them in flight across the MFMA block (a load inside a conditional is followed by
+// s_waitcnt vmcnt(0) at the join).
+template <bool KC>
+__device__ __forceinline__ void tile_load_fast(float4 (&r)[4], const float* __restrict__ P, int64_t ld, int64_t row0,
+                                               int64_t k0, int tid) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int c = tid + 256 * it;
+    const float* p = KC ? P + (row0 + (c >> 3)) * ld + k0 + ((c & 7) << 2)
+                        : P + (k0 + (c >> 5)) * ld + row0 + ((c & 31) << 2);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    r[it] = make_float4(v.x, v.y, v.z, v.w);
+  }
+}
+
 template <bool KC>
 __device__ __forceinline__ void tile_store(const float4 (&r)[4], float* __restrict__ S, int tid) {
   constexpr int LD = img_ld(KC);
@@ -97,7 +114,8 @@ __device__ __forceinline__ void tile_store(const float4 (&r)[4], float* __restri
       S[(k + 3) * LD + row] = r[it].w;
     } else {
       const int k = c >> 5, row = (c & 31) << 2;
-      *reinterpret_cast<float4*>(&S[k * LD + row]) = r[it];
+      const f32x4 v = {r[it].x, r[it].y, r[it].z, r[it].w};  // native vector: one ds_write_b128 straight from VGPRs
+      *reinterpret_cast<f32x4*>(&S[k * LD + row]) = v;
     }
   }
 }
@@ -177,7 +195,7 @@ __device__ __forceinline__ void gemm_tile_bn_stats(const GemmArgs& g, const f32x
   }
 }
 
-template <bool AKC, bool BKC>
+template <bool AKC, bool BKC, bool FAST>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float As[2][BK * LDS_LD];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDS_LD];
@@ -207,6 +225,38 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 
   float4 ra[4], rb[4];
   const int64_t nk = (kend - kbeg + BK - 1) / BK;
+  const int lr = lane & 31, lk = lane >> 5;
+  if (FAST) {
+    // every tile interior (host-checked): tile t+1's loads are issued unconditionally before tile t's MFMAs (the last
+    // iteration re-reads its own tile into the idle buffer instead of branching around the loads)
+    tile_load_fast<AKC>(ra, g.A, g.lda, m0, kbeg, tid);
+    tile_load_fast<BKC>(rb, g.B, g.ldb, n0, kbeg, tid);
+    tile_store<AKC>(ra, As[0], tid);
+    tile_store<BKC>(rb, Bs[0], tid);
+    __syncthreads();
+    for (int64_t kt = 0; kt < nk; ++kt) {
+      const int cur = (int)(kt & 1);
+      const int64_t kn = kbeg + (kt + 1 < nk ? kt + 1 : kt) * BK;
+      tile_load_fast<AKC>(ra, g.A, g.lda, m0, kn, tid);
+      tile_load_fast<BKC>(rb, g.B, g.ldb, n0, kn, tid);
+      __builtin_amdgcn_sched_barrier(0);  // keep the loads above the MFMA block (the scheduler sinks them to their use)
+      const float* as = As[cur] + wm * 64 + lr;
+      const float* bs = Bs[cur] + wn * 64 + lr;
+#pragma unroll
+      for (int k2 = 0; k2 < BK / 2; ++k2) {
+        const int k = 2 * k2 + lk;
+        const float a0 = as[k * LDA_S], a1 = as[k * LDA_S + 32];
+        const float b0 = bs[k * LDB_S], b1 = bs[k * LDB_S + 32];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
+      tile_store<AKC>(ra, As[cur ^ 1], tid);
+      tile_store<BKC>(rb, Bs[cur ^ 1], tid);
+      __syncthreads();
+    }
+  } else {
   if (nk > 0) {
     tile_load<AKC>(ra, g.A, g.lda, g.M, kend, m0, kbeg, g.vecA, tid);
     tile_load<BKC>(rb, g.B, g.ldb, g.N, kend, n0, kbeg, g.vecB, tid);
@@ -214,7 +264,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     tile_store<BKC>(rb, Bs[0], tid);
   }
   __syncthreads();
-  const int lr = lane & 31, lk = lane >> 5;
   for (int64_t kt = 0; kt < nk; ++kt) {
     const int cur = (int)(kt & 1);
     if (kt + 1 < nk) {
@@ -238,6 +287,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
       tile_store<BKC>(rb, Bs[cur ^ 1], tid);
     }
     __syncthreads();
+  }
   }
 
   gemm_epilogue(g, acc, m0, n0, wm, wn, lr, lk, bz);
@@ -275,7 +325,7 @@ __device__ __forceinline__ void tile_store_bf16(const float4 (&r)[4], unsigned s
   }
 }
 
-template <bool AKC, bool BKC>
+template <bool AKC, bool BKC, bool FAST>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
   __shared__ __attribute__((aligned(16))) unsigned short As[2][BM * HROW];
   __shared__ __attribute__((aligned(16))) unsigned short Bs[2][BN * HROW];
@@ -301,17 +351,27 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
 
   float4 ra[4], rb[4];
   const int64_t nk = (kend - kbeg + BK - 1) / BK;
-  if (nk > 0) {
+  const int lr = lane & 31, lk = lane >> 5;
+  if (FAST) {  // all tiles interior: unconditional loads issued above the MFMA block (see gemm_f32_kernel)
+    tile_load_fast<AKC>(ra, g.A, g.lda, m0, kbeg, tid);
+    tile_load_fast<BKC>(rb, g.B, g.ldb, n0, kbeg, tid);
+  } else if (nk > 0) {
     tile_load<AKC>(ra, g.A, g.lda, g.M, kend, m0, kbeg, g.vecA, tid);
     tile_load<BKC>(rb, g.B, g.ldb, g.N, kend, n0, kbeg, g.vecB, tid);
+  }
+  if (nk > 0) {
     tile_store_bf16<AKC>(ra, As[0], tid);
     tile_store_bf16<BKC>(rb, Bs[0], tid);
   }
   __syncthreads();
-  const int lr = lane & 31, lk = lane >> 5;
   for (int64_t kt = 0; kt < nk; ++kt) {
     const int cur = (int)(kt & 1);
-    if (kt + 1 < nk) {
+    if (FAST) {
+      const int64_t kn = kbeg + (kt + 1 < nk ? kt + 1 : kt) * BK;
+      tile_load_fast<AKC>(ra, g.A, g.lda, m0, kn, tid);
+      tile_load_fast<BKC>(rb, g.B, g.ldb, n0, kn, tid);
+      __builtin_amdgcn_sched_barrier(0);
+    } else if (kt + 1 < nk) {
       tile_load<AKC>(ra, g.A, g.lda, g.M, kend, m0, kbeg + (kt + 1) * BK, g.vecA, tid);
       tile_load<BKC>(rb, g.B, g.ldb, g.N, kend, n0, kbeg + (kt + 1) * BK, g.vecB, tid);
     }
@@ -328,7 +388,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
     }
-    if (kt + 1 < nk) {
+    if (FAST || kt + 1 < nk) {
       tile_store_bf16<AKC>(ra, As[cur ^ 1], tid);
       tile_store_bf16<BKC>(rb, Bs[cur ^ 1], tid);
     }
@@ -403,16 +463,31 @@ static int gemm_impl(bool bf16, int transA, int transB, int64_t M, int64_t N, in
   dim3 grid((unsigned)(gx * gy * splits));
   hipStream_t s = (hipStream_t)stream;
   const bool akc = !transA, bkc = transB != 0;
+  // all tiles interior: M, N multiples of 128, every split's K range a multiple of 32, 16-byte loads legal
+  const bool fast = g.vecA && g.vecB && M % BM == 0 && N % BN == 0 && K % BK == 0 &&
+                    (int64_t)splits * g.k_per_split == K;
   if (bf16) {
-    if (akc && bkc) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, dim3(256), 0, s, g);
-    else if (akc && !bkc) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, dim3(256), 0, s, g);
-    else if (!akc && bkc) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, dim3(256), 0, s, g);
+#define TRS_GEMM(A_, B_)                                                                         \
+  {                                                                                              \
+    if (fast) hipLaunchKernelGGL((gemm_bf16_kernel<A_, B_, true>), grid, dim3(256), 0, s, g);    \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<A_, B_, false>), grid, dim3(256), 0, s, g);        \
+  }
+    if (akc && bkc) TRS_GEMM(true, true)
+    else if (akc && !bkc) TRS_GEMM(true, false)
+    else if (!akc && bkc) TRS_GEMM(false, true)
+    else TRS_GEMM(false, false)
+#undef TRS_GEMM
   } else {
-    if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, s, g);
-    else if (akc && !bkc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, s, g);
-    else if (!akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, s, g);
+#define TRS_GEMM(A_, B_)                                                                         \
+  {                                                                                              \
+    if (fast) hipLaunchKernelGGL((gemm_f32_kernel<A_, B_, true>), grid, dim3(256), 0, s, g);     \
+    else hipLaunchKernelGGL((gemm_f32_kernel<A_, B_, false>), grid, dim3(256), 0, s, g);         \
+  }
+    if (akc && bkc) TRS_GEMM(true, true)
+    else if (akc && !bkc) TRS_GEMM(true, false)
+    else if (!akc && bkc) TRS_GEMM(false, true)
+    else TRS_GEMM(false, false)
+#undef TRS_GEMM
   }
   TRS_CHECK_LAUNCH("gemm kernel");
   if (splits > 1) {
