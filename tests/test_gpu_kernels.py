@@ -312,6 +312,12 @@ def test_gemm_split_k_wgrad_shape_and_strided_views():
     assert rel_err(out_v.cpu().numpy(), dy[:, 8:72].astype(np.float64).T @ x[:, 40:168].astype(np.float64)) < 3e-6
     out_u = ops.gemm(True, False, tdy[:, 3:70], tx[:, 1:150])   # unaligned views: scalar-load path
     assert rel_err(out_u.cpu().numpy(), dy[:, 3:70].astype(np.float64).T @ x[:, 1:150].astype(np.float64)) < 3e-6
+    # interior-tile fast path with an uneven split-K (412 k-tiles over 42 splits of 10: the last split has 2)
+    rows = 412 * 32
+    dy = rs.normal(0, 1, (rows, 512)).astype(np.float32)
+    x = rs.normal(0, 1, (rows, 384)).astype(np.float32)
+    out_f = ops.gemm(True, False, torch.from_numpy(dy).to(DEV), torch.from_numpy(x).to(DEV))
+    assert rel_err(out_f.cpu().numpy(), dy.astype(np.float64).T @ x.astype(np.float64)) < 3e-6
 
 
 @pytest.mark.parametrize("B,H", [(64, 32), (1000, 130), (5000, 7), (256, 512)])

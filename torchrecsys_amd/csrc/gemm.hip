@@ -463,9 +463,10 @@ static int gemm_impl(bool bf16, int transA, int transB, int64_t M, int64_t N, in
   dim3 grid((unsigned)(gx * gy * splits));
   hipStream_t s = (hipStream_t)stream;
   const bool akc = !transA, bkc = transB != 0;
-  // all tiles interior: M, N multiples of 128, every split's K range a multiple of 32, 16-byte loads legal
+  // all tiles interior: M, N multiples of 128, K a multiple of 32 with at least one k-tile in every split (the last
+  // split may be shorter), 16-byte loads legal
   const bool fast = g.vecA && g.vecB && M % BM == 0 && N % BN == 0 && K % BK == 0 &&
-                    (int64_t)splits * g.k_per_split == K;
+                    (int64_t)(splits - 1) * g.k_per_split < K;
   if (bf16) {
 #define TRS_GEMM(A_, B_)                                                                         \
   {                                                                                              \
