@@ -178,6 +178,128 @@ __global__ __launch_bounds__(TRS_BLOCK) void sorted_item_update_kernel(const Sor
   }
 }
 
+// STAGED form, wave-cooperative: a 256-thread workgroup owns one 64-reference chunk (= RUN_CHUNK, so a run never leaves
+// the chunk).  Every wave detects the run leaders with ONE lane per reference (coalesced keys / payloads, then the
+// reference's coefficient c = -lr*gz), ranks them (ballot + popcount) and publishes rank -> lane through LDS; the
+// leaders are then dealt round-robin to the lane groups of the four waves.  A group knows its run's members from the
+// continuation mask, gets their staging rows t and coefficients by shuffle, and issues the item row plus up to MEMB
+// member rows for SLOTS runs at once — no load sits under a branch and no load depends on a loop-carried compare.
+constexpr int SI_SLOTS = 3, SI_MEMB = 3;
+
+template <typename KeyT, int VEC, int G, int K, bool FULL>
+__global__ __launch_bounds__(TRS_BLOCK) void sorted_item_update_staged_kernel(const SortedArgs a) {
+  constexpr int N = K * VEC;
+  constexpr int TPW = TRS_WAVE / G;
+  constexpr int NW = TRS_BLOCK / TRS_WAVE;
+  __shared__ unsigned char lead_lane[NW][TRS_WAVE];
+  const trs_tables& T = a.T;
+  const int D = T.D;
+  const int64_t n = 2 * a.B;
+  const KeyT* keys = reinterpret_cast<const KeyT*>(a.keys);
+  const KeyT row_mask = (KeyT)(((uint64_t)1 << a.item_bits) - 1);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lig = lane % G, gi = lane / G;
+  const int64_t nchunk = (n + RUN_CHUNK - 1) / RUN_CHUNK;
+  for (int64_t ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
+    const int64_t base = ch * RUN_CHUNK;
+    const int64_t i = base + lane;
+    const bool valid = i < n;
+    const int64_t il = valid ? i : n - 1;
+    const KeyT k0 = keys[il];
+    const KeyT kp = keys[il > 0 ? il - 1 : 0];
+    const KeyT knext = keys[base + RUN_CHUNK < n ? base + RUN_CHUNK : n - 1];  // first key of the next chunk
+    const RefPayload me = a.vals[il];
+    const int t = (int)(me.tw >> 1);
+    const float c = -a.lr * a.gz[(int64_t)(me.tw & 1u) * a.B + t];
+    const bool head = il == 0 || kp != k0;                // first reference of the row in this step
+    const bool cont = valid && lane > 0 && !head;         // continues the run of the lane before it
+    const bool lead = valid && !cont;
+    const uint64_t lmask = __ballot(lead), cmask = __ballot(cont);
+    const int nlead = __popcll(lmask);
+    const int rank = __popcll(lmask & (((uint64_t)1 << lane) - 1));
+    if (lead) lead_lane[wv][rank] = (unsigned char)lane;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t klo = (uint32_t)(k0 & (KeyT)0xffffffffu), khi = (uint32_t)((uint64_t)k0 >> 32);
+    // rounds of TPW leaders; round r belongs to wave r % NW; SLOTS rounds per pass
+    for (int r0 = wv; r0 * TPW < nlead; r0 += NW * SI_SLOTS) {
+      int l[SI_SLOTS], len[SI_SLOTS], hd[SI_SLOTS];
+      KeyT keyv[SI_SLOTS];
+      bool has[SI_SLOTS];
+      int64_t row[SI_SLOTS];
+      RowReg<VEC, K> w[SI_SLOTS], u[SI_SLOTS][SI_MEMB];
+      float wl[SI_SLOTS], cm[SI_SLOTS][SI_MEMB];
+#pragma unroll
+      for (int s = 0; s < SI_SLOTS; ++s) {
+        const int want = (r0 + s * NW) * TPW + gi;
+        has[s] = want < nlead;
+        l[s] = has[s] ? (int)lead_lane[wv][want] : 0;
+        const uint64_t after = l[s] < 63 ? (cmask >> (l[s] + 1)) : 0ull;
+        len[s] = 1 + (int)__ffsll((unsigned long long)~after) - 1;
+        const uint64_t key = ((uint64_t)(uint32_t)__shfl((int)khi, l[s], 64) << 32) | (uint32_t)__shfl((int)klo, l[s], 64);
+        keyv[s] = (KeyT)key;
+        hd[s] = __shfl((int)head, l[s], 64);
+        row[s] = has[s] ? (int64_t)((KeyT)key & row_mask) : 0;
+        row_load<VEC, G, K, FULL>(w[s], T.item, row[s], D, lig);
+        wl[s] = T.item_lin[row[s]];
+#pragma unroll
+        for (int j = 0; j < SI_MEMB; ++j) {
+          const int src = l[s] + j < 64 ? l[s] + j : 63;
+          const int tj = __shfl(t, src, 64);
+          const float cj = __shfl(c, src, 64);
+          cm[s][j] = (has[s] && j < len[s]) ? cj : 0.f;
+          row_load<VEC, G, K, FULL>(u[s][j], a.ustage, (int64_t)tj, D, lig);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < SI_SLOTS; ++s) {
+        RowReg<VEC, K> acc;
+        // same order as a sequential walk of the run: c0*u0, then += c*u member by member
+#pragma unroll
+        for (int q = 0; q < N; ++q) acc.v[q] = cm[s][0] * u[s][0].v[q];
+        float lin = cm[s][0];
+#pragma unroll
+        for (int j = 1; j < SI_MEMB; ++j) {
+          // lanes past the run multiply by c = 0; their row bits are cleared too so that a non-finite stranger cannot leak in
+          const uint32_t on = (has[s] && j < len[s]) ? 0xffffffffu : 0u;
+#pragma unroll
+          for (int q = 0; q < N; ++q) acc.v[q] += cm[s][j] * __uint_as_float(__float_as_uint(u[s][j].v[q]) & on);
+          lin += cm[s][j];
+        }
+        if (!has[s]) continue;
+        for (int j = SI_MEMB; j < len[s]; ++j) {  // longer runs (hot rows): one more row per turn
+          const RefPayload pl = a.vals[base + l[s] + j];
+          const int tj = (int)(pl.tw >> 1);
+          const float cj = -a.lr * a.gz[(int64_t)(pl.tw & 1u) * a.B + tj];
+          RowReg<VEC, K> uj;
+          row_load<VEC, G, K, FULL>(uj, a.ustage, (int64_t)tj, D, lig);
+#pragma unroll
+          for (int q = 0; q < N; ++q) acc.v[q] += cj * uj.v[q];
+          lin += cj;
+        }
+        const bool cut_tail = (l[s] + len[s] == RUN_CHUNK) && (base + RUN_CHUNK < n) && knext == keyv[s];
+        float* irow = T.item + row[s] * (int64_t)D;
+        if (hd[s] != 0 && !cut_tail) {
+#pragma unroll
+          for (int q = 0; q < N; ++q) w[s].v[q] += acc.v[q];
+          row_store<VEC, G, K>(w[s], irow, D, lig);
+          if (lig == 0) T.item_lin[row[s]] = wl[s] + lin;
+        } else {  // a cut piece of a long segment (hot row): several groups add into the row
+#pragma unroll
+          for (int kk = 0; kk < K; ++kk) {
+            const int e = (kk * G + lig) * VEC;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q)
+              if (e + q < D) atomicAdd(irow + e + q, acc.v[kk * VEC + q]);
+          }
+          if (lig == 0) atomicAdd(T.item_lin + row[s], lin);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // lead_lane is rewritten by the next chunk
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- user duplicates
 // flags[q] = 1 iff the user of position q is referenced by another triple of the same batch (static for the epoch):
 // sort (batch * 2^user_bits + user, q) and compare neighbours.
@@ -503,11 +625,12 @@ int trs_launch_sorted_item_update(const trs_tables* tables, const void* keys_ste
   }
   const int tpw = TRS_WAVE / c.g;
   const dim3 gr(trs_grid((2 * batch + tpw - 1) / tpw, TRS_BLOCK / TRS_WAVE)), bl(TRS_BLOCK);
+  const dim3 gs(trs_grid((2 * batch + RUN_CHUNK - 1) / RUN_CHUNK, 1));  // staged form: one 64-reference chunk per workgroup
 #define TRS_SL(V, GG, KK, FULL)                                                                                      \
   {                                                                                                                  \
-    if (key_bytes == 4 && ustage) hipLaunchKernelGGL((sorted_item_update_kernel<uint32_t, V, GG, KK, FULL, true>), gr, bl, 0, s, a); \
+    if (key_bytes == 4 && ustage) hipLaunchKernelGGL((sorted_item_update_staged_kernel<uint32_t, V, GG, KK, FULL>), gs, bl, 0, s, a); \
     else if (key_bytes == 4) hipLaunchKernelGGL((sorted_item_update_kernel<uint32_t, V, GG, KK, FULL, false>), gr, bl, 0, s, a);     \
-    else if (ustage) hipLaunchKernelGGL((sorted_item_update_kernel<uint64_t, V, GG, KK, FULL, true>), gr, bl, 0, s, a);              \
+    else if (ustage) hipLaunchKernelGGL((sorted_item_update_staged_kernel<uint64_t, V, GG, KK, FULL>), gs, bl, 0, s, a);             \
     else hipLaunchKernelGGL((sorted_item_update_kernel<uint64_t, V, GG, KK, FULL, false>), gr, bl, 0, s, a);                         \
   }
 #define TRS_CASE(V, GG, KK)                                                                  \
