@@ -731,6 +731,10 @@ int trs_launch_sorted_item_update(const trs_tables* tables, const void* keys_ste
                                   int64_t batch, int64_t item_bits, const float* gz, float lr, uint64_t* uown,
                                   uint32_t* udup, uint32_t stamp, const float* ustage, hipStream_t s);
 int trs_item_bits_for(int64_t n_items);
+int trs_launch_sorted_updates_fused(const trs_tables* tables, const void* keys_step, const void* vals_step,
+                                    int64_t batch, int64_t item_bits, const float* gz, float lr, const float* ustage,
+                                    const void* ukeys_step, const void* uvals_step, int64_t q0, const float* du,
+                                    hipStream_t s);
 int trs_launch_sorted_user_dup_update(const trs_tables* tables, const void* ukeys_step, const void* uvals_step,
                                       int key_bytes, int64_t batch, int64_t q0, const float* du, const float* gz,
                                       float lr, hipStream_t s);
@@ -823,6 +827,18 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
     if (sorted) {  // K2: per-run owner update from the presorted references, then K3
       const char* ks = (const char*)sorted_keys_dev + (int64_t)st * 2 * batch * key_bytes;
       const char* vs = (const char*)sorted_vals_dev + (int64_t)st * 2 * batch * 8;
+      if (inl && key_bytes == 4 && ukey_bytes == 4) {  // item + duplicated-user updates in one launch
+        const char* uk = (const char*)sorted_ukeys_dev + (int64_t)st * batch * 4;
+        const char* uv = (const char*)sorted_uvals_dev + (int64_t)st * batch * 4;
+        rc = trs_launch_sorted_updates_fused(tables, ks, vs, batch, item_bits, a.gz, a.lr, a.ustage, uk, uv,
+                                             slice_pos0 + (int64_t)st * batch, a.du, s);
+        if (rc) return rc;
+        if (ev) {
+          (void)hipEventRecord(ev[2], s);
+          (void)hipEventRecord(ev[3], s);
+        }
+        continue;
+      }
       rc = trs_launch_sorted_item_update(tables, ks, vs, key_bytes, batch, item_bits, a.gz, a.lr,
                                          inl ? nullptr : a.uown, a.udup, a.stamp, inl ? a.ustage : nullptr, s);
       if (rc) return rc;

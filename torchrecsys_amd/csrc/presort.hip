@@ -187,7 +187,7 @@ __global__ __launch_bounds__(TRS_BLOCK) void sorted_item_update_kernel(const Sor
 constexpr int SI_SLOTS = 3, SI_MEMB = 3;
 
 template <typename KeyT, int VEC, int G, int K, bool FULL>
-__global__ __launch_bounds__(TRS_BLOCK) void sorted_item_update_staged_kernel(const SortedArgs a) {
+__device__ __forceinline__ void sorted_item_update_staged_body(const SortedArgs& a, int block_id, int n_blocks) {
   constexpr int N = K * VEC;
   constexpr int TPW = TRS_WAVE / G;
   constexpr int NW = TRS_BLOCK / TRS_WAVE;
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(TRS_BLOCK) void sorted_item_update_staged_kernel(co
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int lig = lane % G, gi = lane / G;
   const int64_t nchunk = (n + RUN_CHUNK - 1) / RUN_CHUNK;
-  for (int64_t ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
+  for (int64_t ch = block_id; ch < nchunk; ch += n_blocks) {
     const int64_t base = ch * RUN_CHUNK;
     const int64_t i = base + lane;
     const bool valid = i < n;
@@ -342,7 +342,7 @@ struct UserDupArgs {
 };
 
 template <typename KeyT, int VEC, int G, int K, bool FULL>
-__global__ __launch_bounds__(TRS_BLOCK) void sorted_user_dup_update_kernel(const UserDupArgs a) {
+__device__ __forceinline__ void sorted_user_dup_update_body(const UserDupArgs& a, int block_id, int n_blocks) {
   constexpr int N = K * VEC;
   constexpr int TPW = TRS_WAVE / G;
   const trs_tables& T = a.T;
@@ -352,8 +352,8 @@ __global__ __launch_bounds__(TRS_BLOCK) void sorted_user_dup_update_kernel(const
   const KeyT user_mask = (KeyT)(((uint64_t)1 << a.user_bits) - 1);
   const int lane = threadIdx.x & 63;
   const int lig = lane % G;
-  const int64_t wave = ((int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x) >> 6;
-  const int64_t nwave = ((int64_t)gridDim.x * TRS_BLOCK) >> 6;
+  const int64_t wave = ((int64_t)block_id * TRS_BLOCK + threadIdx.x) >> 6;
+  const int64_t nwave = ((int64_t)n_blocks * TRS_BLOCK) >> 6;
   const int gi = lane / G;
   // detection: one lane per sorted entry (64 entries per wave), keys and positions in one round of loads; the few run
   // leaders are then spread over the wave's TPW lane groups, which fetch the run's staged gradients and the user row
@@ -424,6 +424,29 @@ __global__ __launch_bounds__(TRS_BLOCK) void sorted_user_dup_update_kernel(const
       if (lig == 0) T.user_lin[user] = wl + (-a.lr) * lin;
     }
   }
+}
+
+template <typename KeyT, int VEC, int G, int K, bool FULL>
+__global__ __launch_bounds__(TRS_BLOCK) void sorted_item_update_staged_kernel(const SortedArgs a) {
+  sorted_item_update_staged_body<KeyT, VEC, G, K, FULL>(a, blockIdx.x, gridDim.x);
+}
+
+template <typename KeyT, int VEC, int G, int K, bool FULL>
+__global__ __launch_bounds__(TRS_BLOCK) void sorted_user_dup_update_kernel(const UserDupArgs a) {
+  sorted_user_dup_update_body<KeyT, VEC, G, K, FULL>(a, blockIdx.x, gridDim.x);
+}
+
+// Both updates of a presorted step in ONE launch (they touch different tables and only depend on K1): the first
+// n_user_blocks workgroups walk the duplicated-user runs, the rest the item chunks.  Saves a kernel boundary and hides
+// the short, latency-bound user pass under the item pass.  32-bit keys on both sides (the common case).
+template <int VEC, int G, int K, bool FULL>
+__global__ __launch_bounds__(TRS_BLOCK) void sorted_updates_fused_kernel(const SortedArgs ia, const UserDupArgs ua,
+                                                                        int n_user_blocks) {
+  if ((int)blockIdx.x < n_user_blocks)
+    sorted_user_dup_update_body<uint32_t, VEC, G, K, FULL>(ua, blockIdx.x, n_user_blocks);
+  else
+    sorted_item_update_staged_body<uint32_t, VEC, G, K, FULL>(ia, (int)blockIdx.x - n_user_blocks,
+                                                              (int)gridDim.x - n_user_blocks);
 }
 
 static int bits_for(int64_t n) {
@@ -658,6 +681,64 @@ int trs_launch_sorted_item_update(const trs_tables* tables, const void* keys_ste
 }
 
 int trs_item_bits_for(int64_t n_items) { return bits_for(n_items); }
+
+// Fused launch of the staged item update and the duplicated-user update (both with 32-bit keys).
+int trs_launch_sorted_updates_fused(const trs_tables* tables, const void* keys_step, const void* vals_step,
+                                    int64_t batch, int64_t item_bits, const float* gz, float lr, const float* ustage,
+                                    const void* ukeys_step, const void* uvals_step, int64_t q0, const float* du,
+                                    hipStream_t s) {
+  SortedArgs ia = {};
+  ia.T = *tables;
+  ia.keys = keys_step;
+  ia.vals = (const RefPayload*)vals_step;
+  ia.B = batch;
+  ia.item_bits = (int)item_bits;
+  ia.gz = gz;
+  ia.lr = lr;
+  ia.ustage = ustage;
+  UserDupArgs ua = {};
+  ua.T = *tables;
+  ua.ukeys = ukeys_step;
+  ua.uvals = (const uint32_t*)uvals_step;
+  ua.B = batch;
+  ua.q0 = q0;
+  ua.user_bits = bits_for(tables->n_users);
+  ua.du = du;
+  ua.gz = gz;
+  ua.lr = lr;
+  RowCfg c;
+  if (!pick_row_cfg(tables->D, c)) {
+    trs_set_error("unsupported n_factors D=%d", tables->D);
+    return TRS_E_ARG;
+  }
+  const int nu = trs_grid((batch + TRS_WAVE - 1) / TRS_WAVE, TRS_BLOCK / TRS_WAVE);
+  const int ni = trs_grid((2 * batch + RUN_CHUNK - 1) / RUN_CHUNK, 1);
+  const dim3 gr(nu + ni), bl(TRS_BLOCK);
+#define TRS_CASE(V, GG, KK)                                                                                      \
+  if (c.vec == V && c.g == GG && c.k == KK) {                                                                    \
+    if (V * GG * KK == tables->D)                                                                                \
+      hipLaunchKernelGGL((sorted_updates_fused_kernel<V, GG, KK, true>), gr, bl, 0, s, ia, ua, nu);              \
+    else                                                                                                         \
+      hipLaunchKernelGGL((sorted_updates_fused_kernel<V, GG, KK, false>), gr, bl, 0, s, ia, ua, nu);             \
+    TRS_CHECK_LAUNCH("sorted_updates_fused_kernel");                                                             \
+    return TRS_OK;                                                                                               \
+  }
+  TRS_CASE(4, 2, 1)
+  TRS_CASE(4, 4, 1)
+  TRS_CASE(4, 8, 1)
+  TRS_CASE(4, 16, 1)
+  TRS_CASE(4, 32, 1)
+  TRS_CASE(4, 64, 1)
+  TRS_CASE(4, 64, 2)
+  TRS_CASE(4, 64, 4)
+  TRS_CASE(1, 4, 1)
+  TRS_CASE(1, 16, 1)
+  TRS_CASE(1, 64, 1)
+  TRS_CASE(1, 64, 4)
+#undef TRS_CASE
+  trs_set_error("internal: no kernel for D=%d", tables->D);
+  return TRS_E_ARG;
+}
 
 int trs_launch_sorted_user_dup_update(const trs_tables* tables, const void* ukeys_step, const void* uvals_step,
                                       int key_bytes, int64_t batch, int64_t q0, const float* du, const float* gz,
