@@ -150,39 +150,46 @@ def main():
     if events:
         def _ms(rec):  # (TimingEvents, i, j) from the C step loop, or (torch start, torch end) from the generic path
             return rec[0].elapsed_ms(rec[1], rec[2]) if len(rec) == 3 else rec[0].elapsed_time(rec[1])
-        mean_ms = {k: sum(_ms(r) for r in v) / len(v) for k, v in events.items()}
+        raw_ms = {k: sum(_ms(r) for r in v) / len(v) for k, v in events.items()}
+        # An interval between two hipEventRecords contains the record's own cost (a barrier packet + timestamp write).
+        # On the presorted path the last two events of a step are recorded back to back, so that cost is measured live
+        # and subtracted; rocprofv3's kernel durations (profiles/) do not contain it.
+        ev_ms = raw_ms.pop("event_overhead", 0.0)
+        mean_ms = {k: max(v - ev_ms, 1e-6) for k, v in raw_ms.items()}
         dom = max(mean_ms, key=mean_ms.get)
+        row = 4 * D + 4  # one embedding row + its 1-wide term
+        inline_user = "sorted_updates_fused_kernel" in mean_ms or "sorted_item_update_kernel" in mean_ms
         # algorithmic bytes per triple of each kernel (DESIGN.md "Kernels"): the forward+backward pass reads the ids and
-        # the R rows (+1-wide terms) once: 16 + R(4D+4) + 8; the update pass writes the R rows once: 12 + R(4D+4)
-        per_triple = {"score_kernel<fwd_bwd>": 16 + R * (4 * D + 4) + 8, "score_sgd_update_kernel": 12 + R * (4 * D + 4),
-                      # fast path (csrc/fast_step.hip): K1 reads the ids + R rows (+1-wide terms); K2 writes the 2 item
-                      # rows (+terms) and needs the user row; K3 writes the user row (+term)
-                      "fwd_stage_kernel": 16 + R * (4 * D + 4) + 8, "item_update_kernel": 12 + 3 * (4 * D + 4),
-                      "user_update_kernel": 4 + (4 * D + 4)}
-        # "item_update_kernel" = sorted_item_update_kernel (presorted references), or the two launches
-        # item_owner_update_kernel (plain) + item_update_kernel<.,2> (atomics) when the presort is off
+        # the R rows once and writes the two loss-gradient scalars; the update passes write the R rows once
+        per_triple = {"score_kernel<fwd_bwd>": 16 + R * row + 8, "score_sgd_update_kernel": 12 + R * row,
+                      # fast path (csrc/fast_step.hip): K1 reads the ids + R rows; on the presorted path it also writes
+                      # the user row (users referenced once per batch are updated in place by K1)
+                      "fwd_stage_kernel": 16 + R * row + 8 + (row if inline_user else 0),
+                      # item updates: write the 2 item rows, need the user row
+                      "item_update_kernel": 12 + 3 * row, "sorted_item_update_kernel": 12 + 3 * row,
+                      "sorted_updates_fused_kernel": 12 + 3 * row,
+                      "user_update_kernel": 4 + row, "sorted_user_dup_update_kernel": 4 + row}
         ach = per_triple[dom] * B / (mean_ms[dom] * 1e-3) / 1e9
         # measured HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
-        # corrected as MI355X_MICROARCH.md prescribes); valid for the c2 workload on one GPU only
+        # corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py); valid for the c2 workload on one GPU only
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if args.config == "c2" and os.path.exists(pmc_path):
             pk = json.load(open(pmc_path))["kernels"]
-            parts = {"item_update_kernel": ("sorted_item_update_kernel",) if "sorted_item_update_kernel" in pk
-                     else ("item_owner_update_kernel", "item_update_kernel"),
-                     "fwd_stage_kernel": ("fwd_stage_kernel",), "user_update_kernel": ("user_plain_update_kernel",)}
-            if all(q in pk for q in parts.get(dom, ("?",))):
-                traffic = sum(pk[q]["traffic_bytes_per_launch"] for q in parts[dom])
+            parts = {"item_update_kernel": ("item_owner_update_kernel", "item_update_kernel")}.get(dom, (dom,))
+            if all(q in pk for q in parts):
+                traffic = sum(pk[q]["traffic_bytes_per_launch"] for q in parts)
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                            "mean_launch_us": {k: 1e3 * v for k, v in mean_ms.items()},
+                           "event_record_overhead_us": 1e3 * ev_ms,
                            "algorithmic_bytes_per_triple": per_triple[dom]}
     # ---- CPU baseline: the op-sequence port of the reference's fit() loop on this box's host cores ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cpu_fit
         cores = min(16, len(os.sched_getaffinity(0)))  # the one-GPU box share (oversubscribing collapses torch CPU ops)
         n_rows = min(n_inter, 4_000_000)
-        res = cpu_fit.time_steps(net, n_users, n_items, D, B, n_rows=n_rows, steps=40, warmup=1, dynamic=dynamic,
+        res = cpu_fit.time_steps(net, n_users, n_items, D, B, n_rows=n_rows, steps=100, warmup=1, dynamic=dynamic,
                                  threads=cores, max_seconds=20.0)
         out["cpu_baseline"] = {"value": res["interactions_per_s"], "unit": "interactions/s", "cores": res["threads"],
                                "kind": "port",

@@ -151,12 +151,12 @@ class SparseScorerTrainer:
             evs[4 * s:4 * s + 4] = [te.handles[4 * j + q] for q in range(4)]
         return te, evs, len(sampled)
 
-    def _collect_events(self, te, n_sampled):
+    def _collect_events(self, te, n_sampled, names=("fwd_stage_kernel", "item_update_kernel", "user_update_kernel")):
+        """names: what ran between the four events of a step (item_update_kernel = phases a + b when not presorted)."""
         ke = self.kernel_events
         for j in range(n_sampled):
-            ke.setdefault("fwd_stage_kernel", []).append((te, 4 * j, 4 * j + 1))
-            ke.setdefault("item_update_kernel", []).append((te, 4 * j + 1, 4 * j + 2))  # phases a + b
-            ke.setdefault("user_update_kernel", []).append((te, 4 * j + 2, 4 * j + 3))
+            for q, name in enumerate(names):
+                ke.setdefault(name, []).append((te, 4 * j + q, 4 * j + q + 1))
 
     def fast_stream_steps(self, st, shuffle_key, sample_seed, first_pos, batch, n_steps, loss_sums):
         """n_steps fused steps straight from the resident stream `st` (dict user/pos/neg int32); loss_sums: (n_steps,)
@@ -253,7 +253,11 @@ class SparseScorerTrainer:
                             self.gz, self.du, loss_sums, self.err, self.scratch, self._stamps(n_steps), evs, sk, sv,
                             ps.key_bytes, udup, self.ustage, usorted)
         if te is not None:
-            self._collect_events(te, ns)
+            # 32-bit keys: item and duplicated-user updates are ONE launch, and the last two events are recorded back to
+            # back — that interval is the cost of an event record itself
+            fused = ps.key_bytes == 4 and ps.ukey_bytes == 4
+            self._collect_events(te, ns, ("fwd_stage_kernel", "sorted_updates_fused_kernel", "event_overhead") if fused
+                                 else ("fwd_stage_kernel", "sorted_item_update_kernel", "sorted_user_dup_update_kernel"))
 
     def fast_array_steps(self, ep, first, batch, n_steps, loss_sums):
         """n_steps fused steps over consecutive batches of host-prepared epoch id arrays `ep` (dict user/pos/neg int32,
