@@ -90,7 +90,8 @@ def main():
     with contextlib.redirect_stdout(io.StringIO()):
         torch.manual_seed(7)
         model = TorchRecSys.from_tensors(users, items, n_users=n_users, n_items=n_items, n_factors=D, net_type=net,
-                                         split_ratio=0.8, dynamic_neg_sampling=dynamic, rng="device", seed=7 + rank)
+                                         split_ratio=0.8, dynamic_neg_sampling=dynamic, rng="device", seed=7 + rank,
+                                         pre_sharded=True)  # every rank generated its own 100M-interaction shard
     del users, items
     opt = torch.optim.SGD(model.parameters(), lr=1e-2)
     runner = model.make_runner(opt, B)

@@ -61,6 +61,15 @@ def _worker(rank, world, port, ret):
         assert torch.allclose(t, torch.full((6, 3), 11.0))
         tot = tdist.allreduce_scalar_sum([1.0, float(rank)], torch.device("cpu"))
         assert tot == [2.0, 1.0]
+        # --- the model's per-rank view of a split: cut by rank, unless the caller ingested its own shard already
+        from torchrecsys_amd.model import TorchRecSys
+        data = {"user_id": torch.arange(10), "pos_item_id": torch.arange(10)}
+        m = TorchRecSys.__new__(TorchRecSys)
+        m._dev_cache = {}
+        s10, e10 = tdist.shard_bounds(10, rank, world)
+        assert torch.equal(m._rank_rows(data)["user_id"], torch.arange(10)[s10:e10])
+        m.pre_sharded = True
+        assert m._rank_rows(data) is data
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()

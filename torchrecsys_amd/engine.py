@@ -10,6 +10,8 @@ Optimiser dispatch:
                                                    gradients autograd would have produced, then optimizer.step().
 Moments live in optimizer.state[p] under torch's own key names, so optimizer.state_dict() stays truthful.
 """
+import os
+
 import torch
 
 from . import ops
@@ -177,7 +179,8 @@ class SparseScorerTrainer:
         """Most item rows get several references per step when 2B is a sizeable fraction of n_items: then grouping the
         references by row once per epoch slice removes the float atomics from the item update."""
         n_items = self.params[1].shape[0]
-        if self.fast_lr is None or 2 * batch < 0.25 * n_items:
+        dense = float(os.environ.get("TRS_PRESORT_MIN_DENSITY", "0.25"))  # tuning knob: 0 = always, inf = never
+        if self.fast_lr is None or 2 * batch < dense * n_items:
             return False
         memo = self.__dict__.setdefault("_ps_fits", {})
         if batch not in memo:  # decided once: two buffer sets (one being sorted while the other is read)

@@ -80,9 +80,11 @@ class TorchRecSys(torch.nn.Module):
     def from_tensors(cls, user_ids, item_ids, n_users=None, n_items=None, item_metadata=None, metadata_names=None,
                      n_factors=80, net_type='linear', split_ratio=0.8, dynamic_neg_sampling=False, use_amp=False,
                      use_cuda=False, debug=False, path='./', hidden_layers=None, use_batch_norm=True, rng=None,
-                     seed=0):
+                     seed=0, pre_sharded=False):
         """Tensor-native ingest (no DataFrame): id tensors on the CPU or already in HBM.  GPU tensors default to
-        rng='device' (stream resident in HBM, on-device shuffle and sampler)."""
+        rng='device' (stream resident in HBM, on-device shuffle and sampler).  pre_sharded=True: under data parallelism
+        the given interactions already ARE this rank's shard (each rank ingested its own part), so they are not cut
+        again by rank."""
         from .dataset.dataset import TensorProcessData
         self = cls.__new__(cls)
         torch.nn.Module.__init__(self)
@@ -94,6 +96,7 @@ class TorchRecSys(torch.nn.Module):
             raise ValueError("GPU-resident id tensors require rng='device'")
         self._setup(dp, dp.metadata_id_col, n_factors, net_type, dynamic_neg_sampling, use_amp, use_cuda, debug, path,
                     hidden_layers, use_batch_norm, rng, seed)
+        self.pre_sharded = bool(pre_sharded)
         return self
 
     def _setup(self, data_processor, metadata_id_col, n_factors, net_type, dynamic_neg_sampling, use_amp, use_cuda,
@@ -197,7 +200,7 @@ class TorchRecSys(torch.nn.Module):
     def _rank_rows(self, data):
         """This rank's contiguous shard of a split under data parallelism (the whole split in a single process)."""
         rank, world = tdist.world_info()
-        if world == 1:
+        if world == 1 or getattr(self, "pre_sharded", False):
             return data
         key = id(data)
         if self._dev_cache.get('shard_key') != key:
