@@ -400,7 +400,7 @@ class FitRunner:
             while done < k and self.next_batch < full:
                 n = min(k - done, full - self.next_batch, 64)
                 b = self.next_batch
-                if presort:  # dense regime: item references grouped by row per slice of batches (csrc/presort.hip)
+                if presort:  # item references grouped by row per slice of batches (csrc/presort.hip)
                     sl = self.trainer.SLICE_BATCHES
                     if self._slice is None or not (self._slice[0] <= b < self._slice[0] + self._slice[1].n_batches):
                         s0 = (b // sl) * sl
