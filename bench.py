@@ -30,16 +30,32 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md "Chip-level parameters")
 
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # dense matrix peaks (MI355X_MICROARCH.md), no sparsity
+
 CONFIGS = {
-    # name: (net, n_users, n_items, interactions, D, batch, description)
-    "c2": ("fm", 1_000_000, 100_000, 100_000_000, 64, 65_536,
-           "c2: net_type='fm', 1M users x 100K items x 100M interactions, dim=64, dynamic_neg_sampling=True, "
-           "batch 65536, SGD(lr=1e-2), fp32"),
-    "c1": ("linear", 3_000, 1_000, 100_000, 32, 1_024,
-           "c1: net_type='linear', 3000 users x 1000 items x 100000 interactions, dim=32, batch 1024, static negatives"),
-    "c4": ("fm", 10_000_000, 1_000_000, 125_000_000, 128, 32_768,
-           "c4 per-GPU shard: net_type='fm', 10M users x 1M items, 125M-interaction shard of 1B, dim=128, "
-           "per-GPU batch 32768 (global 262144 at 8 GPUs)"),
+    # name: net, n_users, n_items, interactions generated per rank, D, per-GPU batch, [metadata category counts],
+    #       [hidden layers], bf16 GEMM inputs, description
+    "c2": dict(net="fm", n_users=1_000_000, n_items=100_000, n=100_000_000, D=64, B=65_536, meta=[], hidden=None,
+               amp=False,
+               desc="c2: net_type='fm', 1M users x 100K items x 100M interactions, dim=64, dynamic_neg_sampling=True, "
+                    "batch 65536, SGD(lr=1e-2), fp32"),
+    "c1": dict(net="linear", n_users=3_000, n_items=1_000, n=100_000, D=32, B=1_024, meta=[], hidden=None, amp=False,
+               desc="c1: net_type='linear', 3000 users x 1000 items x 100000 interactions, dim=32, batch 1024, "
+                    "static negatives"),
+    "c4": dict(net="fm", n_users=10_000_000, n_items=1_000_000, n=125_000_000, D=128, B=32_768, meta=[], hidden=None,
+               amp=False,
+               desc="c4 per-GPU shard: net_type='fm', 10M users x 1M items, 125M-interaction shard of 1B, dim=128, "
+                    "per-GPU batch 32768 (global 262144 at 8 GPUs)"),
+    "c3": dict(net="mlp", n_users=1_000_000, n_items=100_000, n=100_000_000, D=128, B=65_536, meta=[10_000],
+               hidden=[512, 256, 128], amp=False,
+               desc="c3: net_type='mlp' hidden [512,256,128] + BatchNorm, 1M users x 100K items + 1 metadata column "
+                    "(10K categories) x 100M interactions, dim=128, dynamic_neg_sampling=True, batch 65536, "
+                    "SGD(lr=1e-2), fp32"),
+    "c5": dict(net="mlp", n_users=10_000_000, n_items=1_000_000, n=125_000_000, D=256, B=32_768,
+               meta=[10_000, 10_000, 10_000], hidden=[1024, 512, 256], amp=True,
+               desc="c5 per-GPU shard: net_type='mlp' hidden [1024,512,256] + BatchNorm, 10M users x 1M items + 3 "
+                    "metadata columns (10K categories each), 125M-interaction shard of 1B, dim=256, bf16 GEMM inputs / "
+                    "fp32 accumulate, per-GPU batch 32768 (global 262144 at 8 GPUs), SGD(lr=1e-2)"),
 }
 
 
@@ -82,16 +98,29 @@ def main():
     from torchrecsys_amd.model import TorchRecSys
     _lib.check(_lib.load().trs_check_device(), "trs_check_device")
 
-    net, n_users, n_items, n_inter, D, B, desc = CONFIGS[args.config]
+    cfg = CONFIGS[args.config]
+    net, n_users, n_items, n_inter, D, B, desc = (cfg[k] for k in ("net", "n_users", "n_items", "n", "D", "B", "desc"))
     dynamic = args.config != "c1"
     users, items = synth_stream(n_users, n_items, n_inter, dev, seed=1000 + rank)
+    meta = None
+    if cfg["meta"]:  # one categorical id per item and column, every category present
+        g = torch.Generator(device=dev)
+        g.manual_seed(5)
+        cols = []
+        for nc in cfg["meta"]:
+            c = torch.randint(0, nc, (n_items,), device=dev, dtype=torch.int32, generator=g)
+            c[:nc] = torch.arange(nc, device=dev, dtype=torch.int32)
+            cols.append(c)
+        meta = torch.stack(cols, dim=1).contiguous()
     import contextlib
     import io
     with contextlib.redirect_stdout(io.StringIO()):
         torch.manual_seed(7)
-        model = TorchRecSys.from_tensors(users, items, n_users=n_users, n_items=n_items, n_factors=D, net_type=net,
-                                         split_ratio=0.8, dynamic_neg_sampling=dynamic, rng="device", seed=7 + rank,
-                                         pre_sharded=True)  # every rank generated its own 100M-interaction shard
+        kw = dict(hidden_layers=cfg["hidden"]) if net == "mlp" else {}
+        model = TorchRecSys.from_tensors(users, items, n_users=n_users, n_items=n_items, item_metadata=meta,
+                                         n_factors=D, net_type=net, split_ratio=0.8, dynamic_neg_sampling=dynamic,
+                                         use_amp=cfg["amp"], rng="device", seed=7 + rank, pre_sharded=True, **kw)
+        # pre_sharded: every rank generated its own interaction shard
     del users, items
     opt = torch.optim.SGD(model.parameters(), lr=1e-2)
     runner = model.make_runner(opt, B)
@@ -119,14 +148,22 @@ def main():
 
     run(args.warmup)
     barrier()
+    is_mlp = net == "mlp"
     if not args.no_kernel_events:
-        runner.trainer.kernel_events = {}
+        if is_mlp:
+            model.net.compute.gemm_events = []
+        else:
+            runner.trainer.kernel_events = {}
     t0 = time.perf_counter()
     run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    events = runner.trainer.kernel_events or {}
-    runner.trainer.kernel_events = None
+    events = (getattr(runner.trainer, "kernel_events", None) or {}) if not is_mlp else {}
+    gemm_events = model.net.compute.gemm_events if is_mlp else None
+    if is_mlp:
+        model.net.compute.gemm_events = None
+    else:
+        runner.trainer.kernel_events = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -135,18 +172,39 @@ def main():
 
     triples = args.steps * B * world
     value = 2.0 * triples / elapsed
-    R = 3
+    M = len(cfg["meta"])
+    R = 3 + 2 * M
     step_bytes = 16 + 2 * R * (4 * D + 4)  # FM/Linear fused SGD step, rows read once + written once
+    dtype = "bf16" if cfg["amp"] else "f32"
     out = {
         "metric": "training interactions/sec (pos+neg)", "value": value, "unit": "interactions/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {"workload": desc, "global_batch": B * world, "per_gpu_batch": B,
-                   "parallelism": f"dp{world}: interaction stream sharded, tables replicated, no per-step collective "
-                                  f"(FM/Linear have no dense parameters)",
+                   "parallelism": (f"dp{world}: interaction stream sharded, tables replicated, one flat all-reduce of the "
+                                   f"dense gradients per step" if is_mlp else
+                                   f"dp{world}: interaction stream sharded, tables replicated, no per-step collective "
+                                   f"(FM/Linear have no dense parameters)"),
                    "rng": "device (Feistel epoch shuffle + Philox4x32-10 negative sampler)"},
-        "step_algorithmic_GBps_per_gpu": step_bytes * B * args.steps / elapsed / 1e9,
     }
+    if not is_mlp:
+        out["step_algorithmic_GBps_per_gpu"] = step_bytes * B * args.steps / elapsed / 1e9
+    # ---- MLP: the GEMMs are the dominant kernels, bound by the matrix cores ----
+    if gemm_events:
+        dims = [(2 + M) * D] + list(cfg["hidden"])
+        P = sum(a_ * b_ for a_, b_ in zip(dims[:-1], dims[1:])) + dims[-1]  # MACs per sample
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in gemm_events)
+        fl = sum(f for _, _, f in gemm_events)
+        ach = fl / (ms * 1e-3) / 1e12
+        peak = MFMA_PEAK_TFLOPS[dtype]
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel" if cfg["amp"] else "gemm_f32_kernel",
+                           "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                           "gemm_launches_per_step": len(gemm_events) / args.steps,
+                           "gemm_ms_per_step": ms / args.steps, "gemm_share_of_step": ms / (1e3 * elapsed),
+                           "algorithmic_flops_per_triple": 12 * P,
+                           "whole_step_TFLOPs": 12.0 * P * B * args.steps / elapsed / 1e12,
+                           "note": "event intervals around the GEMM launches (HIP events on the launch stream); they "
+                                   "include one event record each"}
     # ---- roofline of the dominant kernel: algorithmic bytes per launch / mean launch duration (HIP events) ----
     if events:
         def _ms(rec):  # (TimingEvents, i, j) from the C step loop, or (torch start, torch end) from the generic path
@@ -191,7 +249,7 @@ def main():
         cores = min(16, len(os.sched_getaffinity(0)))  # the one-GPU box share (oversubscribing collapses torch CPU ops)
         n_rows = min(n_inter, 4_000_000)
         res = cpu_fit.time_steps(net, n_users, n_items, D, B, n_rows=n_rows, steps=100, warmup=1, dynamic=dynamic,
-                                 threads=cores, max_seconds=20.0)
+                                 threads=cores, max_seconds=20.0, meta_cats=cfg["meta"], hidden=cfg["hidden"])
         out["cpu_baseline"] = {"value": res["interactions_per_s"], "unit": "interactions/s", "cores": res["threads"],
                                "kind": "port",
                                "sample": f"{res['steps']} steps of batch {B} ({res['seconds']:.1f} s) on full-size "

@@ -245,9 +245,10 @@ int trs_topk(const float* scores_dev, int64_t n, int32_t k, int64_t* idx_out_dev
  * model.py:171-185).  Workspaces are caller-allocated fp32 arrays of the size the *_workspace_* helpers return. */
 
 /* x0 = [user[u] | item[i] | meta_0[..] | ...] (collaborative/mlp.py:93-105): positive pass into rows [0,B) of x and,
- * when passes == 2, the negative pass into rows [B,2B); row stride ld >= (2+M)*D floats. */
-int trs_mlp_gather_concat(const trs_tables* tables, const trs_batch* batch, int32_t passes, float* x_dev, int64_t ld,
-                          void* stream);
+ * when passes == 2, the negative pass into rows [B,2B); row stride ld >= (2+M)*D elements.  x_dev (fp32) and/or
+ * x_bf16_dev (bf16, RNE: the operand image of the bf16-resident GEMMs) — either may be NULL. */
+int trs_mlp_gather_concat(const trs_tables* tables, const trs_batch* batch, int32_t passes, float* x_dev,
+                          void* x_bf16_dev, int64_t ld, void* stream);
 
 /* C(M,N) = alpha * op(A)(M,K) * op(B)(K,N) + beta * C [+ bias(N) on every row], fp32 in / fp32 accumulate on
  * v_mfma_f32_32x32x2_f32 (an exact fp32 FMA chain).  Row-major; transA: 0 = A stored (M,K), 1 = stored (K,M);
@@ -271,6 +272,22 @@ int trs_gemm_bf16(int transA, int transB, int64_t M, int64_t N, int64_t K, float
                   const float* bias_dev, float* bn_part_dev, void* workspace_dev, int64_t workspace_bytes,
                   void* stream);
 
+/* bf16-RESIDENT GEMM of the use_amp path (activations and weight images already stored as bf16 in HBM; fp32
+ * accumulation and fp32 output; same epilogue options as trs_gemm_f32).  tn = 0: C(M,N) = alpha * A(M,K) B(N,K)^T, both
+ * operands k-contiguous (forward with W, dgrad with the transposed weight image); tn = 1: C(M,N) = alpha * A(K,M)^T
+ * B(K,N) (wgrad dW = dy^T x: both operands "one row per sample"; fragments come out of the transposing LDS read
+ * ds_read_b64_tr_b16).  M, N multiples of 128, K a multiple of 64, 16-byte aligned rows (lda, ldb in bf16 elements,
+ * multiples of 8).  Replaces the reference's autocast `linear` (model.py:86-88,192-195; SURVEY 8a7: bf16 inputs, fp32
+ * accumulate, no loss scaling). */
+int64_t trs_gemm_bf16in_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int trs_gemm_bf16in(int tn, int64_t M, int64_t N, int64_t K, float alpha, const void* A_dev, int64_t lda,
+                    const void* B_dev, int64_t ldb, float beta, float* C_dev, int64_t ldc, const float* bias_dev,
+                    float* bn_part_dev, void* workspace_dev, int64_t workspace_bytes, void* stream);
+/* dst (rows, cols) bf16 copy and/or dst_t (cols, rows) transposed bf16 copy of an fp32 matrix (either may be NULL):
+ * the per-step refresh of the weight images the bf16-resident GEMMs read. */
+int trs_f32_to_bf16(const float* src_dev, int64_t rows, int64_t cols, int64_t ld, void* dst_dev, void* dst_t_dev,
+                    void* stream);
+
 /* Train-mode BatchNorm1d statistics of y (passes*rows_per_pass, H) per pass: mean_out/var_out (passes,H), biased
  * variance (chunked two-pass + Chan combination in fp64).  running_mean/var (H) non-NULL: updated once per pass in
  * pass order with `momentum` and the unbiased variance (torch.nn.BatchNorm1d under collaborative/mlp.py:82,110).
@@ -287,22 +304,24 @@ int trs_bn_stats_finalize(const float* part_dev, int64_t rows_per_pass, int32_t 
                           float* running_var_dev, void* stream);
 
 /* out = relu(((y - mean) / sqrt(var + eps)) * gamma + beta)  (use_bn = 0: out = relu(y)); statistics indexed per
- * pass when stat_passes == passes, shared when stat_passes == 1 (eval mode: running statistics).
+ * pass when stat_passes == passes, shared when stat_passes == 1 (eval mode: running statistics).  out_dev (fp32)
+ * and/or out_bf16_dev (bf16 image for the bf16-resident GEMMs; needs H % 4 == 0), same row stride ldo in elements.
  * (collaborative/mlp.py:108-112) */
 int trs_bn_relu_forward(const float* y_dev, int64_t rows_per_pass, int32_t passes, int32_t H, int64_t ld,
                         int32_t use_bn, int32_t stat_passes, const float* mean_dev, const float* var_dev,
-                        const float* gamma_dev, const float* beta_dev, float eps, float* out_dev, int64_t ldo,
-                        void* stream);
+                        const float* gamma_dev, const float* beta_dev, float eps, float* out_dev, void* out_bf16_dev,
+                        int64_t ldo, void* stream);
 
 /* Backward of relu(bn(y)) in train mode from dx = dL/d(out): dy (same shape), dgamma/dbeta (H) summed over both
  * passes.  use_bn = 0: dy = dx * [y > 0].  dy_colsum_dev (H, may be NULL): column sums of dy = the gradient of the
- * preceding Linear's bias, summed per pass first like trs_colsum.  workspace: trs_bn_backward_workspace_floats(...)
- * floats. */
+ * preceding Linear's bias, summed per pass first like trs_colsum.  dy_dev (fp32) and/or dy_bf16_dev (bf16 image for
+ * the bf16-resident GEMMs; needs H % 4 == 0), row stride ldd elements.  workspace:
+ * trs_bn_backward_workspace_floats(...) floats. */
 int64_t trs_bn_backward_workspace_floats(int64_t rows_per_pass, int32_t H, int32_t passes);
 int trs_bn_relu_backward(const float* y_dev, const float* dx_dev, int64_t rows_per_pass, int32_t passes, int32_t H,
                          int64_t ld, int64_t ldd, int32_t use_bn, const float* mean_dev, const float* var_dev,
-                         const float* gamma_dev, const float* beta_dev, float eps, float* dy_dev, float* dgamma_dev,
-                         float* dbeta_dev, float* dy_colsum_dev, float* workspace_dev, void* stream);
+                         const float* gamma_dev, const float* beta_dev, float eps, float* dy_dev, void* dy_bf16_dev,
+                         float* dgamma_dev, float* dbeta_dev, float* dy_colsum_dev, float* workspace_dev, void* stream);
 
 /* out[h] = sum_r w[r] * x[r][h] over the passes*rows_per_pass rows (row_weight NULL: plain column sums): bias
  * gradients and the output layer's weight gradient.  Summed per pass first (identical chunking in both passes), so a

@@ -48,6 +48,30 @@ class _Tables(torch.nn.Module):
         return (self.user(u) * self.item(i)).sum(1).view(-1, 1) + self.user1(u) + self.item1(i)
 
 
+class _MLPTables(torch.nn.Module):
+    """Op sequence of collaborative/mlp.py:66-115: sparse embeddings, concat, (Linear, BatchNorm1d, relu)*, Linear."""
+
+    def __init__(self, n_users, n_items, D, meta_cats, hidden):
+        super().__init__()
+        E = torch.nn.Embedding
+        self.user = E(n_users, D, sparse=True)
+        self.item = E(n_items, D, sparse=True)
+        self.meta = torch.nn.ModuleList([E(c, D, sparse=True) for c in meta_cats])
+        with torch.no_grad():
+            for t in [self.user, self.item, *self.meta]:
+                t.weight.normal_(0, 1.0 / D)
+        dims = [(2 + len(meta_cats)) * D] + list(hidden)
+        self.fcs = torch.nn.ModuleList([torch.nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:])])
+        self.bns = torch.nn.ModuleList([torch.nn.BatchNorm1d(b) for b in dims[1:]])
+        self.out = torch.nn.Linear(dims[-1], 1)
+
+    def score(self, u, i, m):
+        x = torch.cat([self.user(u), self.item(i)] + [t(m[:, k]) for k, t in enumerate(self.meta)], dim=1)
+        for fc, bn in zip(self.fcs, self.bns):
+            x = torch.relu(bn(fc(x)))
+        return self.out(x)
+
+
 def _sample_loop(pos_list, n_items):
     out = []
     for p in pos_list:
@@ -59,7 +83,7 @@ def _sample_loop(pos_list, n_items):
 
 
 def time_steps(net_type, n_users, n_items, D, batch_size, n_rows, steps, warmup=1, dynamic=True, lr=1e-2, threads=None,
-               seed=7, max_seconds=30.0):
+               seed=7, max_seconds=30.0, meta_cats=(), hidden=None):
     """Run `warmup` + up to `steps` training steps on a synthetic stream of `n_rows` interactions and return
     {"interactions_per_s", "steps", "seconds", "threads"}.  Stops early once `max_seconds` of timed work is reached."""
     if threads:
@@ -69,7 +93,13 @@ def time_steps(net_type, n_users, n_items, D, batch_size, n_rows, steps, warmup=
     users = torch.randint(0, n_users, (n_rows,))
     items = torch.randint(0, n_items, (n_rows,))
     static_neg = torch.randint(0, n_items, (n_rows,))
-    net = _Tables(net_type, n_users, n_items, D)
+    is_mlp = net_type == "mlp"
+    if is_mlp:
+        net = _MLPTables(n_users, n_items, D, list(meta_cats), list(hidden))
+        item_meta = torch.stack([torch.randint(0, c, (n_items,)) for c in meta_cats], dim=1) if meta_cats else \
+            torch.zeros((n_items, 0), dtype=torch.long)
+    else:
+        net = _Tables(net_type, n_users, n_items, D)
     opt = torch.optim.SGD(net.parameters(), lr=lr)
     perm = torch.randperm(n_rows)
     done, t_total, i = 0, 0.0, 0
@@ -83,7 +113,10 @@ def time_steps(net_type, n_users, n_items, D, batch_size, n_rows, steps, warmup=
             n = torch.tensor(_sample_loop(p.tolist(), n_items), dtype=torch.long)
         else:
             n = static_neg[idx]
-        pos, neg = net.score(u, p), net.score(u, n)
+        if is_mlp:  # metadata of an item by table lookup (the reference walks a dict per row, dataset.py:391-396)
+            pos, neg = net.score(u, p, item_meta[p]), net.score(u, n, item_meta[n])
+        else:
+            pos, neg = net.score(u, p), net.score(u, n)
         loss = torch.clamp(neg - pos + 1.0, 0.0).mean()
         opt.zero_grad()
         loss.backward()

@@ -320,6 +320,38 @@ def test_gemm_split_k_wgrad_shape_and_strided_views():
     assert rel_err(out_f.cpu().numpy(), dy.astype(np.float64).T @ x.astype(np.float64)) < 3e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (384, 256, 448), (128, 384, 64 * 37)])
+def test_gemm_bf16_resident_nt_and_tn(M, N, K):
+    """bf16 operands in HBM, fp32 accumulate: exact products of the bf16 values, so the fp64 product of the SAME rounded
+    operands is matched to fp32 summation accuracy.  tn: both operands stored one row per k (ds_read_b64_tr_b16)."""
+    ops = _ops()
+    rs = np.random.RandomState(M + N + K)
+    A = torch.from_numpy(rs.normal(0, 1, (M, K)).astype(np.float32)).to(DEV)
+    Bm = torch.from_numpy(rs.normal(0, 1, (N, K)).astype(np.float32)).to(DEV)
+    bias = torch.from_numpy(rs.normal(0, 1, N).astype(np.float32)).to(DEV)
+    Ab, Bb = A.to(torch.bfloat16), Bm.to(torch.bfloat16)
+    ref = Ab.double().cpu().numpy() @ Bb.double().cpu().numpy().T
+    out = ops.gemm_bf16in(False, Ab, Bb, bias=bias)
+    assert rel_err(out.cpu().numpy(), ref + bias.cpu().numpy()[None, :]) < 2e-6
+    out_t = ops.gemm_bf16in(True, Ab.t().contiguous(), Bb.t().contiguous())  # (K,M), (K,N)
+    assert rel_err(out_t.cpu().numpy(), ref) < 2e-6
+    # weight images: bf16 copy + transposed copy, RNE like torch
+    w = torch.from_numpy(rs.normal(0, 1, (70, 45)).astype(np.float32)).to(DEV)
+    d, dt = torch.empty((70, 45), dtype=torch.bfloat16, device=DEV), torch.empty((45, 70), dtype=torch.bfloat16, device=DEV)
+    ops.f32_to_bf16(w, d, dt)
+    assert torch.equal(d, w.to(torch.bfloat16)) and torch.equal(dt, w.to(torch.bfloat16).t().contiguous())
+
+
+def test_gemm_bf16_resident_split_k_wgrad_shape():
+    ops = _ops()
+    rs = np.random.RandomState(3)
+    rows = 64 * 300
+    dy = torch.from_numpy(rs.normal(0, 1, (rows, 256)).astype(np.float32)).to(DEV).to(torch.bfloat16)
+    x = torch.from_numpy(rs.normal(0, 1, (rows, 384)).astype(np.float32)).to(DEV).to(torch.bfloat16)
+    out = ops.gemm_bf16in(True, dy, x)
+    assert rel_err(out.cpu().numpy(), dy.double().cpu().numpy().T @ x.double().cpu().numpy()) < 3e-6
+
+
 @pytest.mark.parametrize("B,H", [(64, 32), (1000, 130), (5000, 7), (256, 512)])
 @pytest.mark.parametrize("passes", [1, 2])
 def test_bn_stats_forward_backward(B, H, passes):

@@ -344,3 +344,39 @@ def test_mlp_bf16_amp_tracks_fp32():
         a, c = out[True][2][k].reshape(-1).astype(np.float64), out[False][2][k].reshape(-1).astype(np.float64)
         assert a @ c / (np.linalg.norm(a) * np.linalg.norm(c)) > 0.97, k
     assert not np.array_equal(out[True][0], out[False][0])  # the bf16 path really ran
+
+
+@pytest.mark.parametrize("use_bn", [True, False])
+def test_mlp_bf16_resident_path_tracks_fp32(use_bn):
+    """use_amp on tile-aligned shapes: layer inputs and BN-backward outputs live in HBM as bf16 and the nine GEMMs of a
+    step run on the bf16-resident kernels (forward / dgrad through weight images, wgrad through the transposing LDS
+    read).  A training step matches the fp32 step at bf16 tolerance, and the two bf16 implementations (resident vs
+    fp32-staged, same rounding points except the stored activations) agree closely."""
+    from torchrecsys_amd.model import TorchRecSys
+    rs = np.random.RandomState(0)
+    n_u, n_i, n, B = 500, 300, 4096, 256
+    users = torch.from_numpy(np.concatenate([np.arange(n_u), rs.randint(0, n_u, n - n_u)]).astype(np.int64))
+    items = torch.from_numpy(np.concatenate([np.arange(n_i), rs.randint(0, n_i, n - n_i)]).astype(np.int64))
+    res = {}
+    for mode in ("fp32", "amp"):
+        seed(11)
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = TorchRecSys.from_tensors(users, items, n_users=n_u, n_items=n_i, n_factors=64, net_type="mlp",
+                                             hidden_layers=[256, 128], use_batch_norm=use_bn, use_amp=(mode == "amp"),
+                                             dynamic_neg_sampling=True, rng="reference")
+        net = model.net
+        net.train()
+        dev = net.user.weight.device
+        ids = {"user": torch.arange(B, device=dev) % n_u, "pos": (torch.arange(B, device=dev) * 7) % n_i,
+               "neg": (torch.arange(B, device=dev) * 13 + 5) % n_i}
+        assert net.compute._resident(2 * B, True) == (mode == "amp")
+        scores, ctx = net.compute.forward(ids, 2, True)
+        g = torch.cat([torch.full((B,), -1.0 / B, device=dev), torch.full((B,), 1.0 / B, device=dev)])
+        grads, dx0 = net.compute.backward(ctx, g)
+        res[mode] = (scores.cpu().numpy(), dx0.cpu().numpy(),
+                     {n_: grads[p].cpu().numpy() for n_, p in net.named_parameters() if p in grads})
+    assert rel_err(res["amp"][0], res["fp32"][0]) < 3e-2
+    for a, c in [(res["amp"][1], res["fp32"][1])] + [(res["amp"][2][k], res["fp32"][2][k])
+                                                       for k in ("fcs.0.weight", "fcs.1.weight", "output_layer.weight")]:
+        a, c = a.reshape(-1).astype(np.float64), c.reshape(-1).astype(np.float64)
+        assert a @ c / (np.linalg.norm(a) * np.linalg.norm(c)) > 0.985

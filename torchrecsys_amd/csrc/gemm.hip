@@ -398,6 +398,168 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
   if (g.bn_part) gemm_tile_bn_stats(g, acc, reinterpret_cast<float*>(&As[0][0]), m0, n0, wm, wn, lr, lk, by);
 }
 
+// ---- bf16-RESIDENT variant (the MLP's use_amp path): operands already live in HBM as bf16, so a 128 x 64 operand
+// tile is 16 KB instead of the 32 KB (read as fp32) of a 32-deep tile above and needs no conversion while staging.
+//   TN = false: A stored (M,K), B stored (N,K), k contiguous: LDS images [m|n][k] (rows padded to 72 bf16 = 144 B, so
+//               the 16 lanes of a ds_read_b128 group hit 16 distinct 16-B slots); a lane's fragment = one ds_read_b128.
+//   TN = true : A stored (K,M), B stored (K,N) (wgrad: dW = dy^T x, both operands "row = sample"): the tile is copied
+//               into LDS as it lies ([k][m|n], 16-B chunks along m) and the MFMA fragments — 8 consecutive k of one
+//               m — come out of ds_read_b64_tr_b16, the gfx950 transposing LDS read: per 16-lane group it reads a block
+//               of 4 rows (k) x 16 columns (m) and hands lane i column i.  Row stride 160 bf16 = 80 dwords = 16 (mod 64
+//               banks): the four rows of a block cover the 64 banks exactly once.
+// Interior tiles only (M, N % 128 == 0, K % 64 == 0 per split, 16-B aligned rows): checked on the host.
+constexpr int BK2 = 64;
+constexpr int NT_ROW = 72;    // bf16 per LDS row of an [m][k] image (64 + 8 pad)
+constexpr int TN_ROW = 160;   // bf16 per LDS row of a [k][m] image (128 + 32 pad)
+using i16x4 = __attribute__((ext_vector_type(4))) short;
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+
+struct Gemm16Args {
+  const unsigned short* A;
+  const unsigned short* B;
+  float* C;
+  const float* bias;
+  int64_t M, N, K;
+  int64_t lda, ldb, ldc;
+  float alpha, beta;
+  int64_t k_per_split;
+  float* slabs;
+  int gx, gy, splits;
+  float* bn_part;
+};
+
+// one 128 x 64 (NT) or 64 x 128 (TN) bf16 tile = 1024 16-byte chunks, 4 per thread
+template <bool TN>
+__device__ __forceinline__ void tile16_load(i32x4 (&r)[4], const unsigned short* __restrict__ P, int64_t ld,
+                                            int64_t row0, int64_t k0, int tid) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int c = tid + 256 * it;
+    const unsigned short* p = TN ? P + (k0 + (c >> 4)) * ld + row0 + ((c & 15) << 3)   // 16 chunks per k-row of 128
+                                 : P + (row0 + (c >> 3)) * ld + k0 + ((c & 7) << 3);   // 8 chunks per row of 64 k
+    r[it] = *reinterpret_cast<const i32x4*>(p);
+  }
+}
+template <bool TN>
+__device__ __forceinline__ void tile16_store(const i32x4 (&r)[4], unsigned short* __restrict__ S, int tid) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int c = tid + 256 * it;
+    unsigned short* d = TN ? S + (c >> 4) * TN_ROW + ((c & 15) << 3) : S + (c >> 3) * NT_ROW + ((c & 7) << 3);
+    *reinterpret_cast<i32x4*>(d) = r[it];
+  }
+}
+
+template <bool TN>
+__global__ __launch_bounds__(256) void gemm_bf16in_kernel(const Gemm16Args g) {
+  constexpr int IMG = TN ? BK2 * TN_ROW : BM * NT_ROW;  // bf16 elements per operand image
+  __shared__ __attribute__((aligned(16))) unsigned short As[2][IMG];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[2][IMG];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int64_t lid = blockIdx.x;
+  const int64_t nwg = gridDim.x;
+  if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);  // XCD-aware tile order (see gemm_f32_kernel)
+  const int bx = (int)(lid % g.gx);
+  const int by = (int)((lid / g.gx) % g.gy);
+  const int bz = (int)(lid / ((int64_t)g.gx * g.gy));
+  const int64_t m0 = (int64_t)by * BM, n0 = (int64_t)bx * BN;
+  const int64_t kbeg = (int64_t)bz * g.k_per_split;
+  const int64_t kend = (kbeg + g.k_per_split < g.K) ? kbeg + g.k_per_split : g.K;
+  const int64_t nk = (kend - kbeg) / BK2;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int lr = lane & 31, lk = lane >> 5;
+  // TN fragment addressing: 16-lane group gq = lane / 16 reads m-columns (gq & 1) * 16 .. +15 and k-rows
+  // (gq >> 1) * 8 .. +7 in two blocks of 4 rows; lane 4q + p of the group supplies row q, columns 4p .. 4p+3
+  const int gq = lane >> 4, li = lane & 15;
+  const int tr_off = (((gq >> 1) * 8 + (li >> 2)) * TN_ROW + (gq & 1) * 16 + ((li & 3) << 2));
+
+  i32x4 ra[4], rb[4];
+  tile16_load<TN>(ra, g.A, g.lda, m0, kbeg, tid);
+  tile16_load<TN>(rb, g.B, g.ldb, n0, kbeg, tid);
+  tile16_store<TN>(ra, As[0], tid);
+  tile16_store<TN>(rb, Bs[0], tid);
+  __syncthreads();
+  for (int64_t kt = 0; kt < nk; ++kt) {
+    const int cur = (int)(kt & 1);
+    const int64_t kn = kbeg + (kt + 1 < nk ? kt + 1 : kt) * BK2;
+    tile16_load<TN>(ra, g.A, g.lda, m0, kn, tid);
+    tile16_load<TN>(rb, g.B, g.ldb, n0, kn, tid);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < BK2 / 16; ++ks) {
+      bf16x8 a0, a1, b0, b1;
+      if (TN) {
+        using lds_v4 = __attribute__((address_space(3))) i16x4;
+        const unsigned short* ab = As[cur] + ks * 16 * TN_ROW + wm * 64 + tr_off;
+        const unsigned short* bb = Bs[cur] + ks * 16 * TN_ROW + wn * 64 + tr_off;
+        i16x4 t[8];
+        t[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(ab));
+        t[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(ab + 4 * TN_ROW));
+        t[2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(ab + 32));
+        t[3] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(ab + 32 + 4 * TN_ROW));
+        t[4] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(bb));
+        t[5] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(bb + 4 * TN_ROW));
+        t[6] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(bb + 32));
+        t[7] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(bb + 32 + 4 * TN_ROW));
+        a0 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(t[0], t[1], 0, 1, 2, 3, 4, 5, 6, 7));
+        a1 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(t[2], t[3], 0, 1, 2, 3, 4, 5, 6, 7));
+        b0 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(t[4], t[5], 0, 1, 2, 3, 4, 5, 6, 7));
+        b1 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(t[6], t[7], 0, 1, 2, 3, 4, 5, 6, 7));
+      } else {
+        const unsigned short* as = As[cur] + (wm * 64 + lr) * NT_ROW + ks * 16 + lk * 8;
+        const unsigned short* bs = Bs[cur] + (wn * 64 + lr) * NT_ROW + ks * 16 + lk * 8;
+        a0 = *reinterpret_cast<const bf16x8*>(as);
+        a1 = *reinterpret_cast<const bf16x8*>(as + 32 * NT_ROW);
+        b0 = *reinterpret_cast<const bf16x8*>(bs);
+        b1 = *reinterpret_cast<const bf16x8*>(bs + 32 * NT_ROW);
+      }
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    tile16_store<TN>(ra, As[cur ^ 1], tid);
+    tile16_store<TN>(rb, Bs[cur ^ 1], tid);
+    __syncthreads();
+  }
+  GemmArgs e = {};
+  e.C = g.C; e.bias = g.bias; e.M = g.M; e.N = g.N; e.K = g.K; e.ldc = g.ldc; e.alpha = g.alpha; e.beta = g.beta;
+  e.slabs = g.slabs; e.splits = g.splits; e.bn_part = g.bn_part;
+  gemm_epilogue(e, acc, m0, n0, wm, wn, lr, lk, bz);
+  if (g.bn_part) gemm_tile_bn_stats(e, acc, reinterpret_cast<float*>(&As[0][0]), m0, n0, wm, wn, lr, lk, by);
+}
+
+// fp32 (rows, cols) -> bf16 copy (same layout) and, optionally, the transposed bf16 copy (cols, rows): the per-step
+// refresh of the MLP's weight images (tiny: the weights, not the activations).
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, int64_t rows, int64_t cols,
+                                                         int64_t ld, unsigned short* __restrict__ dst,
+                                                         unsigned short* __restrict__ dst_t) {
+  __shared__ float tile[32][33];
+  const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    const int64_t r = r0 + j, c = c0 + tx;
+    const float v = (r < rows && c < cols) ? src[r * ld + c] : 0.f;
+    tile[j][tx] = v;
+    if (dst && r < rows && c < cols) dst[r * cols + c] = __builtin_bit_cast(unsigned short, (__bf16)v);
+  }
+  __syncthreads();
+  if (dst_t)
+    for (int j = ty; j < 32; j += 8) {
+      const int64_t c = c0 + j, r = r0 + tx;
+      if (r < rows && c < cols) dst_t[c * rows + r] = __builtin_bit_cast(unsigned short, (__bf16)tile[tx][j]);
+    }
+}
+
 // C = alpha * sum_z slabs[z] + beta * C (+ bias): the launch-boundary reduce of the split-K partial slabs, fixed
 // summation order (bitwise reproducible).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int splits, int64_t M,
@@ -513,4 +675,60 @@ extern "C" int trs_gemm_bf16(int transA, int transB, int64_t M, int64_t N, int64
                              void* workspace_dev, int64_t workspace_bytes, void* stream) {
   return gemm_impl(true, transA, transB, M, N, K, alpha, A_dev, lda, B_dev, ldb, beta, C_dev, ldc, bias_dev,
                    bn_part_dev, workspace_dev, workspace_bytes, stream);
+}
+
+// bf16-resident GEMM.  tn = 0: C(M,N) = alpha * A(M,K) B(N,K)^T; tn = 1: C(M,N) = alpha * A(K,M)^T B(K,N).
+extern "C" int64_t trs_gemm_bf16in_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  return trs_gemm_f32_workspace_bytes(M, N, K);
+}
+
+extern "C" int trs_gemm_bf16in(int tn, int64_t M, int64_t N, int64_t K, float alpha, const void* A_dev, int64_t lda,
+                               const void* B_dev, int64_t ldb, float beta, float* C_dev, int64_t ldc,
+                               const float* bias_dev, float* bn_part_dev, void* workspace_dev,
+                               int64_t workspace_bytes, void* stream) {
+  TRS_REQUIRE(A_dev && B_dev && C_dev, "trs_gemm_bf16in: NULL operand");
+  TRS_REQUIRE(M > 0 && N > 0 && K > 0 && M % BM == 0 && N % BN == 0 && K % BK2 == 0,
+              "trs_gemm_bf16in: needs M, N multiples of 128 and K a multiple of 64 (got %lld x %lld x %lld)",
+              (long long)M, (long long)N, (long long)K);
+  TRS_REQUIRE(lda >= (tn ? M : K) && ldb >= (tn ? N : K) && ldc >= N, "trs_gemm_bf16in: leading dimension too small");
+  TRS_REQUIRE((((uintptr_t)A_dev | (uintptr_t)B_dev) & 15) == 0 && lda % 8 == 0 && ldb % 8 == 0,
+              "trs_gemm_bf16in: operands must be 16-byte aligned with leading dimensions that are multiples of 8");
+  int splits = bn_part_dev ? 1 : pick_splits(M, N, K);
+  const int64_t kt = K / BK2;
+  if (splits > kt) splits = (int)kt;
+  int64_t per = (kt + splits - 1) / splits;
+  splits = (int)((kt + per - 1) / per);  // every split gets at least one k-tile
+  TRS_REQUIRE(!bn_part_dev || beta == 0.f, "trs_gemm_bf16in: fused BatchNorm statistics need beta == 0");
+  TRS_REQUIRE(splits == 1 || (workspace_dev && workspace_bytes >= (int64_t)splits * M * N * 4),
+              "trs_gemm_bf16in: workspace too small");
+  Gemm16Args g;
+  g.A = (const unsigned short*)A_dev; g.B = (const unsigned short*)B_dev; g.C = C_dev; g.bias = bias_dev;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.alpha = alpha; g.beta = beta;
+  g.k_per_split = per * BK2;
+  g.slabs = (float*)workspace_dev;
+  g.bn_part = bn_part_dev;
+  const int64_t gx = N / BN, gy = M / BM;
+  TRS_REQUIRE(gx * gy * splits < ((int64_t)1 << 31), "trs_gemm_bf16in: problem too large for the launch grid");
+  g.gx = (int)gx; g.gy = (int)gy; g.splits = splits;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)(gx * gy * splits));
+  if (tn) hipLaunchKernelGGL((gemm_bf16in_kernel<true>), grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((gemm_bf16in_kernel<false>), grid, dim3(256), 0, s, g);
+  TRS_CHECK_LAUNCH("gemm_bf16in_kernel");
+  if (splits > 1) {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(trs_grid(M * N, 256)), dim3(256), 0, s, g.slabs, splits, M, N,
+                       C_dev, ldc, alpha, beta, bias_dev);
+    TRS_CHECK_LAUNCH("splitk_reduce_kernel");
+  }
+  return TRS_OK;
+}
+
+extern "C" int trs_f32_to_bf16(const float* src_dev, int64_t rows, int64_t cols, int64_t ld, void* dst_dev,
+                               void* dst_t_dev, void* stream) {
+  TRS_REQUIRE(src_dev && (dst_dev || dst_t_dev) && rows > 0 && cols > 0 && ld >= cols, "trs_f32_to_bf16: bad arguments");
+  dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
+  hipLaunchKernelGGL(f32_to_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, src_dev, rows, cols, ld,
+                     (unsigned short*)dst_dev, (unsigned short*)dst_t_dev);
+  TRS_CHECK_LAUNCH("f32_to_bf16_kernel");
+  return TRS_OK;
 }

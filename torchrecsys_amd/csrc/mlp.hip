@@ -12,12 +12,22 @@ namespace {
 constexpr int CHUNK_ROWS = 256;  // rows per partial-reduction chunk
 
 // ------------------------------------------------------------------------------------------- gather-concat
+__device__ __forceinline__ unsigned short f2bf(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+// 4 floats -> 4 bf16 (RNE) as one 8-byte store
+__device__ __forceinline__ void st_bf16x4(unsigned short* dst, float a, float b, float c, float d) {
+  uint2 v;
+  v.x = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+  v.y = (uint32_t)f2bf(c) | ((uint32_t)f2bf(d) << 16);
+  *reinterpret_cast<uint2*>(dst) = v;
+}
+
 struct GatherArgs {
   trs_tables T;
   trs_batch Bt;
-  float* x;
+  float* x;             // fp32 image, or NULL
   int64_t ld;
   int passes;
+  unsigned short* x16;  // bf16 image (use_amp: what the bf16-resident GEMMs read), or NULL; same ld (elements)
 };
 
 // one (row, field) segment of D floats per G-lane group; fields: 0 user, 1 item, 2+m metadata m
@@ -48,13 +58,26 @@ __global__ __launch_bounds__(TRS_BLOCK) void mlp_gather_kernel(const GatherArgs 
       id = trs_ld_idx(pass ? a.Bt.neg_meta : a.Bt.pos_meta, ib, t * T.M + m);
       n_rows = T.n_meta[m];
     }
-    float* dst = a.x + row * a.ld + (int64_t)f * D + 4 * c;
+    const int64_t doff = row * a.ld + (int64_t)f * D + 4 * c;
+    float* dst = a.x + doff;
     if ((uint64_t)id >= (uint64_t)n_rows) {
       if (c == 0 && a.Bt.err_flag_dev) atomicOr(a.Bt.err_flag_dev, 1);
-      for (int q = 0; q < 4 && 4 * c + q < D; ++q) dst[q] = 0.f;
+      for (int q = 0; q < 4 && 4 * c + q < D; ++q) {
+        if (a.x) dst[q] = 0.f;
+        if (a.x16) a.x16[doff + q] = 0;
+      }
       continue;
     }
     const float* src = tab + id * (int64_t)D + 4 * c;
+    if (a.x16) {
+      if (vec && ((a.ld & 3) == 0)) {
+        const float4 v = *reinterpret_cast<const float4*>(src);
+        st_bf16x4(a.x16 + doff, v.x, v.y, v.z, v.w);
+      } else {
+        for (int q = 0; q < 4 && 4 * c + q < D; ++q) a.x16[doff + q] = f2bf(src[q]);
+      }
+      if (!a.x) continue;
+    }
     if (vec && ((a.ld & 3) == 0)) {
       *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
     } else {
@@ -169,7 +192,8 @@ __global__ void bn_running_update_kernel(const float* __restrict__ mean, const f
 // (stat_passes = 2: batch statistics; 1: running statistics in eval mode).  use_bn = 0: out = relu(y).
 struct BnFwdArgs {
   const float* y;
-  float* out;
+  float* out;             // fp32 output, or NULL
+  unsigned short* out16;  // bf16 output (row stride ldo elements), or NULL
   int64_t rows_per_pass, ld, ldo;
   int H, passes, stat_passes, use_bn;
   const float *mean, *var, *gamma, *beta;
@@ -229,6 +253,7 @@ struct BnBwdArgs {
   float* part;
   const float* sums;  // (passes, 2, H) final s1, s2 (apply kernel)
   float* cs_part;     // optional (passes, n_chunks, H): per-chunk column sums of dy (the layer's bias gradient)
+  unsigned short* dy16;  // optional bf16 copy of dy (row stride ldd elements): what the bf16-resident GEMMs read
 };
 
 __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
@@ -509,7 +534,10 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_relu_fwd_v4_kernel(const BnFwdAr
         const float x = a.use_bn ? ((v[q] - mu[q]) * is[q]) * ga[q] + be[q] : v[q];
         v[q] = fmaxf(x, 0.f);
       }
-      if (rr < r1) *reinterpret_cast<float4*>(a.out + (base + rr) * a.ldo + col) = make_float4(v[0], v[1], v[2], v[3]);
+      if (rr < r1) {
+        if (a.out) *reinterpret_cast<float4*>(a.out + (base + rr) * a.ldo + col) = make_float4(v[0], v[1], v[2], v[3]);
+        if (a.out16) st_bf16x4(a.out16 + (base + rr) * a.ldo + col, v[0], v[1], v[2], v[3]);
+      }
     }
   }
 }
@@ -564,7 +592,8 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_apply_v4_kernel(const BnBwdA
         }
       }
       if (rr < r1 && live) {
-        *reinterpret_cast<float4*>(a.dy + (base + rr) * a.ldd + col) = make_float4(o[0], o[1], o[2], o[3]);
+        if (a.dy) *reinterpret_cast<float4*>(a.dy + (base + rr) * a.ldd + col) = make_float4(o[0], o[1], o[2], o[3]);
+        if (a.dy16) st_bf16x4(a.dy16 + (base + rr) * a.ldd + col, o[0], o[1], o[2], o[3]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) cs[q] += o[q];
       }
@@ -635,8 +664,8 @@ static int n_chunks_of(int64_t rows) { return (int)((rows + CHUNK_ROWS - 1) / CH
 }  // namespace
 
 extern "C" int trs_mlp_gather_concat(const trs_tables* tables, const trs_batch* batch, int32_t passes, float* x_dev,
-                                     int64_t ld, void* stream) {
-  TRS_REQUIRE(tables && batch && x_dev, "trs_mlp_gather_concat: NULL argument");
+                                     void* x_bf16_dev, int64_t ld, void* stream) {
+  TRS_REQUIRE(tables && batch && (x_dev || x_bf16_dev), "trs_mlp_gather_concat: NULL argument");
   TRS_REQUIRE(tables->M >= 0 && tables->M <= TRS_MAX_META, "trs_mlp_gather_concat: bad M");
   TRS_REQUIRE(tables->user && tables->item && tables->D > 0, "trs_mlp_gather_concat: bad tables");
   for (int m = 0; m < tables->M; ++m) TRS_REQUIRE(tables->meta[m], "trs_mlp_gather_concat: metadata table %d NULL", m);
@@ -647,7 +676,7 @@ extern "C" int trs_mlp_gather_concat(const trs_tables* tables, const trs_batch* 
   TRS_REQUIRE(batch->user && batch->pos && (passes == 1 || batch->neg), "trs_mlp_gather_concat: ids are NULL");
   TRS_REQUIRE(tables->M == 0 || (batch->pos_meta && (passes == 1 || batch->neg_meta)),
               "trs_mlp_gather_concat: metadata ids NULL");
-  GatherArgs a = {*tables, *batch, x_dev, ld, passes};
+  GatherArgs a = {*tables, *batch, x_dev, ld, passes, (unsigned short*)x_bf16_dev};
   const int64_t total = (int64_t)passes * batch->B * (2 + tables->M) * ((tables->D + 3) / 4);
   hipLaunchKernelGGL(mlp_gather_kernel, dim3(trs_grid(total, TRS_BLOCK)), dim3(TRS_BLOCK), 0, (hipStream_t)stream, a);
   TRS_CHECK_LAUNCH("mlp_gather_kernel");
@@ -706,15 +735,18 @@ extern "C" int trs_bn_stats_finalize(const float* part_dev, int64_t rows_per_pas
 extern "C" int trs_bn_relu_forward(const float* y_dev, int64_t rows_per_pass, int32_t passes, int32_t H, int64_t ld,
                                    int32_t use_bn, int32_t stat_passes, const float* mean_dev, const float* var_dev,
                                    const float* gamma_dev, const float* beta_dev, float eps, float* out_dev,
-                                   int64_t ldo, void* stream) {
-  TRS_REQUIRE(y_dev && out_dev, "trs_bn_relu_forward: NULL argument");
+                                   void* out_bf16_dev, int64_t ldo, void* stream) {
+  TRS_REQUIRE(y_dev && (out_dev || out_bf16_dev), "trs_bn_relu_forward: NULL argument");
   TRS_REQUIRE(rows_per_pass >= 0 && H > 0 && ld >= H && ldo >= H && passes >= 1, "trs_bn_relu_forward: bad shape");
   TRS_REQUIRE(!use_bn || (mean_dev && var_dev && gamma_dev && beta_dev), "trs_bn_relu_forward: BN tensors are NULL");
   TRS_REQUIRE(stat_passes == 1 || stat_passes == passes, "trs_bn_relu_forward: stat_passes must be 1 or passes");
   if (rows_per_pass == 0) return TRS_OK;
-  BnFwdArgs a = {y_dev, out_dev, rows_per_pass, ld, ldo, H, passes, stat_passes, use_bn, mean_dev, var_dev, gamma_dev,
-                 beta_dev, eps};
-  if (v4_ok(y_dev, H, ld) && v4_ok(out_dev, H, ldo)) {
+  BnFwdArgs a = {y_dev, out_dev, (unsigned short*)out_bf16_dev, rows_per_pass, ld, ldo, H, passes, stat_passes, use_bn,
+                 mean_dev, var_dev, gamma_dev, beta_dev, eps};
+  const bool v4 = v4_ok(y_dev, H, ld) && (!out_dev || v4_ok(out_dev, H, ldo)) &&
+                  (!out_bf16_dev || (ldo % 4 == 0 && ((uintptr_t)out_bf16_dev & 7) == 0));
+  TRS_REQUIRE(v4 || (out_dev && !out_bf16_dev), "trs_bn_relu_forward: the bf16 output needs H %% 4 == 0 and aligned rows");
+  if (v4) {
     const V4Shape v = v4_shape(H);
     hipLaunchKernelGGL(bn_relu_fwd_v4_kernel, dim3(v.gx, n_chunks_of(rows_per_pass), passes), dim3(TRS_BLOCK), 0,
                        (hipStream_t)stream, a, v.tpr);
@@ -729,9 +761,9 @@ extern "C" int trs_bn_relu_forward(const float* y_dev, int64_t rows_per_pass, in
 extern "C" int trs_bn_relu_backward(const float* y_dev, const float* dx_dev, int64_t rows_per_pass, int32_t passes,
                                     int32_t H, int64_t ld, int64_t ldd, int32_t use_bn, const float* mean_dev,
                                     const float* var_dev, const float* gamma_dev, const float* beta_dev, float eps,
-                                    float* dy_dev, float* dgamma_dev, float* dbeta_dev, float* dy_colsum_dev,
-                                    float* workspace_dev, void* stream) {
-  TRS_REQUIRE(y_dev && dx_dev && dy_dev && workspace_dev, "trs_bn_relu_backward: NULL argument");
+                                    float* dy_dev, void* dy_bf16_dev, float* dgamma_dev, float* dbeta_dev,
+                                    float* dy_colsum_dev, float* workspace_dev, void* stream) {
+  TRS_REQUIRE(y_dev && dx_dev && (dy_dev || dy_bf16_dev) && workspace_dev, "trs_bn_relu_backward: NULL argument");
   TRS_REQUIRE(rows_per_pass > 0 && H > 0 && ld >= H && ldd >= H && passes >= 1 && passes <= 2,
               "trs_bn_relu_backward: bad shape");
   TRS_REQUIRE(!use_bn || (mean_dev && var_dev && gamma_dev && beta_dev), "trs_bn_relu_backward: BN tensors are NULL");
@@ -741,7 +773,7 @@ extern "C" int trs_bn_relu_backward(const float* y_dev, const float* dx_dev, int
   float* sums = workspace_dev + (int64_t)passes * nc * 2 * H;  // (passes,2,H) behind the partials
   float* cs_part = sums + (int64_t)passes * 2 * H;             // (passes,nc,H) column-sum partials of dy
   BnBwdArgs a = {y_dev, dx_dev, dy_dev, rows_per_pass, ld, ldd, H, passes, use_bn, nc, mean_dev, var_dev, gamma_dev,
-                 beta_dev, eps, workspace_dev, sums, dy_colsum_dev ? cs_part : nullptr};
+                 beta_dev, eps, workspace_dev, sums, dy_colsum_dev ? cs_part : nullptr, (unsigned short*)dy_bf16_dev};
   if (use_bn) {
     if (v4_ok(y_dev, H, ld) && v4_ok(dx_dev, H, ldd) && v4_ok(workspace_dev, H, 4)) {
       const V4Shape v = v4_shape(H);
@@ -754,7 +786,10 @@ extern "C" int trs_bn_relu_backward(const float* y_dev, const float* dx_dev, int
                        dgamma_dev, dbeta_dev);
     TRS_CHECK_LAUNCH("bn_bwd_final_kernel");
   }
-  if (v4_ok(y_dev, H, ld) && v4_ok(dx_dev, H, ldd) && v4_ok(dy_dev, H, ldd) && v4_ok(workspace_dev, H, 4)) {
+  const bool v4a = v4_ok(y_dev, H, ld) && v4_ok(dx_dev, H, ldd) && (!dy_dev || v4_ok(dy_dev, H, ldd)) &&
+                   v4_ok(workspace_dev, H, 4) && (!dy_bf16_dev || ((uintptr_t)dy_bf16_dev & 7) == 0);
+  TRS_REQUIRE(v4a || (dy_dev && !dy_bf16_dev), "trs_bn_relu_backward: the bf16 output needs H %% 4 == 0 and aligned rows");
+  if (v4a) {
     const V4Shape v = v4_shape(H);
     hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3(v.gx, nc, passes), dim3(TRS_BLOCK), 0, s, a, v.tpr);
     TRS_CHECK_LAUNCH("bn_bwd_apply_kernel");

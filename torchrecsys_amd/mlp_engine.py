@@ -27,6 +27,50 @@ class MLPCompute:
 
     def __init__(self, net):
         self.net = net
+        self.gemm_events = None  # bench.py: list of (start event, end event, flops) per GEMM launch when not None
+
+    def _resident(self, rows, training):
+        """bf16-resident path: use_amp, training step, every GEMM of the net made of interior tiles."""
+        net = self.net
+        if not (net.use_bf16 and training):
+            return False
+        dims = [net.input_shape] + [fc.out_features for fc in net.fcs]
+        return rows % 128 == 0 and all(d % 128 == 0 for d in dims)
+
+    def _refresh_weight_images(self):
+        """bf16 images of the fp32 master weights, (H_out, H_in) for the forward and transposed (H_in, H_out) for the
+        input gradient; rewritten every step (the optimiser updates the fp32 weights)."""
+        net = self.net
+        if getattr(self, "w16", None) is None:
+            dev = net.fcs[0].weight.device
+            self.w16 = [torch.empty(fc.weight.shape, dtype=torch.bfloat16, device=dev) for fc in net.fcs]
+            self.w16t = [torch.empty(fc.weight.shape[::-1], dtype=torch.bfloat16, device=dev) for fc in net.fcs]
+        for fc, w, wt in zip(net.fcs, self.w16, self.w16t):
+            ops.f32_to_bf16(fc.weight.data, w, wt)
+
+    def _gemm16(self, tn, A, B, **kw):
+        ev = self.gemm_events
+        if ev is None:
+            return ops.gemm_bf16in(tn, A, B, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = ops.gemm_bf16in(tn, A, B, **kw)
+        e1.record()
+        ev.append((e0, e1, 2.0 * out.shape[0] * out.shape[1] * (A.shape[0] if tn else A.shape[1])))
+        return out
+
+    def _gemm(self, *a, **kw):
+        ev = self.gemm_events
+        if ev is None:
+            return ops.gemm(*a, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = ops.gemm(*a, **kw)
+        e1.record()
+        A = a[2]
+        K = A.shape[0] if a[0] else A.shape[1]
+        ev.append((e0, e1, 2.0 * out.shape[0] * out.shape[1] * K))
+        return out
 
     def _dims(self):
         net = self.net
@@ -42,9 +86,18 @@ class MLPCompute:
         err = net._err_flag()
         Bt, keep = ops.make_batch(ids["user"], ids["pos"], ids.get("neg") if passes == 2 else None,
                                   ids.get("pos_meta"), ids.get("neg_meta") if passes == 2 else None, err)
-        x = torch.empty((rows, net.input_shape), dtype=torch.float32, device=dev)
-        ops.mlp_gather_concat(net.tables(), Bt, passes, x)
-        ctx = {"ids": ids, "B": B, "passes": passes, "x": [x], "y": [], "mean": [], "var": [], "training": training}
+        # use_amp on shapes the bf16-resident kernels take: layer inputs x_l live in HBM as bf16 only (what the forward
+        # and weight-gradient GEMMs read), pre-BN outputs y_l stay fp32 (statistics, backward recompute)
+        res = self._resident(rows, training)
+        if res:
+            self._refresh_weight_images()
+            x = torch.empty((rows, net.input_shape), dtype=torch.bfloat16, device=dev)
+            ops.mlp_gather_concat(net.tables(), Bt, passes, x16=x)
+        else:
+            x = torch.empty((rows, net.input_shape), dtype=torch.float32, device=dev)
+            ops.mlp_gather_concat(net.tables(), Bt, passes, x)
+        ctx = {"ids": ids, "B": B, "passes": passes, "x": [x], "y": [], "mean": [], "var": [], "training": training,
+               "resident": res}
         for l in range(L):
             fc = net.fcs[l]
             # train-mode BN: the batch statistics come out of the GEMM epilogue (one partial per 128-row tile) when no
@@ -54,7 +107,10 @@ class MLPCompute:
             if fuse_stats:
                 n_tiles = (rows + ops.GEMM_TILE_ROWS - 1) // ops.GEMM_TILE_ROWS
                 part = torch.empty((n_tiles, 2, fc.out_features), dtype=torch.float32, device=dev)
-            y = ops.gemm(False, True, x, fc.weight.data, bias=fc.bias.data, bf16=net.use_bf16, bn_part=part)
+            if res:
+                y = self._gemm16(False, x, self.w16[l], bias=fc.bias.data, bn_part=part)
+            else:
+                y = self._gemm(False, True, x, fc.weight.data, bias=fc.bias.data, bf16=net.use_bf16, bn_part=part)
             ctx["y"].append(y)
             mean = var = gamma = beta = None
             stat_passes = 1
@@ -76,8 +132,12 @@ class MLPCompute:
                     mean, var = bn.running_mean, bn.running_var
             ctx["mean"].append(mean)
             ctx["var"].append(var)
-            xn = torch.empty_like(y)
-            ops.bn_relu_forward(y, B, passes, use_bn, stat_passes, mean, var, gamma, beta, BN_EPS, xn)
+            if res and l < L - 1:  # the next layer's input: bf16 only (the last layer's output feeds the fp32 H -> 1 dot)
+                xn = torch.empty(y.shape, dtype=torch.bfloat16, device=dev)
+                ops.bn_relu_forward(y, B, passes, use_bn, stat_passes, mean, var, gamma, beta, BN_EPS, out16=xn)
+            else:
+                xn = torch.empty_like(y)
+                ops.bn_relu_forward(y, B, passes, use_bn, stat_passes, mean, var, gamma, beta, BN_EPS, xn)
             x = xn
             ctx["x"].append(x)
         out = torch.empty(rows, dtype=torch.float32, device=dev)
@@ -106,19 +166,28 @@ class MLPCompute:
         ops.colsum(g.reshape(-1, 1), slot(ol.bias), passes=passes)
         dx = torch.empty_like(xL)
         ops.outer(g, ol.weight.data.reshape(-1), dx)
+        res = ctx.get("resident", False)
         for l in reversed(range(L)):
             fc = net.fcs[l]
             y = ctx["y"][l]
-            dy = torch.empty_like(y)
+            if res:
+                dy = None
+                dy16 = torch.empty(y.shape, dtype=torch.bfloat16, device=y.device)
+            else:
+                dy, dy16 = torch.empty_like(y), None
             if use_bn:
                 bn = net.bns[l]
                 ops.bn_relu_backward(y, dx, B, passes, True, ctx["mean"][l], ctx["var"][l], bn.weight.data, bn.bias.data,
-                                     BN_EPS, dy, slot(bn.weight), slot(bn.bias), dy_colsum=slot(fc.bias))
+                                     BN_EPS, dy, slot(bn.weight), slot(bn.bias), dy_colsum=slot(fc.bias), dy16=dy16)
             else:
                 ops.bn_relu_backward(y, dx, B, passes, False, None, None, None, None, BN_EPS, dy, None, None,
-                                     dy_colsum=slot(fc.bias))          # db = column sums of dy, from the same kernel
-            ops.gemm(True, False, dy, ctx["x"][l], out=slot(fc.weight), bf16=net.use_bf16)  # dW = dy^T x (split-K)
-            dx = ops.gemm(False, False, dy, fc.weight.data, bf16=net.use_bf16)      # dx = dy W
+                                     dy_colsum=slot(fc.bias), dy16=dy16)  # db = column sums of dy, from the same kernel
+            if res:
+                self._gemm16(True, dy16, ctx["x"][l], out=slot(fc.weight))   # dW = dy^T x (transposing LDS reads)
+                dx = self._gemm16(False, dy16, self.w16t[l])                 # dx = dy W through the W^T image
+            else:
+                self._gemm(True, False, dy, ctx["x"][l], out=slot(fc.weight), bf16=net.use_bf16)  # dW = dy^T x (split-K)
+                dx = self._gemm(False, False, dy, fc.weight.data, bf16=net.use_bf16)      # dx = dy W
         return grads, dx
 
 

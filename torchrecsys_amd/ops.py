@@ -311,8 +311,12 @@ def topk(scores, k):
 
 
 # ------------------------------------------------------------------------------------------------- MLP kernels
-def mlp_gather_concat(T, Bt, passes, x):
-    check(_lib.load().trs_mlp_gather_concat(C.byref(T), C.byref(Bt), passes, ptr(x), x.stride(0), _stream()),
+def mlp_gather_concat(T, Bt, passes, x=None, x16=None):
+    """x: fp32 (rows, (2+M)D) and/or x16: the same image in bfloat16 (same row stride in elements)."""
+    ld = (x if x is not None else x16).stride(0)
+    if x is not None and x16 is not None and x16.stride(0) != ld:
+        raise ValueError("mlp_gather_concat: x and x16 must share the row stride")
+    check(_lib.load().trs_mlp_gather_concat(C.byref(T), C.byref(Bt), passes, ptr(x), ptr(x16), ld, _stream()),
           "trs_mlp_gather_concat")
 
 
@@ -353,6 +357,42 @@ def gemm(transA, transB, A, B, out=None, bias=None, alpha=1.0, beta=0.0, bf16=Fa
     return out
 
 
+def gemm_bf16in(tn, A, B, out=None, bias=None, bn_part=None):
+    """bf16-resident GEMM: tn False: out(M,N) = A(M,K) B(N,K)^T; tn True: out(M,N) = A(K,M)^T B(K,N).  A, B bfloat16 GPU
+    tensors with a contiguous last dimension; fp32 accumulation and output."""
+    lib = _lib.load()
+    for t in (A, B):
+        if t.dtype != torch.bfloat16 or t.stride(-1) != 1 or not t.is_cuda:
+            raise ValueError("gemm_bf16in operands must be bfloat16 GPU tensors with a contiguous last dimension")
+    if tn:
+        K, M = A.shape
+        Kb, N = B.shape
+    else:
+        M, K = A.shape
+        N, Kb = B.shape
+    if K != Kb:
+        raise ValueError(f"gemm_bf16in: inner dimensions differ ({K} vs {Kb})")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    wsb = 0 if bn_part is not None else lib.trs_gemm_bf16in_workspace_bytes(M, N, K)
+    ws = _workspace(A.device, wsb) if wsb else None
+    check(lib.trs_gemm_bf16in(int(tn), M, N, K, 1.0, ptr(A), A.stride(0), ptr(B), B.stride(0), 0.0, ptr(out),
+                              out.stride(0), ptr(bias), ptr(bn_part), ptr(ws), wsb, _stream()), "trs_gemm_bf16in")
+    return out
+
+
+def gemm_bf16in_ok(M, N, K):
+    """Shapes the bf16-resident kernels take (all tiles interior)."""
+    return M % GEMM_TILE_ROWS == 0 and N % 128 == 0 and K % 64 == 0
+
+
+def f32_to_bf16(src, dst=None, dst_t=None):
+    """bf16 copy (dst, same shape) and/or transposed bf16 copy (dst_t) of a 2-D fp32 GPU tensor."""
+    rows, cols = src.shape
+    check(_lib.load().trs_f32_to_bf16(ptr(src), rows, cols, src.stride(0), ptr(dst), ptr(dst_t), _stream()),
+          "trs_f32_to_bf16")
+
+
 def bn_batch_stats(y, rows_per_pass, passes, momentum, mean_out, var_out, running_mean, running_var):
     lib = _lib.load()
     H = y.shape[1]
@@ -369,21 +409,23 @@ def bn_stats_finalize(part, rows_per_pass, chunk_rows, H, passes, momentum, mean
           "trs_bn_stats_finalize")
 
 
-def bn_relu_forward(y, rows_per_pass, passes, use_bn, stat_passes, mean, var, gamma, beta, eps, out):
+def bn_relu_forward(y, rows_per_pass, passes, use_bn, stat_passes, mean, var, gamma, beta, eps, out=None, out16=None):
+    """out: fp32 and/or out16: bfloat16 image of relu(bn(y)) (same row stride in elements)."""
     H = y.shape[1]
+    ldo = (out if out is not None else out16).stride(0)
     check(_lib.load().trs_bn_relu_forward(ptr(y), rows_per_pass, passes, H, y.stride(0), int(use_bn), stat_passes,
-                                          ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps), ptr(out),
-                                          out.stride(0), _stream()), "trs_bn_relu_forward")
+                                          ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps), ptr(out), ptr(out16),
+                                          ldo, _stream()), "trs_bn_relu_forward")
 
 
 def bn_relu_backward(y, dx, rows_per_pass, passes, use_bn, mean, var, gamma, beta, eps, dy, dgamma, dbeta,
-                     dy_colsum=None):
+                     dy_colsum=None, dy16=None):
     lib = _lib.load()
     H = y.shape[1]
     ws = _workspace(y.device, 4 * lib.trs_bn_backward_workspace_floats(rows_per_pass, H, passes))
     check(lib.trs_bn_relu_backward(ptr(y), ptr(dx), rows_per_pass, passes, H, y.stride(0), dx.stride(0), int(use_bn),
-                                   ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps), ptr(dy), ptr(dgamma),
-                                   ptr(dbeta), ptr(dy_colsum), ptr(ws), _stream()), "trs_bn_relu_backward")
+                                   ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps), ptr(dy), ptr(dy16),
+                                   ptr(dgamma), ptr(dbeta), ptr(dy_colsum), ptr(ws), _stream()), "trs_bn_relu_backward")
 
 
 def colsum(x, out, row_weight=None, passes=1):
