@@ -197,7 +197,7 @@ def main():
         fl = sum(f for _, _, f in gemm_events)
         ach = fl / (ms * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[dtype]
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel" if cfg["amp"] else "gemm_f32_kernel",
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16in_kernel" if cfg["amp"] else "gemm_f32_kernel",
                            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                            "gemm_launches_per_step": len(gemm_events) / args.steps,
                            "gemm_ms_per_step": ms / args.steps, "gemm_share_of_step": ms / (1e3 * elapsed),

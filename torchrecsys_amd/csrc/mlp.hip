@@ -9,7 +9,7 @@
 
 namespace {
 
-constexpr int CHUNK_ROWS = 256;  // rows per partial-reduction chunk
+constexpr int CHUNK_ROWS = 128;  // rows per partial-reduction chunk = per workgroup of the streaming kernels
 
 // ------------------------------------------------------------------------------------------- gather-concat
 __device__ __forceinline__ unsigned short f2bf(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
