@@ -619,12 +619,10 @@ def test_presort_generates_the_same_batches_as_batch_prepare():
             assert torch.equal(arr[b * B:(b + 1) * B], out[k]), (k, b)
     # sorted references: per batch ascending item rows, a permutation of the batch's 2B references
     n = 2 * nb * B
-    kt = torch.uint32 if ps.key_bytes == 4 else torch.int64
-    keys = ps.keys.view(kt)[n:].cpu().numpy().astype(np.int64)
-    bits = int(np.ceil(np.log2(NI)))
-    assert (np.diff(keys) >= 0).all()
+    assert ps.key_bytes == 4  # keys = item rows, one sort segment per batch
+    keys = ps.keys.view(torch.uint32)[n:].cpu().numpy().astype(np.int64)
     for b in range(nb):
-        items = keys[2 * b * B:2 * (b + 1) * B] & ((1 << bits) - 1)
-        assert ((keys[2 * b * B:2 * (b + 1) * B] >> bits) == b).all()
+        items = keys[2 * b * B:2 * (b + 1) * B]
+        assert (np.diff(items) >= 0).all()
         exp = np.sort(np.concatenate([ps.ids[1][b * B:(b + 1) * B].cpu().numpy(), ps.ids[2][b * B:(b + 1) * B].cpu().numpy()]))
         assert np.array_equal(items, exp)

@@ -729,7 +729,8 @@ using namespace trs;
 // presort.hip
 int trs_launch_sorted_item_update(const trs_tables* tables, const void* keys_step, const void* vals_step, int key_bytes,
                                   int64_t batch, int64_t item_bits, const float* gz, float lr, uint64_t* uown,
-                                  uint32_t* udup, uint32_t stamp, const float* ustage, hipStream_t s);
+                                  uint32_t* udup, uint32_t stamp, const float* ustage, const int32_t* user_ids,
+                                  hipStream_t s);
 int trs_item_bits_for(int64_t n_items);
 int trs_launch_sorted_updates_fused(const trs_tables* tables, const void* keys_step, const void* vals_step,
                                     int64_t batch, int64_t item_bits, const float* gz, float lr, const float* ustage,
@@ -826,7 +827,7 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
     if (ev) (void)hipEventRecord(ev[1], s);
     if (sorted) {  // K2: per-run owner update from the presorted references, then K3
       const char* ks = (const char*)sorted_keys_dev + (int64_t)st * 2 * batch * key_bytes;
-      const char* vs = (const char*)sorted_vals_dev + (int64_t)st * 2 * batch * 8;
+      const char* vs = (const char*)sorted_vals_dev + (int64_t)st * 2 * batch * 4;
       if (inl && key_bytes == 4 && ukey_bytes == 4) {  // item + duplicated-user updates in one launch
         const char* uk = (const char*)sorted_ukeys_dev + (int64_t)st * batch * 4;
         const char* uv = (const char*)sorted_uvals_dev + (int64_t)st * batch * 4;
@@ -840,7 +841,7 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
         continue;
       }
       rc = trs_launch_sorted_item_update(tables, ks, vs, key_bytes, batch, item_bits, a.gz, a.lr,
-                                         inl ? nullptr : a.uown, a.udup, a.stamp, inl ? a.ustage : nullptr, s);
+                                         inl ? nullptr : a.uown, a.udup, a.stamp, inl ? a.ustage : nullptr, a.user, s);
       if (rc) return rc;
       if (ev) (void)hipEventRecord(ev[2], s);
       if (inl) {

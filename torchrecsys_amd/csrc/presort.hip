@@ -5,25 +5,41 @@
 // step.  The references of a whole epoch are known when the epoch starts (the shuffle is a keyed bijection of the
 // position, the negative a counter-based draw), so they are grouped ONCE per epoch:
 //   epoch_refs_kernel   every position q of the epoch -> its triple (u, i, j) [written out: K1 then reads contiguous ids
-//                       instead of deriving them] and two references  key = batch * 2^item_bits + item,
-//                       payload = {user, (t << 1) | which};
-//   rocprim radix sort  by key over the item_bits + batch_bits low bits: per batch, references sorted by item row.
+//                       instead of deriving them] and two references  key = item row, payload = (t << 1) | which;
+//   rocprim segmented radix sort, one segment per batch (the positions of a batch are contiguous already, so sorting on
+//                       a (batch, item) key would spend half its passes on bits that are in order): item_bits = 17 at
+//                       c2 -> two 9-bit passes, one 1024-thread workgroup per batch; measured 0.95 ms per 512 batches of
+//                       131 072 references against 2.0 ms for the global 26-bit sort (tools/micro/segsort_bench.hip).
 // Per step, sorted_item_update_kernel gives every run of equal keys to ONE lane group: it sums c * u over the run
 // (c = -lr * gz of the reference, u = the still-unmodified user row) in registers and applies it with a single plain
 // whole-row read-modify-write.  Runs are cut at 64-reference boundaries so a hot row (skewed data) is reduced by many
 // groups in parallel; only such cut runs fall back to float atomics (one add per 64 references instead of 64).
 #include <cstring>
 
-#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "score_kernels.h"
 
 namespace trs {
 
 struct RefPayload {
-  int32_t user;
   uint32_t tw;  // (t << 1) | which   (t = position inside the batch, which: 0 positive / 1 negative)
 };
+
+// segment s of the sort = [s * len, (s + 1) * len)
+struct SegBegin {
+  uint32_t len;
+  __host__ __device__ uint32_t operator()(uint32_t s) const { return s * len; }
+};
+using SegIt = rocprim::transform_iterator<rocprim::counting_iterator<uint32_t>, SegBegin>;
+static inline SegIt seg_it(uint32_t first, uint32_t len) {
+  return rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(first), SegBegin{len});
+}
+// 9-bit (item rows) / 10-bit (users) digits need >= 512 / 1024 threads; 1024 x 8 measured best for both
+using ItemSortCfg = rocprim::segmented_radix_sort_config<9, rocprim::kernel_config<1024, 8>>;
+using UserSortCfg = rocprim::segmented_radix_sort_config<10, rocprim::kernel_config<1024, 8>>;
 
 struct EpochArgs {
   const int2* sui;  // resident stream {user, item} or NULL (ids given in user/pos/neg)
@@ -75,9 +91,9 @@ __global__ __launch_bounds__(TRS_BLOCK) void epoch_refs_kernel(const EpochArgs a
     }
     const int64_t b = q / a.batch;
     const uint32_t t = (uint32_t)(q - b * a.batch);
-    keys[2 * q] = (KeyT)(((uint64_t)b << a.item_bits) | (uint64_t)i);
-    keys[2 * q + 1] = (KeyT)(((uint64_t)b << a.item_bits) | (uint64_t)j);
-    RefPayload v0 = {(int32_t)u, (t << 1)}, v1 = {(int32_t)u, (t << 1) | 1u};
+    keys[2 * q] = (KeyT)i;
+    keys[2 * q + 1] = (KeyT)j;
+    RefPayload v0 = {(t << 1)}, v1 = {(t << 1) | 1u};
     a.vals[2 * q] = v0;
     a.vals[2 * q + 1] = v1;
   }
@@ -88,6 +104,7 @@ struct SortedArgs {
   trs_tables T;
   const void* keys;         // this step's 2B sorted keys
   const RefPayload* vals;   // this step's 2B sorted payloads
+  const int32_t* user_ids;  // this step's B user ids (position t -> user): the unstaged form reads the user table
   int64_t B;
   int item_bits;
   const float* gz;          // (2,B)
@@ -126,20 +143,21 @@ __global__ __launch_bounds__(TRS_BLOCK) void sorted_item_update_kernel(const Sor
     const KeyT key = keys[ic];
     const KeyT prev = keys[ic > 0 ? ic - 1 : 0];
     const RefPayload me = a.vals[ic];
+    const int64_t me_user = STAGED ? 0 : (int64_t)a.user_ids[me.tw >> 1];
     const bool head = ic == 0 || prev != key;
     const bool leader = valid && (head || (ic % RUN_CHUNK) == 0);
     uint64_t own = 0;
-    if (!STAGED) own = a.uown[me.user];
+    if (!STAGED) own = a.uown[me_user];
     const float* ubase = STAGED ? a.ustage : T.user;
     const float c0 = -a.lr * a.gz[(int64_t)(me.tw & 1u) * a.B + (me.tw >> 1)];
     const int64_t row = (int64_t)(key & row_mask);
     RowReg<VEC, K> u0, w;
-    row_load<VEC, G, K, FULL>(u0, ubase, leader ? (STAGED ? (int64_t)(me.tw >> 1) : (int64_t)me.user) : 0, D, lig);
+    row_load<VEC, G, K, FULL>(u0, ubase, leader ? (STAGED ? (int64_t)(me.tw >> 1) : me_user) : 0, D, lig);
     row_load<VEC, G, K, FULL>(w, T.item, leader ? row : 0, D, lig);
     const float wl = T.item_lin[leader ? row : 0];
     // the positive reference of a triple also checks whether its user row has other references in this step (K3)
     if (!STAGED && valid && (me.tw & 1u) == 0 && lig == 0 && own != (hi | (uint64_t)(me.tw >> 1)))
-      a.udup[me.user] = a.stamp;
+      a.udup[me_user] = a.stamp;
     if (!leader) continue;
     const int64_t chunk_end = (ic / RUN_CHUNK + 1) * RUN_CHUNK < n ? (ic / RUN_CHUNK + 1) * RUN_CHUNK : n;
     RowReg<VEC, K> acc;
@@ -151,7 +169,7 @@ __global__ __launch_bounds__(TRS_BLOCK) void sorted_item_update_kernel(const Sor
       const RefPayload pl = a.vals[j];
       const float c = -a.lr * a.gz[(int64_t)(pl.tw & 1u) * a.B + (pl.tw >> 1)];
       RowReg<VEC, K> u;
-      row_load<VEC, G, K, FULL>(u, ubase, STAGED ? (int64_t)(pl.tw >> 1) : (int64_t)pl.user, D, lig);
+      row_load<VEC, G, K, FULL>(u, ubase, STAGED ? (int64_t)(pl.tw >> 1) : (int64_t)a.user_ids[pl.tw >> 1], D, lig);
 #pragma unroll
       for (int q = 0; q < N; ++q) acc.v[q] += c * u.v[q];
       lin += c;
@@ -302,14 +320,13 @@ __device__ __forceinline__ void sorted_item_update_staged_body(const SortedArgs&
 
 // ---------------------------------------------------------------------------------------------- user duplicates
 // flags[q] = 1 iff the user of position q is referenced by another triple of the same batch (static for the epoch):
-// sort (batch * 2^user_bits + user, q) and compare neighbours.
+// segmented sort of (user, q) with one segment per batch, then compare neighbours inside the segment.
 template <typename KeyT>
 __global__ __launch_bounds__(TRS_BLOCK) void user_keys_kernel(const int32_t* __restrict__ user, int64_t n_pos,
-                                                             int64_t batch, int user_bits, KeyT* __restrict__ keys,
-                                                             uint32_t* __restrict__ vals) {
+                                                             KeyT* __restrict__ keys, uint32_t* __restrict__ vals) {
   const int64_t stride = (int64_t)gridDim.x * TRS_BLOCK;
   for (int64_t q = (int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x; q < n_pos; q += stride) {
-    keys[q] = (KeyT)(((uint64_t)(q / batch) << user_bits) | (uint64_t)(uint32_t)user[q]);
+    keys[q] = (KeyT)(uint32_t)user[q];
     vals[q] = (uint32_t)q;
   }
 }
@@ -317,11 +334,12 @@ __global__ __launch_bounds__(TRS_BLOCK) void user_keys_kernel(const int32_t* __r
 template <typename KeyT>
 __global__ __launch_bounds__(TRS_BLOCK) void user_flags_kernel(const KeyT* __restrict__ keys,
                                                               const uint32_t* __restrict__ vals, int64_t n_pos,
-                                                              uint8_t* __restrict__ flags) {
+                                                              int64_t batch, uint8_t* __restrict__ flags) {
   const int64_t stride = (int64_t)gridDim.x * TRS_BLOCK;
   for (int64_t s = (int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x; s < n_pos; s += stride) {
     const KeyT k = keys[s];
-    const bool dup = (s > 0 && keys[s - 1] == k) || (s + 1 < n_pos && keys[s + 1] == k);
+    const int64_t in_seg = s % batch;
+    const bool dup = (in_seg > 0 && keys[s - 1] == k) || (in_seg + 1 < batch && keys[s + 1] == k);
     flags[vals[s]] = dup ? 1 : 0;
   }
 }
@@ -331,7 +349,7 @@ __global__ __launch_bounds__(TRS_BLOCK) void user_flags_kernel(const KeyT* __res
 // plain read-modify-write (K1 already updated every user referenced once).  No atomics: the step is reproducible.
 struct UserDupArgs {
   trs_tables T;
-  const void* ukeys;      // this step's B sorted (batch, user) keys
+  const void* ukeys;      // this step's B sorted user ids
   const uint32_t* uvals;  // this step's B sorted positions (slice-relative q)
   int64_t B;
   int64_t q0;             // slice-relative position of the step's first triple
@@ -467,18 +485,15 @@ extern "C" int trs_epoch_presort_sizes(int64_t n_batches, int64_t batch, int64_t
   TRS_REQUIRE(n_batches > 0 && batch > 0 && n_items > 0, "trs_epoch_presort_sizes: bad arguments");
   TRS_REQUIRE(key_bytes_out && keys_total_bytes_out && vals_total_bytes_out && temp_bytes_out,
               "trs_epoch_presort_sizes: NULL output");
-  const int bits = bits_for(n_items) + bits_for(n_batches);
-  TRS_REQUIRE(bits <= 62, "trs_epoch_presort_sizes: key does not fit 62 bits");
-  const int kb = bits <= 32 ? 4 : 8;
+  const int bits = bits_for(n_items);
+  TRS_REQUIRE(bits <= 32 && 2 * n_batches * batch < ((int64_t)1 << 32), "trs_epoch_presort_sizes: slice too long");
+  const int kb = 4;
   const size_t n = (size_t)(2 * n_batches * batch);
   size_t temp = 0;
-  hipError_t e;
-  if (kb == 4)
-    e = rocprim::radix_sort_pairs(nullptr, temp, (uint32_t*)nullptr, (uint32_t*)nullptr, (RefPayload*)nullptr,
-                                  (RefPayload*)nullptr, n, 0u, (unsigned)bits, (hipStream_t)0);
-  else
-    e = rocprim::radix_sort_pairs(nullptr, temp, (uint64_t*)nullptr, (uint64_t*)nullptr, (RefPayload*)nullptr,
-                                  (RefPayload*)nullptr, n, 0u, (unsigned)bits, (hipStream_t)0);
+  hipError_t e = rocprim::segmented_radix_sort_pairs<ItemSortCfg>(
+      nullptr, temp, (uint32_t*)nullptr, (uint32_t*)nullptr, (RefPayload*)nullptr, (RefPayload*)nullptr, n,
+      (unsigned)n_batches, seg_it(0, (uint32_t)(2 * batch)), seg_it(1, (uint32_t)(2 * batch)), 0u, (unsigned)bits,
+      (hipStream_t)0);
   TRS_REQUIRE(e == hipSuccess, "trs_epoch_presort_sizes: rocprim size query failed");
   *key_bytes_out = kb;
   *keys_total_bytes_out = 2 * (int64_t)n * kb;
@@ -520,38 +535,27 @@ extern "C" int trs_epoch_presort(const int32_t* stream_ui_dev, const int32_t* ne
   a.keys = keys_dev;
   a.vals = (RefPayload*)vals_dev;
   a.err = err_flag_dev;
-  const int bits = a.item_bits + bits_for(n_batches);
-  TRS_REQUIRE(bits <= 62, "trs_epoch_presort: key does not fit 62 bits");
-  const bool k32 = bits <= 32;
+  const int bits = a.item_bits;
+  TRS_REQUIRE(bits <= 32 && 2 * n_pos < ((int64_t)1 << 32), "trs_epoch_presort: slice too long");
   const int src = !stream_ui_dev ? 0 : (neg_static_dev ? 2 : 1);
   hipStream_t s = (hipStream_t)stream;
   const dim3 gr(trs_grid(n_pos, TRS_BLOCK)), bl(TRS_BLOCK);
-#define TRS_EP(KT)                                                                      \
-  {                                                                                     \
-    if (src == 0) hipLaunchKernelGGL((epoch_refs_kernel<KT, 0>), gr, bl, 0, s, a);       \
-    else if (src == 1) hipLaunchKernelGGL((epoch_refs_kernel<KT, 1>), gr, bl, 0, s, a);  \
-    else hipLaunchKernelGGL((epoch_refs_kernel<KT, 2>), gr, bl, 0, s, a);                \
-  }
-  if (k32) TRS_EP(uint32_t) else TRS_EP(uint64_t)
-#undef TRS_EP
+  if (src == 0) hipLaunchKernelGGL((epoch_refs_kernel<uint32_t, 0>), gr, bl, 0, s, a);
+  else if (src == 1) hipLaunchKernelGGL((epoch_refs_kernel<uint32_t, 1>), gr, bl, 0, s, a);
+  else hipLaunchKernelGGL((epoch_refs_kernel<uint32_t, 2>), gr, bl, 0, s, a);
   TRS_CHECK_LAUNCH("epoch_refs_kernel");
   const size_t n = (size_t)(2 * n_pos);
   size_t temp = (size_t)temp_bytes;
   RefPayload* vin = (RefPayload*)vals_dev;
   RefPayload* vout = vin + n;
-  hipError_t e;
-  if (k32) {
-    uint32_t* kin = (uint32_t*)keys_dev;
-    e = rocprim::radix_sort_pairs(temp_dev, temp, kin, kin + n, vin, vout, n, 0u, (unsigned)bits, s);
-    *sorted_keys_out = (void*)(kin + n);
-  } else {
-    uint64_t* kin = (uint64_t*)keys_dev;
-    e = rocprim::radix_sort_pairs(temp_dev, temp, kin, kin + n, vin, vout, n, 0u, (unsigned)bits, s);
-    *sorted_keys_out = (void*)(kin + n);
-  }
+  uint32_t* kin = (uint32_t*)keys_dev;
+  hipError_t e = rocprim::segmented_radix_sort_pairs<ItemSortCfg>(
+      temp_dev, temp, kin, kin + n, vin, vout, n, (unsigned)n_batches, seg_it(0, (uint32_t)(2 * batch)),
+      seg_it(1, (uint32_t)(2 * batch)), 0u, (unsigned)bits, s);
+  *sorted_keys_out = (void*)(kin + n);
   *sorted_vals_out = (void*)vout;
   if (e != hipSuccess) {
-    trs_set_error("trs_epoch_presort: rocprim::radix_sort_pairs failed: %s", hipGetErrorString(e));
+    trs_set_error("trs_epoch_presort: rocprim::segmented_radix_sort_pairs failed: %s", hipGetErrorString(e));
     return TRS_E_LAUNCH;
   }
   return TRS_OK;
@@ -564,17 +568,14 @@ extern "C" int trs_epoch_user_dups_sizes(int64_t n_batches, int64_t batch, int64
   TRS_REQUIRE(n_batches > 0 && batch > 0 && n_users > 0 && ukeys_bytes_out && uvals_bytes_out && temp_bytes_out,
               "trs_epoch_user_dups_sizes: bad arguments");
   TRS_REQUIRE(n_batches * batch < ((int64_t)1 << 32), "trs_epoch_user_dups_sizes: slice too long");
-  const int bits = bits_for(n_users) + bits_for(n_batches);
-  const int kb = bits <= 32 ? 4 : 8;
+  const int bits = bits_for(n_users);
+  TRS_REQUIRE(bits <= 32, "trs_epoch_user_dups_sizes: user ids do not fit 32 bits");
+  const int kb = 4;
   const size_t n = (size_t)(n_batches * batch);
   size_t temp = 0;
-  hipError_t e;
-  if (kb == 4)
-    e = rocprim::radix_sort_pairs(nullptr, temp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                  (uint32_t*)nullptr, n, 0u, (unsigned)bits, (hipStream_t)0);
-  else
-    e = rocprim::radix_sort_pairs(nullptr, temp, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
-                                  (uint32_t*)nullptr, n, 0u, (unsigned)bits, (hipStream_t)0);
+  hipError_t e = rocprim::segmented_radix_sort_pairs<UserSortCfg>(
+      nullptr, temp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n,
+      (unsigned)n_batches, seg_it(0, (uint32_t)batch), seg_it(1, (uint32_t)batch), 0u, (unsigned)bits, (hipStream_t)0);
   TRS_REQUIRE(e == hipSuccess, "trs_epoch_user_dups_sizes: rocprim size query failed");
   *ukeys_bytes_out = 2 * (int64_t)n * kb;
   *uvals_bytes_out = 2 * (int64_t)n * 4;
@@ -591,34 +592,25 @@ extern "C" int trs_epoch_user_dups(const int32_t* user_dev, int64_t n_batches, i
               "trs_epoch_user_dups: bad sizes");
   const int64_t n_pos = n_batches * batch;
   const int user_bits = bits_for(n_users);
-  const int bits = user_bits + bits_for(n_batches);
+  TRS_REQUIRE(user_bits <= 32, "trs_epoch_user_dups: user ids do not fit 32 bits");
   hipStream_t s = (hipStream_t)stream;
   const dim3 gr(trs_grid(n_pos, TRS_BLOCK)), bl(TRS_BLOCK);
   size_t temp = (size_t)temp_bytes;
   uint32_t* vin = (uint32_t*)uvals_dev;
-  hipError_t e;
-  if (bits <= 32) {
-    uint32_t* kin = (uint32_t*)ukeys_dev;
-    hipLaunchKernelGGL((user_keys_kernel<uint32_t>), gr, bl, 0, s, user_dev, n_pos, batch, user_bits, kin, vin);
-    e = rocprim::radix_sort_pairs(temp_dev, temp, kin, kin + n_pos, vin, vin + n_pos, (size_t)n_pos, 0u,
-                                  (unsigned)bits, s);
-    if (e == hipSuccess)
-      hipLaunchKernelGGL((user_flags_kernel<uint32_t>), gr, bl, 0, s, kin + n_pos, vin + n_pos, n_pos, flags_out_dev);
-    if (sorted_ukeys_out) *sorted_ukeys_out = (void*)(kin + n_pos);
-    if (ukey_bytes_out) *ukey_bytes_out = 4;
-  } else {
-    uint64_t* kin = (uint64_t*)ukeys_dev;
-    hipLaunchKernelGGL((user_keys_kernel<uint64_t>), gr, bl, 0, s, user_dev, n_pos, batch, user_bits, kin, vin);
-    e = rocprim::radix_sort_pairs(temp_dev, temp, kin, kin + n_pos, vin, vin + n_pos, (size_t)n_pos, 0u,
-                                  (unsigned)bits, s);
-    if (e == hipSuccess)
-      hipLaunchKernelGGL((user_flags_kernel<uint64_t>), gr, bl, 0, s, kin + n_pos, vin + n_pos, n_pos, flags_out_dev);
-    if (sorted_ukeys_out) *sorted_ukeys_out = (void*)(kin + n_pos);
-    if (ukey_bytes_out) *ukey_bytes_out = 8;
-  }
+  uint32_t* kin = (uint32_t*)ukeys_dev;
+  hipLaunchKernelGGL((user_keys_kernel<uint32_t>), gr, bl, 0, s, user_dev, n_pos, kin, vin);
+  // one segment per batch, keys = user id: two 10-bit passes for up to 2^20 users
+  hipError_t e = rocprim::segmented_radix_sort_pairs<UserSortCfg>(
+      temp_dev, temp, kin, kin + n_pos, vin, vin + n_pos, (size_t)n_pos, (unsigned)n_batches,
+      seg_it(0, (uint32_t)batch), seg_it(1, (uint32_t)batch), 0u, (unsigned)user_bits, s);
+  if (e == hipSuccess)
+    hipLaunchKernelGGL((user_flags_kernel<uint32_t>), gr, bl, 0, s, kin + n_pos, vin + n_pos, n_pos, batch,
+                       flags_out_dev);
+  if (sorted_ukeys_out) *sorted_ukeys_out = (void*)(kin + n_pos);
+  if (ukey_bytes_out) *ukey_bytes_out = 4;
   if (sorted_uvals_out) *sorted_uvals_out = (void*)(vin + n_pos);
   if (e != hipSuccess) {
-    trs_set_error("trs_epoch_user_dups: rocprim::radix_sort_pairs failed: %s", hipGetErrorString(e));
+    trs_set_error("trs_epoch_user_dups: rocprim::segmented_radix_sort_pairs failed: %s", hipGetErrorString(e));
     return TRS_E_LAUNCH;
   }
   TRS_CHECK_LAUNCH("user_keys/flags_kernel");
@@ -628,11 +620,13 @@ extern "C" int trs_epoch_user_dups(const int32_t* user_dev, int64_t n_batches, i
 // One launch of the sorted item update for a step (used by trs_train_steps_sgd's sorted mode).
 int trs_launch_sorted_item_update(const trs_tables* tables, const void* keys_step, const void* vals_step, int key_bytes,
                                   int64_t batch, int64_t n_batches_bits_items, const float* gz, float lr,
-                                  uint64_t* uown, uint32_t* udup, uint32_t stamp, const float* ustage, hipStream_t s) {
+                                  uint64_t* uown, uint32_t* udup, uint32_t stamp, const float* ustage,
+                                  const int32_t* user_ids, hipStream_t s) {
   SortedArgs a = {};
   a.T = *tables;
   a.keys = keys_step;
   a.vals = (const RefPayload*)vals_step;
+  a.user_ids = user_ids;
   a.B = batch;
   a.item_bits = (int)n_batches_bits_items;
   a.gz = gz;

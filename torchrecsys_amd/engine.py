@@ -173,7 +173,7 @@ class SparseScorerTrainer:
             self._collect_events(te, ns)
 
     # ---- presorted item references (csrc/presort.hip) ---------------------------------------------------------------
-    SLICE_BATCHES = 256  # batches grouped per presort call (bounds the buffers: 2*256*B references)
+    SLICE_BATCHES = int(os.environ.get("TRS_SLICE_BATCHES", "512"))  # batches grouped per presort call (bounds the buffers: 2 x 512 x B references per set)
 
     def wants_presort(self, batch):
         """Group the item references by row once per epoch slice (removes the float atomics from the item update and

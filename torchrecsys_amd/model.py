@@ -259,6 +259,7 @@ class TorchRecSys(torch.nn.Module):
                                                           torch.profiler.ProfilerActivity.CUDA],
                                               record_shapes=True, profile_memory=True, with_stack=True)
                 prof.__enter__()
+            runner.more_epochs = epoch < epochs - 1  # lets the last slice's steps hide the next epoch's first presort
             runner.begin_epoch()
             runner.run_steps(runner.num_batches)
             avg_loss = runner.end_epoch()
@@ -372,17 +373,21 @@ class FitRunner:
             self.ep = m._host_epoch(self.data, self.loader)
         else:
             self.st = m._device_stream('train')
-            ge = m._fit_epochs_done
-            seed = m.seed + 1000003 * tdist.world_info()[0]  # every rank draws its own negatives
-            self.shuffle_key, self.sample_seed = _mix64(seed, 2 * ge + 1), _mix64(seed, 2 * ge + 2)
+            self.shuffle_key, self.sample_seed = self._epoch_keys(m._fit_epochs_done)
 
-    def _presort(self, s0, full, prefetch=False):
+    def _epoch_keys(self, epochs_done):
+        """(shuffle key, sampler seed) of the device-RNG epoch that follows `epochs_done` finished ones."""
+        seed = self.m.seed + 1000003 * tdist.world_info()[0]  # every rank draws its own negatives
+        return _mix64(seed, 2 * epochs_done + 1), _mix64(seed, 2 * epochs_done + 2)
+
+    def _presort(self, s0, full, prefetch=False, next_epoch=False):
         m, B, sl = self.m, self.batch_size, self.trainer.SLICE_BATCHES
         nb = min(sl, full - s0)
-        tag = (self._epoch_no, s0, nb, B)
+        tag = (self._epoch_no + int(next_epoch), s0, nb, B)
         if m.rng == 'device':
-            return self.trainer.presort_slice(nb, B, self.st, self.shuffle_key, self.sample_seed, s0 * B, tag=tag,
-                                              prefetch=prefetch)
+            sk, ss = self._epoch_keys(m._fit_epochs_done + 1) if next_epoch else (self.shuffle_key, self.sample_seed)
+            return self.trainer.presort_slice(nb, B, self.st, sk, ss, s0 * B, tag=tag, prefetch=prefetch)
+        assert not next_epoch  # the reference-RNG epoch is drawn from the host generators at begin_epoch
         return self.trainer.presort_slice(nb, B, given_ids=[self.ep[k_][s0 * B:(s0 + nb) * B]
                                                             for k_ in ('user', 'pos', 'neg')], tag=tag,
                                           prefetch=prefetch)
@@ -407,6 +412,9 @@ class FitRunner:
                         self._slice = (s0, self._presort(s0, full))
                         if s0 + sl < full:  # next slice: sorted on a side stream while this slice's steps run
                             self._presort(s0 + sl, full, prefetch=True)
+                        elif m.rng == 'device' and getattr(self, 'more_epochs', True):  # last slice: the next epoch's keys
+                            # are known, start on its first slice
+                            self._presort(0, full, prefetch=True, next_epoch=True)
                     s0, ps = self._slice
                     n = min(n, s0 + ps.n_batches - b)
                     self.trainer.fast_sorted_steps(ps, b - s0, B, n, self.loss_sums[b:b + n])

@@ -205,7 +205,7 @@ class EpochPresort:
         """(user, pos, neg id views, sorted keys address, sorted vals address, user-duplicate flags view) for the steps
         starting at batch b."""
         o = b * self.batch
-        return ([t[o:] for t in self.ids], self.sorted_keys + 2 * o * self.key_bytes, self.sorted_vals + 2 * o * 8,
+        return ([t[o:] for t in self.ids], self.sorted_keys + 2 * o * self.key_bytes, self.sorted_vals + 2 * o * 4,
                 self.user_dup[o:], (self.sorted_ukeys + o * self.ukey_bytes, self.sorted_uvals + o * 4,
                                     self.ukey_bytes, o))
 
