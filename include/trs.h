@@ -164,19 +164,19 @@ int trs_train_steps_sgd(int net, const trs_tables* tables, const int32_t* stream
                         float* ustage_buf_dev, const void* sorted_ukeys_dev, const void* sorted_uvals_dev,
                         int32_t ukey_bytes, int64_t slice_pos0, void** events, void* stream);
 
-/* Epoch-level grouping of the item references by row (dense regime: most item rows are referenced several times per
- * step).  trs_epoch_presort covers n_batches whole batches starting at epoch position first_pos: it writes the triples'
- * ids (generated from the resident stream exactly as trs_batch_prepare would, or taken as given when stream_ui is NULL)
- * and the 2*batch references of every batch sorted by item row (rocprim radix sort; key = batch*2^bits(n_items) + item,
- * payload = {user, (t<<1)|which}).  Passing the sorted arrays (offset to the first batch of the call) to
+/* Epoch-level grouping of the item references by row.  trs_epoch_presort covers n_batches whole batches starting at
+ * epoch position first_pos: it writes the triples' ids (generated from the resident stream exactly as
+ * trs_batch_prepare would, or taken as given when stream_ui is NULL) and the 2*batch references of every batch sorted
+ * by item row (rocprim segmented radix sort, one segment per batch; key = item row (uint32), payload = (t<<1)|which
+ * (uint32), t = position inside the batch).  Passing the sorted arrays (offset to the first batch of the call) to
  * trs_train_steps_sgd together with the id arrays replaces K2a/K2b by one atomic-free launch: each run of equal keys is
  * summed by one lane group and applied with a plain whole-row read-modify-write (runs are cut every 64 references; cut
  * pieces of hot rows use float atomics).  Buffers: keys/vals two halves each (sizes from trs_epoch_presort_sizes). */
 /* Per-position flags of an epoch slice: 1 iff the triple's user is referenced by another triple of the same batch
- * (sort of (batch, user) pairs).  Passing them (offset to the first batch) with a (batch,D) staging buffer to
+ * (segmented sort of the user ids, one segment per batch).  Passing them (offset to the first batch) with a (batch,D) staging buffer to
  * trs_train_steps_sgd in presorted mode lets K1 apply the user update itself for users referenced once in the batch
  * (plain store; K1 then stages the OLD user row for the item update instead of the gradient) — K3 shrinks to the
- * duplicated users: with the slice's sorted (batch,user) pairs (offset to the call's first batch; slice_pos0 = that
+ * duplicated users: with the slice's sorted (user, position) pairs (offset to the call's first batch; slice_pos0 = that
  * batch's first position in the slice) each run of equal users is summed by one lane group and applied with one plain
  * read-modify-write.  The step then contains no float atomic except for cut runs of hot item rows. */
 int trs_epoch_user_dups_sizes(int64_t n_batches, int64_t batch, int64_t n_users, int64_t* ukeys_bytes_out,
