@@ -1,4 +1,4 @@
-"""Scratch: where does the time go at an epoch boundary (c2)?"""
+"""Where the time goes around an epoch boundary at c2 (first steps under the next slice's presort, steady steps, tail)."""
 import os, sys, time, io, contextlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
