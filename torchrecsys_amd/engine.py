@@ -122,6 +122,15 @@ class SparseScorerTrainer:
         self.row_state = {}
         if self.kind in ("sparse_adam", "adagrad"):
             self.row_state = {id(p): RowState(p) for p in self.params}
+        # presorted epoch slices (csrc/presort.hip): two buffer sets, the one being built on the side stream and the one
+        # the step kernels read
+        self.ustage = None            # (capacity, D) pre-update user rows staged by K1 for the item update
+        self._ps_fits = {}            # batch size -> do the two buffer sets fit
+        self._ps_sets = [None, None]  # ops.EpochPresort per set
+        self._ps_tags = [None, None]  # what each set holds (epoch, first batch, batches, batch size)
+        self._ps_done = [None, None]  # (slice view, completion event) of a prefetched set
+        self._ps_cur = 1              # set the step kernels currently read
+        self._ps_stream = None        # side HIP stream of the prefetch
 
     def _views(self, B):
         """Staging views for a batch of B <= capacity rows (contiguous (R,B,D) / (R,B) prefixes)."""
@@ -184,7 +193,7 @@ class SparseScorerTrainer:
         dense = float(os.environ.get("TRS_PRESORT_MIN_DENSITY", "0"))
         if self.fast_lr is None or 2 * batch < dense * n_items:
             return False
-        memo = self.__dict__.setdefault("_ps_fits", {})
+        memo = self._ps_fits
         if batch not in memo:  # decided once: two buffer sets (one being sorted while the other is read)
             need = 2 * ops.EpochPresort.bytes_needed(self.SLICE_BATCHES, batch, n_items)
             free, _ = torch.cuda.mem_get_info(self.dev)
@@ -192,7 +201,7 @@ class SparseScorerTrainer:
         return memo[batch]
 
     def _presort_run(self, i, n_batches, batch, st, shuffle_key, sample_seed, first_pos, given_ids):
-        sets = self.__dict__.setdefault("_ps_sets", [None, None])
+        sets = self._ps_sets
         ps = sets[i]
         if ps is None or ps.batch != batch or ps.n_batches < n_batches:
             ps = sets[i] = ops.EpochPresort(max(n_batches, min(self.SLICE_BATCHES, n_batches)), batch,
@@ -217,15 +226,13 @@ class SparseScorerTrainer:
         up later by a call with the same `tag`."""
         if st is not None and "ui" not in st:
             st["ui"] = ops.interleave_stream(st["user"], st["pos"])
-        tags = self.__dict__.setdefault("_ps_tags", [None, None])
-        done = self.__dict__.setdefault("_ps_done", [None, None])
-        cur = getattr(self, "_ps_cur", 1)
+        tags, done, cur = self._ps_tags, self._ps_done, self._ps_cur
         main = torch.cuda.current_stream(self.dev)
         if prefetch:
             i = 1 - cur
             if tag is not None and tags[i] == tag:
                 return None
-            if getattr(self, "_ps_stream", None) is None:
+            if self._ps_stream is None:
                 self._ps_stream = torch.cuda.Stream(self.dev)
             side = self._ps_stream
             side.wait_stream(main)  # the steps that read set i were queued before this point
@@ -242,7 +249,7 @@ class SparseScorerTrainer:
                 self._ps_cur = i
                 return ps
         i = 1 - cur
-        if getattr(self, "_ps_stream", None) is not None:
+        if self._ps_stream is not None:
             main.wait_stream(self._ps_stream)  # a prefetch may still be writing set i
         ps = self._presort_run(i, n_batches, batch, st, shuffle_key, sample_seed, first_pos, given_ids)
         tags[i], done[i] = tag, None
@@ -252,7 +259,7 @@ class SparseScorerTrainer:
     def fast_sorted_steps(self, ps, b_in_slice, batch, n_steps, loss_sums):
         te, evs, ns = self._make_events(n_steps) if self.kernel_events is not None else (None, None, 0)
         ids, sk, sv, udup, usorted = ps.step_args(b_in_slice)
-        if getattr(self, "ustage", None) is None:
+        if self.ustage is None:
             self.ustage = torch.empty_like(self.du)  # pre-update user rows staged by K1 for the item update
         ops.train_steps_sgd(self.net.NET, self.net.tables(), None, None, 0, 0, 0, batch, n_steps, self.fast_lr, *ids,
                             self.gz, self.du, loss_sums, self.err, self.scratch, self._stamps(n_steps), evs, sk, sv,
