@@ -153,6 +153,28 @@ int trs_score_backward(int net, const trs_tables* tables, const trs_batch* batch
  * scratch: NULL or trs_train_scratch_bytes(n_users, n_items, batch, D) bytes, zero-initialised once; first_stamp: step counter
  * of the first step, non-zero, strictly increasing over the life of the scratch (re-zero the scratch before it wraps).
  * events: NULL, or 4*n_steps hipEvent_t handles recorded at the K1 | K2a+K2b | K3 boundaries of each step (a step whose handles are NULL is not timed) (bench.py). */
+/* Update rule of the presorted two-launch step (opt == NULL: plain SGD with the lr argument).  The adaptive rules are
+ * the ones the reference's users can actually run on its sparse embedding gradients:
+ * torch.optim.SparseAdam (lazy Adam: rows present in the batch only) and torch.optim.Adagrad's sparse branch, applied
+ * to the COALESCED gradient of each row — which the presorted runs provide: users referenced once are updated by K1,
+ * duplicated users and item rows by their sorted runs; item runs cut at a 64-reference chunk boundary sum their pieces
+ * in gacc and are applied by a small third launch.  State tables have the shapes of the weight tables and are updated
+ * in place (the host mirror keeps them in optimizer.state[p], so optimizer.state_dict() stays truthful). */
+#define TRS_OPT_SGD 0
+#define TRS_OPT_SPARSE_ADAM 1
+#define TRS_OPT_ADAGRAD 2
+typedef struct trs_opt {
+  int32_t kind;
+  float lr, beta1, beta2, eps, lr_decay;
+  int64_t step0;       /* optimiser step count before the first step of the call (same for the four tables) */
+  float *user_s1, *user_s2, *item_s1, *item_s2;                 /* exp_avg | sum, exp_avg_sq | NULL        (n, D) */
+  float *user_lin_s1, *user_lin_s2, *item_lin_s1, *item_lin_s2; /* the same for the 1-wide tables          (n, 1) */
+  float* gacc;         /* (n_items, D) all-zero between steps: meeting point of the pieces of a cut item run */
+  float* gacc_lin;     /* (n_items) */
+  int32_t* cut_rows;   /* (cut_capacity) rows with a cut run in the current step */
+  int32_t* cut_count;  /* [2] zero-initialised once; the steps alternate between the two counters */
+  int32_t cut_capacity; /* >= 2*batch/64 + the number of rows with more than 64 references (2*batch is always enough) */
+} trs_opt;
 int64_t trs_train_scratch_bytes(int64_t n_users, int64_t n_items, int64_t batch, int32_t D);
 int trs_train_steps_sgd(int net, const trs_tables* tables, const int32_t* stream_ui_dev,
                         const int32_t* neg_static_dev, int64_t N,
@@ -162,7 +184,7 @@ int trs_train_steps_sgd(int net, const trs_tables* tables, const int32_t* stream
                         void* scratch_dev, uint32_t first_stamp, const void* sorted_keys_dev,
                         const void* sorted_vals_dev, int32_t key_bytes, const uint8_t* user_dup_flags_dev,
                         float* ustage_buf_dev, const void* sorted_ukeys_dev, const void* sorted_uvals_dev,
-                        int32_t ukey_bytes, int64_t slice_pos0, void** events, void* stream);
+                        int32_t ukey_bytes, int64_t slice_pos0, const trs_opt* opt, void** events, void* stream);
 
 /* Epoch-level grouping of the item references by row.  trs_epoch_presort covers n_batches whole batches starting at
  * epoch position first_pos: it writes the triples' ids (generated from the resident stream exactly as

@@ -291,6 +291,41 @@ def test_presort_slices_prefetched_on_the_side_stream(net_type, rng, monkeypatch
 
 
 @pytest.mark.parametrize("net_type", SPARSE_NETS)
+@pytest.mark.parametrize("oname", ["sparseadam", "adagrad"])
+def test_adaptive_optimisers_fused_presorted_path_equals_generic_path(net_type, oname, monkeypatch):
+    """fit() with SparseAdam / Adagrad runs the presorted two-launch step with the rule fused in (state in
+    optimizer.state[p]); forcing the generic staged path (accumulate + elected-owner apply) on the same batches must
+    give the same training: printed losses, weights and optimiser state."""
+    from torchrecsys_amd.engine import SparseScorerTrainer
+    from torchrecsys_amd.model import TorchRecSys
+    g = load_golden(f"g4_{net_type}_dyn.npz")
+    df = pd.DataFrame({"user": g["df_user"], "item": g["df_item"]})
+    out = {}
+    for path in ("fused", "generic"):
+        if path == "generic":
+            monkeypatch.setattr(SparseScorerTrainer, "wants_presort", lambda self, batch: False)
+        seed(7)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            model = TorchRecSys(dataset=df, user_id_col="user", item_id_col="item", n_factors=16, net_type=net_type,
+                                dynamic_neg_sampling=True)
+            opt = (torch.optim.SparseAdam(list(model.parameters()), lr=0.01) if oname == "sparseadam"
+                   else torch.optim.Adagrad(model.parameters(), lr=0.05))
+            model.fit(optimizer=opt, epochs=2, batch_size=256)
+        losses = [float(x) for x in re.findall(r"Training Loss: ([0-9.]+)", buf.getvalue())]
+        st = opt.state[model.net.item.weight]
+        out[path] = (losses, {k: v.cpu().numpy() for k, v in model.state_dict().items()},
+                     (st["exp_avg_sq"] if oname == "sparseadam" else st["sum"]).cpu().numpy(), int(st["step"]))
+    assert out["fused"][0] == pytest.approx(out["generic"][0], abs=2.01e-4) and len(out["fused"][0]) == 2
+    n_batches = -(-int(len(df) * 0.8) // 256)
+    assert out["fused"][3] == out["generic"][3] == 2 * n_batches  # every step counted once (C loop + partial last batch)
+    for k, v in out["generic"][1].items():
+        d = np.abs(out["fused"][1][k] - v).max(axis=1)
+        assert (d <= 1e-3 * np.abs(v).max()).mean() >= 0.97, k  # bulk: see test_presorted_adaptive_rules_match_the_oracle
+    assert rel_err(out["fused"][2], out["generic"][2]) < 1e-2
+
+
+@pytest.mark.parametrize("net_type", SPARSE_NETS)
 def test_device_rng_mode_trains(net_type):
     """rng='device': on-GPU shuffle + sampler; not the reference's stream, but it must learn the same problem."""
     g = load_golden(f"g4_{net_type}_dyn.npz")

@@ -51,6 +51,20 @@ class TrsBatch(C.Structure):
     ]
 
 
+class TrsOpt(C.Structure):
+    """struct trs_opt (include/trs.h): update rule of the presorted step."""
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("lr_decay", C.c_float),
+        ("step0", C.c_int64),
+        ("user_s1", C.c_void_p), ("user_s2", C.c_void_p), ("item_s1", C.c_void_p), ("item_s2", C.c_void_p),
+        ("user_lin_s1", C.c_void_p), ("user_lin_s2", C.c_void_p), ("item_lin_s1", C.c_void_p),
+        ("item_lin_s2", C.c_void_p),
+        ("gacc", C.c_void_p), ("gacc_lin", C.c_void_p), ("cut_rows", C.c_void_p), ("cut_count", C.c_void_p),
+        ("cut_capacity", C.c_int32),
+    ]
+
+
 _vp, _i32, _i64, _u64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
 _T, _Bp = C.POINTER(TrsTables), C.POINTER(TrsBatch)
 
@@ -76,7 +90,7 @@ PROTOTYPES = {
     "trs_train_scratch_bytes": (C.c_int64, [_i64, _i64, _i64, _i32]),
     "trs_train_steps_sgd": (C.c_int, [C.c_int, _T, _vp, _vp, _i64, _u64, _u64, _i64, _i64, _i32, _f, _vp, _vp, _vp,
                                       _vp, _vp, _vp, _vp, _vp, C.c_uint32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32,
-                                      _i64, _vp, _vp]),
+                                      _i64, C.POINTER(TrsOpt), _vp, _vp]),
     "trs_epoch_user_dups_sizes": (C.c_int, [_i64, _i64, _i64, c_int64_p, c_int64_p, c_int64_p]),
     "trs_epoch_user_dups": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, C.POINTER(C.c_void_p),
                                       C.POINTER(C.c_void_p), c_int32_p, _vp]),

@@ -19,7 +19,9 @@
 // Float atomics run at ~1.3 TB/s chip-wide against ~6 TB/s for plain stores (MI355X_MICROARCH.md "Global float
 // atomics"), so every reference that is provably alone on its row takes the plain path.
 #include "score_kernels.h"
+#include "opt_rows.h"
 
+#include <math.h>
 #include <stdlib.h>
 
 namespace trs {
@@ -58,6 +60,7 @@ struct FastArgs {
   // itself for users referenced once in the batch and stages the OLD user row for K2 instead of the gradient
   const uint8_t* udup_pos;  // (B) 1: this triple's user has another reference in the batch; NULL: mode off
   float* ustage;            // (B,D) pre-update user rows, read by the sorted item update
+  OptArgs o;                // update rule of the presorted mode (kind OPT_SGD: lr above)
 };
 
 struct RawIds {   // loads issued, nothing consumed yet
@@ -127,22 +130,35 @@ template <int VEC, int K>
 struct TripleRows {
   RowReg<VEC, K> u, pi, ni;
   float ul, pl, nl;
+  RowReg<VEC, K> us1, us2;  // adaptive rules: the user row's optimiser state (exp_avg | sum, exp_avg_sq)
+  float uls1, uls2;
 };
 
-template <int VEC, int G, int K, bool FULL>
-__device__ __forceinline__ void load_rows(TripleRows<VEC, K>& r, const trs_tables& T, const TripleIds& id, int lig) {
+template <int VEC, int G, int K, bool FULL, int OPT>
+__device__ __forceinline__ void load_rows(TripleRows<VEC, K>& r, const trs_tables& T, const OptArgs& o,
+                                          const TripleIds& id, int lig) {
   row_load<VEC, G, K, FULL>(r.u, T.user, id.u, T.D, lig);
   row_load<VEC, G, K, FULL>(r.pi, T.item, id.p, T.D, lig);
   row_load<VEC, G, K, FULL>(r.ni, T.item, id.n, T.D, lig);
   r.ul = T.user_lin[id.u];
   r.pl = T.item_lin[id.p];
   r.nl = T.item_lin[id.n];
+  if (OPT != OPT_SGD) {  // compile-time: issued with the rows, unconditionally (duplicated users waste them: 6 % at c2)
+    row_load<VEC, G, K, FULL>(r.us1, o.user_s1, id.u, T.D, lig);
+    r.uls1 = o.user_lin_s1[id.u];
+    if (OPT == OPT_ADAM) {
+      row_load<VEC, G, K, FULL>(r.us2, o.user_s2, id.u, T.D, lig);
+      r.uls2 = o.user_lin_s2[id.u];
+    }
+  }
 }
 
 // INL (presorted mode with user-duplicate flags): the user update of a triple whose user is referenced once in the
 // batch is applied right here (the row is in registers and nobody else reads it this step); the OLD user row is staged
 // for K2 instead of the gradient; only duplicated users stage their gradient for the small atomic pass K3'.
-template <int NET, int VEC, int G, int K, int SRC, bool FULL, bool INL>
+// OPT != OPT_SGD (INL only): the same in-place user update with the SparseAdam / Adagrad rule; its state rows travel with
+// the user row.
+template <int NET, int VEC, int G, int K, int SRC, bool FULL, bool INL, int OPT = OPT_SGD>
 __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) {
   constexpr int N = K * VEC;
   constexpr int TPW = TRS_WAVE / G;
@@ -162,7 +178,7 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
   const int64_t niter = t_first < B ? (B - t_first + stride - 1) / stride : 0;
 
   // Reduce one triple whose rows are in registers and write its staging (stores only: no waits on loads in flight).
-  auto reduce = [&](const TripleRows<VEC, K>& r, const TripleIds& id, int64_t tt) {
+  auto reduce = [&](TripleRows<VEC, K>& r, const TripleIds& id, int64_t tt) {
     const bool live = id.valid && id.ok;
     if (id.valid && !id.ok && lig == 0 && a.err) atomicOr(a.err, 1);
     float pp = 0.f, pn = 0.f;
@@ -210,10 +226,23 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
           row_store<VEC, G, K>(g, a.du + tt * (int64_t)D, D, lig);
         } else {
           RowReg<VEC, K> un;
+          if (OPT == OPT_SGD) {
 #pragma unroll
-          for (int n = 0; n < N; ++n) un.v[n] = r.u.v[n] + (-a.lr) * g.v[n];
-          row_store<VEC, G, K>(un, T.user + id.u * (int64_t)D, D, lig);
-          if (lig == 0) T.user_lin[id.u] = r.ul + (-a.lr) * (gp + gn);
+            for (int n = 0; n < N; ++n) un.v[n] = r.u.v[n] + (-a.lr) * g.v[n];
+            row_store<VEC, G, K>(un, T.user + id.u * (int64_t)D, D, lig);
+            if (lig == 0) T.user_lin[id.u] = r.ul + (-a.lr) * (gp + gn);
+          } else {
+#pragma unroll
+            for (int n = 0; n < N; ++n) un.v[n] = opt_apply<OPT>(r.u.v[n], g.v[n], r.us1.v[n], r.us2.v[n], a.o);
+            row_store<VEC, G, K>(un, T.user + id.u * (int64_t)D, D, lig);
+            row_store<VEC, G, K>(r.us1, a.o.user_s1 + id.u * (int64_t)D, D, lig);
+            if (OPT == OPT_ADAM) row_store<VEC, G, K>(r.us2, a.o.user_s2 + id.u * (int64_t)D, D, lig);
+            if (lig == 0) {
+              T.user_lin[id.u] = opt_apply<OPT>(r.ul, gp + gn, r.uls1, r.uls2, a.o);
+              a.o.user_lin_s1[id.u] = r.uls1;
+              if (OPT == OPT_ADAM) a.o.user_lin_s2[id.u] = r.uls2;
+            }
+          }
         }
       } else {
         row_store<VEC, G, K>(g, a.du + tt * (int64_t)D, D, lig);
@@ -248,16 +277,16 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
   TripleIds idE = finalize_ids<SRC>(a, wE);
   TripleIds idO;
   TripleRows<VEC, K> rE, rO;
-  load_rows<VEC, G, K, FULL>(rE, T, idE, lig);
+  load_rows<VEC, G, K, FULL, OPT>(rE, T, a.o, idE, lig);
   for (int64_t it = 0; it < niter2; it += 2) {
     wE = issue_ids<SRC, INL>(a, t + 2 * stride);
     idO = finalize_ids<SRC>(a, wO);
-    load_rows<VEC, G, K, FULL>(rO, T, idO, lig);
+    load_rows<VEC, G, K, FULL, OPT>(rO, T, a.o, idO, lig);
     reduce(rE, idE, t);
 
     wO = issue_ids<SRC, INL>(a, t + 3 * stride);
     idE = finalize_ids<SRC>(a, wE);
-    load_rows<VEC, G, K, FULL>(rE, T, idE, lig);
+    load_rows<VEC, G, K, FULL, OPT>(rE, T, a.o, idE, lig);
     reduce(rO, idO, t + stride);
     t += 2 * stride;
   }
@@ -620,7 +649,11 @@ static int launch_fwd_stage(const FastArgs& a, hipStream_t s) {
 #define TRS_LAUNCH(V, GG, KK, FULL)                                                                             \
   {                                                                                                             \
     const dim3 gr((unsigned)grid), bl(TRS_BLOCK);                                                               \
-    if (src == 0 && a.udup_pos) hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL, true>), gr, bl, 0, s, a); \
+    if (src == 0 && a.udup_pos && a.o.kind == OPT_ADAM)                                                          \
+      hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL, true, OPT_ADAM>), gr, bl, 0, s, a);           \
+    else if (src == 0 && a.udup_pos && a.o.kind == OPT_ADAGRAD)                                                  \
+      hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL, true, OPT_ADAGRAD>), gr, bl, 0, s, a);        \
+    else if (src == 0 && a.udup_pos) hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL, true>), gr, bl, 0, s, a); \
     else if (src == 0) hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL, false>), gr, bl, 0, s, a);  \
     else if (src == 1) hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 1, FULL, false>), gr, bl, 0, s, a);  \
     else hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 2, FULL, false>), gr, bl, 0, s, a);                \
@@ -735,7 +768,7 @@ int trs_item_bits_for(int64_t n_items);
 int trs_launch_sorted_updates_fused(const trs_tables* tables, const void* keys_step, const void* vals_step,
                                     int64_t batch, int64_t item_bits, const float* gz, float lr, const float* ustage,
                                     const void* ukeys_step, const void* uvals_step, int64_t q0, const float* du,
-                                    hipStream_t s);
+                                    const OptArgs* opt, int parity, hipStream_t s);
 int trs_launch_sorted_user_dup_update(const trs_tables* tables, const void* ukeys_step, const void* uvals_step,
                                       int key_bytes, int64_t batch, int64_t q0, const float* du, const float* gz,
                                       float lr, hipStream_t s);
@@ -754,7 +787,7 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
                                    const void* sorted_keys_dev, const void* sorted_vals_dev, int32_t key_bytes,
                                    const uint8_t* user_dup_flags_dev, float* ustage_buf_dev,
                                    const void* sorted_ukeys_dev, const void* sorted_uvals_dev, int32_t ukey_bytes,
-                                   int64_t slice_pos0, void** events, void* stream) {
+                                   int64_t slice_pos0, const trs_opt* opt, void** events, void* stream) {
   TRS_REQUIRE(net == TRS_NET_LINEAR || net == TRS_NET_FM, "trs_train_steps_sgd: bad net");
   TRS_REQUIRE(tables && tables->M == 0, "trs_train_steps_sgd: only scorers without metadata (M == 0)");
   TRS_REQUIRE(tables->user && tables->item && tables->user_lin && tables->item_lin, "trs_train_steps_sgd: NULL table");
@@ -771,6 +804,18 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
                 "trs_train_steps_sgd: the presorted mode needs the epoch's id arrays, scratch and sorted references");
     TRS_REQUIRE(!inl || (ustage_buf_dev && sorted_ukeys_dev && sorted_uvals_dev && (ukey_bytes == 4 || ukey_bytes == 8)),
                 "trs_train_steps_sgd: user-duplicate flags need the staging buffer and the slice's sorted (batch,user) pairs");
+  }
+  const bool adaptive = opt && opt->kind != TRS_OPT_SGD;
+  if (adaptive) {
+    TRS_REQUIRE(opt->kind == TRS_OPT_SPARSE_ADAM || opt->kind == TRS_OPT_ADAGRAD, "trs_train_steps_sgd: bad opt->kind");
+    TRS_REQUIRE(inl && key_bytes == 4 && ukey_bytes == 4,
+                "trs_train_steps_sgd: the adaptive rules need the presorted mode with user-duplicate flags");
+    TRS_REQUIRE(opt->user_s1 && opt->item_s1 && opt->user_lin_s1 && opt->item_lin_s1 && opt->gacc && opt->gacc_lin &&
+                    opt->cut_rows && opt->cut_count && opt->cut_capacity > 0 && opt->step0 >= 0,
+                "trs_train_steps_sgd: optimiser state / cut-run scratch is NULL");
+    TRS_REQUIRE(opt->kind != TRS_OPT_SPARSE_ADAM ||
+                    (opt->user_s2 && opt->item_s2 && opt->user_lin_s2 && opt->item_lin_s2),
+                "trs_train_steps_sgd: SparseAdam needs exp_avg_sq tables");
   }
   if (from_stream) {
     TRS_REQUIRE(N > 0 && first_pos >= 0 && first_pos + (int64_t)n_steps * batch <= N,
@@ -812,6 +857,20 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
       a.udup_pos = user_dup_flags_dev + (int64_t)st * batch;
       a.ustage = ustage_buf_dev;
     }
+    if (adaptive) {  // this step's effective learning rate, in double like the Python floats of torch.optim
+      OptArgs& o = a.o;
+      const double t = (double)(opt->step0 + st + 1);
+      o.kind = opt->kind == TRS_OPT_SPARSE_ADAM ? OPT_ADAM : OPT_ADAGRAD;
+      o.beta1 = opt->beta1; o.beta2 = opt->beta2; o.eps = opt->eps;
+      o.lr_eff = o.kind == OPT_ADAM
+                     ? (float)((double)opt->lr * sqrt(1.0 - pow((double)opt->beta2, t)) / (1.0 - pow((double)opt->beta1, t)))
+                     : (float)((double)opt->lr / (1.0 + (t - 1.0) * (double)opt->lr_decay));
+      o.user_s1 = opt->user_s1; o.user_s2 = opt->user_s2; o.item_s1 = opt->item_s1; o.item_s2 = opt->item_s2;
+      o.user_lin_s1 = opt->user_lin_s1; o.user_lin_s2 = opt->user_lin_s2;
+      o.item_lin_s1 = opt->item_lin_s1; o.item_lin_s2 = opt->item_lin_s2;
+      o.gacc = opt->gacc; o.gacc_lin = opt->gacc_lin;
+      o.cut_rows = opt->cut_rows; o.cut_count = opt->cut_count; o.cut_capacity = opt->cut_capacity;
+    }
     if (!from_stream) {  // step st reads its ids at [st*batch, (st+1)*batch) of the given arrays
       a.user = user_buf_dev + (int64_t)st * batch;
       a.pos = pos_buf_dev + (int64_t)st * batch;
@@ -832,7 +891,8 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
         const char* uk = (const char*)sorted_ukeys_dev + (int64_t)st * batch * 4;
         const char* uv = (const char*)sorted_uvals_dev + (int64_t)st * batch * 4;
         rc = trs_launch_sorted_updates_fused(tables, ks, vs, batch, item_bits, a.gz, a.lr, a.ustage, uk, uv,
-                                             slice_pos0 + (int64_t)st * batch, a.du, s);
+                                             slice_pos0 + (int64_t)st * batch, a.du, adaptive ? &a.o : nullptr,
+                                             (int)(a.stamp & 1u), s);
         if (rc) return rc;
         if (ev) {
           (void)hipEventRecord(ev[2], s);

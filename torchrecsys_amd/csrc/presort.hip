@@ -21,6 +21,7 @@
 #include <rocprim/iterator/transform_iterator.hpp>
 
 #include "score_kernels.h"
+#include "opt_rows.h"
 
 namespace trs {
 
@@ -113,6 +114,8 @@ struct SortedArgs {
   uint32_t* udup;
   uint32_t stamp;
   const float* ustage;  // (B,D) pre-update user rows staged by K1 (indexed by t), or NULL: read the user table
+  OptArgs o;            // staged form: update rule (OPT_SGD: lr above); adaptive rules coalesce whole runs first
+  int parity;           // step parity: which cut-run counter this step appends to
 };
 
 constexpr int RUN_CHUNK = 64;  // runs are cut at multiples of this many references
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(TRS_BLOCK) void sorted_item_update_kernel(const Sor
 // member rows for SLOTS runs at once — no load sits under a branch and no load depends on a loop-carried compare.
 constexpr int SI_SLOTS = 3, SI_MEMB = 3;
 
-template <typename KeyT, int VEC, int G, int K, bool FULL>
+template <typename KeyT, int VEC, int G, int K, bool FULL, int OPT = OPT_SGD>
 __device__ __forceinline__ void sorted_item_update_staged_body(const SortedArgs& a, int block_id, int n_blocks) {
   constexpr int N = K * VEC;
   constexpr int TPW = TRS_WAVE / G;
@@ -228,7 +231,10 @@ __device__ __forceinline__ void sorted_item_update_staged_body(const SortedArgs&
     const KeyT knext = keys[base + RUN_CHUNK < n ? base + RUN_CHUNK : n - 1];  // first key of the next chunk
     const RefPayload me = a.vals[il];
     const int t = (int)(me.tw >> 1);
-    const float c = -a.lr * a.gz[(int64_t)(me.tw & 1u) * a.B + t];
+    // SGD is linear in the gradient: the learning rate is folded into the coefficient.  The adaptive rules need the
+    // coalesced gradient itself: c = gz.
+    const float gzv = a.gz[(int64_t)(me.tw & 1u) * a.B + t];
+    const float c = OPT == OPT_SGD ? -a.lr * gzv : gzv;
     const bool head = il == 0 || kp != k0;                // first reference of the row in this step
     const bool cont = valid && lane > 0 && !head;         // continues the run of the lane before it
     const bool lead = valid && !cont;
@@ -246,7 +252,8 @@ __device__ __forceinline__ void sorted_item_update_staged_body(const SortedArgs&
       bool has[SI_SLOTS];
       int64_t row[SI_SLOTS];
       RowReg<VEC, K> w[SI_SLOTS], u[SI_SLOTS][SI_MEMB];
-      float wl[SI_SLOTS], cm[SI_SLOTS][SI_MEMB];
+      RowReg<VEC, K> s1[SI_SLOTS], s2[SI_SLOTS];  // optimiser state rows (dead for SGD)
+      float wl[SI_SLOTS], cm[SI_SLOTS][SI_MEMB], ls1[SI_SLOTS], ls2[SI_SLOTS];
 #pragma unroll
       for (int s = 0; s < SI_SLOTS; ++s) {
         const int want = (r0 + s * NW) * TPW + gi;
@@ -260,6 +267,15 @@ __device__ __forceinline__ void sorted_item_update_staged_body(const SortedArgs&
         row[s] = has[s] ? (int64_t)((KeyT)key & row_mask) : 0;
         row_load<VEC, G, K, FULL>(w[s], T.item, row[s], D, lig);
         wl[s] = T.item_lin[row[s]];
+        ls1[s] = ls2[s] = 0.f;
+        if (OPT != OPT_SGD) {
+          row_load<VEC, G, K, FULL>(s1[s], a.o.item_s1, row[s], D, lig);
+          ls1[s] = a.o.item_lin_s1[row[s]];
+          if (OPT == OPT_ADAM) {
+            row_load<VEC, G, K, FULL>(s2[s], a.o.item_s2, row[s], D, lig);
+            ls2[s] = a.o.item_lin_s2[row[s]];
+          }
+        }
 #pragma unroll
         for (int j = 0; j < SI_MEMB; ++j) {
           const int src = l[s] + j < 64 ? l[s] + j : 63;
@@ -288,7 +304,8 @@ __device__ __forceinline__ void sorted_item_update_staged_body(const SortedArgs&
         for (int j = SI_MEMB; j < len[s]; ++j) {  // longer runs (hot rows): one more row per turn
           const RefPayload pl = a.vals[base + l[s] + j];
           const int tj = (int)(pl.tw >> 1);
-          const float cj = -a.lr * a.gz[(int64_t)(pl.tw & 1u) * a.B + tj];
+          const float gj = a.gz[(int64_t)(pl.tw & 1u) * a.B + tj];
+          const float cj = OPT == OPT_SGD ? -a.lr * gj : gj;
           RowReg<VEC, K> uj;
           row_load<VEC, G, K, FULL>(uj, a.ustage, (int64_t)tj, D, lig);
 #pragma unroll
@@ -298,10 +315,41 @@ __device__ __forceinline__ void sorted_item_update_staged_body(const SortedArgs&
         const bool cut_tail = (l[s] + len[s] == RUN_CHUNK) && (base + RUN_CHUNK < n) && knext == keyv[s];
         float* irow = T.item + row[s] * (int64_t)D;
         if (hd[s] != 0 && !cut_tail) {
+          if (OPT == OPT_SGD) {
 #pragma unroll
-          for (int q = 0; q < N; ++q) w[s].v[q] += acc.v[q];
-          row_store<VEC, G, K>(w[s], irow, D, lig);
-          if (lig == 0) T.item_lin[row[s]] = wl[s] + lin;
+            for (int q = 0; q < N; ++q) w[s].v[q] += acc.v[q];
+            row_store<VEC, G, K>(w[s], irow, D, lig);
+            if (lig == 0) T.item_lin[row[s]] = wl[s] + lin;
+          } else {  // the run is the row's whole gradient: apply the rule once, state rows beside the weights
+#pragma unroll
+            for (int q = 0; q < N; ++q) w[s].v[q] = opt_apply<OPT>(w[s].v[q], acc.v[q], s1[s].v[q], s2[s].v[q], a.o);
+            row_store<VEC, G, K>(w[s], irow, D, lig);
+            row_store<VEC, G, K>(s1[s], a.o.item_s1 + row[s] * (int64_t)D, D, lig);
+            if (OPT == OPT_ADAM) row_store<VEC, G, K>(s2[s], a.o.item_s2 + row[s] * (int64_t)D, D, lig);
+            if (lig == 0) {
+              T.item_lin[row[s]] = opt_apply<OPT>(wl[s], lin, ls1[s], ls2[s], a.o);
+              a.o.item_lin_s1[row[s]] = ls1[s];
+              if (OPT == OPT_ADAM) a.o.item_lin_s2[row[s]] = ls2[s];
+            }
+          }
+        } else if (OPT != OPT_SGD) {
+          // a piece of a run cut at a chunk boundary: the rule is not linear, so the pieces first meet in the (zeroed)
+          // gradient accumulator; the head piece lists the row for cut_rows_apply_kernel
+          float* grow = a.o.gacc + row[s] * (int64_t)D;
+#pragma unroll
+          for (int kk = 0; kk < K; ++kk) {
+            const int e = (kk * G + lig) * VEC;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q)
+              if (e + q < D) atomicAdd(grow + e + q, acc.v[kk * VEC + q]);
+          }
+          if (lig == 0) {
+            atomicAdd(a.o.gacc_lin + row[s], lin);
+            if (hd[s] != 0) {
+              const int slot = atomicAdd(a.o.cut_count + a.parity, 1);
+              if (slot < a.o.cut_capacity) a.o.cut_rows[slot] = (int32_t)row[s];
+            }
+          }
         } else {  // a cut piece of a long segment (hot row): several groups add into the row
 #pragma unroll
           for (int kk = 0; kk < K; ++kk) {
@@ -357,9 +405,10 @@ struct UserDupArgs {
   const float* du;        // (B,D) staged user-row gradients (written by K1 for duplicated users)
   const float* gz;        // (2,B)
   float lr;
+  OptArgs o;              // update rule (OPT_SGD: lr above)
 };
 
-template <typename KeyT, int VEC, int G, int K, bool FULL>
+template <typename KeyT, int VEC, int G, int K, bool FULL, int OPT = OPT_SGD>
 __device__ __forceinline__ void sorted_user_dup_update_body(const UserDupArgs& a, int block_id, int n_blocks) {
   constexpr int N = K * VEC;
   constexpr int TPW = TRS_WAVE / G;
@@ -407,9 +456,18 @@ __device__ __forceinline__ void sorted_user_dup_update_body(const UserDupArgs& a
       }
       const int64_t key_lo = __shfl((int)(uint32_t)(k0 & (KeyT)0xffffffffu), l, 64);
       const int64_t user = (int64_t)((uint32_t)key_lo) & (int64_t)user_mask;
-      RowReg<VEC, K> w, acc;
+      RowReg<VEC, K> w, acc, s1, s2;
       row_load<VEC, G, K, FULL>(w, T.user, user, D, lig);
       const float wl = T.user_lin[user];
+      float ls1 = 0.f, ls2 = 0.f;
+      if (OPT != OPT_SGD) {
+        row_load<VEC, G, K, FULL>(s1, a.o.user_s1, user, D, lig);
+        ls1 = a.o.user_lin_s1[user];
+        if (OPT == OPT_ADAM) {
+          row_load<VEC, G, K, FULL>(s2, a.o.user_s2, user, D, lig);
+          ls2 = a.o.user_lin_s2[user];
+        }
+      }
 #pragma unroll
       for (int q = 0; q < N; ++q) acc.v[q] = 0.f;
       float lin = 0.f;
@@ -436,10 +494,62 @@ __device__ __forceinline__ void sorted_user_dup_update_body(const UserDupArgs& a
           lin += a.gz[t] + a.gz[a.B + t];
         }
       }
+      if (OPT == OPT_SGD) {
 #pragma unroll
-      for (int q = 0; q < N; ++q) w.v[q] += (-a.lr) * acc.v[q];
-      row_store<VEC, G, K>(w, T.user + user * (int64_t)D, D, lig);
-      if (lig == 0) T.user_lin[user] = wl + (-a.lr) * lin;
+        for (int q = 0; q < N; ++q) w.v[q] += (-a.lr) * acc.v[q];
+        row_store<VEC, G, K>(w, T.user + user * (int64_t)D, D, lig);
+        if (lig == 0) T.user_lin[user] = wl + (-a.lr) * lin;
+      } else {
+#pragma unroll
+        for (int q = 0; q < N; ++q) w.v[q] = opt_apply<OPT>(w.v[q], acc.v[q], s1.v[q], s2.v[q], a.o);
+        row_store<VEC, G, K>(w, T.user + user * (int64_t)D, D, lig);
+        row_store<VEC, G, K>(s1, a.o.user_s1 + user * (int64_t)D, D, lig);
+        if (OPT == OPT_ADAM) row_store<VEC, G, K>(s2, a.o.user_s2 + user * (int64_t)D, D, lig);
+        if (lig == 0) {
+          T.user_lin[user] = opt_apply<OPT>(wl, lin, ls1, ls2, a.o);
+          a.o.user_lin_s1[user] = ls1;
+          if (OPT == OPT_ADAM) a.o.user_lin_s2[user] = ls2;
+        }
+      }
+    }
+  }
+}
+
+// Item rows whose run was cut at a chunk boundary (adaptive rules): the pieces' sums are in gacc; apply the rule once
+// per listed row, clear the accumulator row, and reset the OTHER step parity's counter for the next step.
+template <int VEC, int G, int K, bool FULL, int OPT>
+__global__ __launch_bounds__(TRS_BLOCK) void cut_rows_apply_kernel(const trs_tables T, const OptArgs o, int parity) {
+  constexpr int N = K * VEC;
+  constexpr int TPW = TRS_WAVE / G;
+  const int D = T.D;
+  const int lane = threadIdx.x & 63, lig = lane % G;
+  int count = o.cut_count[parity];
+  if (count > o.cut_capacity) count = o.cut_capacity;
+  if (blockIdx.x == 0 && threadIdx.x == 0) o.cut_count[parity ^ 1] = 0;
+  const int64_t wave = ((int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x) >> 6;
+  const int64_t nwave = ((int64_t)gridDim.x * TRS_BLOCK) >> 6;
+  for (int64_t i = wave * TPW + lane / G; i < count; i += nwave * TPW) {
+    const int64_t row = o.cut_rows[i];
+    RowReg<VEC, K> w, g, s1, s2, z;
+    row_load<VEC, G, K, FULL>(w, T.item, row, D, lig);
+    row_load<VEC, G, K, FULL>(g, o.gacc, row, D, lig);
+    row_load<VEC, G, K, FULL>(s1, o.item_s1, row, D, lig);
+    if (OPT == OPT_ADAM) row_load<VEC, G, K, FULL>(s2, o.item_s2, row, D, lig);
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      w.v[q] = opt_apply<OPT>(w.v[q], g.v[q], s1.v[q], s2.v[q], o);
+      z.v[q] = 0.f;
+    }
+    row_store<VEC, G, K>(w, T.item + row * (int64_t)D, D, lig);
+    row_store<VEC, G, K>(s1, o.item_s1 + row * (int64_t)D, D, lig);
+    if (OPT == OPT_ADAM) row_store<VEC, G, K>(s2, o.item_s2 + row * (int64_t)D, D, lig);
+    row_store<VEC, G, K>(z, o.gacc + row * (int64_t)D, D, lig);
+    if (lig == 0) {
+      float ls1 = o.item_lin_s1[row], ls2 = OPT == OPT_ADAM ? o.item_lin_s2[row] : 0.f;
+      T.item_lin[row] = opt_apply<OPT>(T.item_lin[row], o.gacc_lin[row], ls1, ls2, o);
+      o.item_lin_s1[row] = ls1;
+      if (OPT == OPT_ADAM) o.item_lin_s2[row] = ls2;
+      o.gacc_lin[row] = 0.f;
     }
   }
 }
@@ -457,14 +567,14 @@ __global__ __launch_bounds__(TRS_BLOCK) void sorted_user_dup_update_kernel(const
 // Both updates of a presorted step in ONE launch (they touch different tables and only depend on K1): the first
 // n_user_blocks workgroups walk the duplicated-user runs, the rest the item chunks.  Saves a kernel boundary and hides
 // the short, latency-bound user pass under the item pass.  32-bit keys on both sides (the common case).
-template <int VEC, int G, int K, bool FULL>
+template <int VEC, int G, int K, bool FULL, int OPT = OPT_SGD>
 __global__ __launch_bounds__(TRS_BLOCK) void sorted_updates_fused_kernel(const SortedArgs ia, const UserDupArgs ua,
                                                                         int n_user_blocks) {
   if ((int)blockIdx.x < n_user_blocks)
-    sorted_user_dup_update_body<uint32_t, VEC, G, K, FULL>(ua, blockIdx.x, n_user_blocks);
+    sorted_user_dup_update_body<uint32_t, VEC, G, K, FULL, OPT>(ua, blockIdx.x, n_user_blocks);
   else
-    sorted_item_update_staged_body<uint32_t, VEC, G, K, FULL>(ia, (int)blockIdx.x - n_user_blocks,
-                                                              (int)gridDim.x - n_user_blocks);
+    sorted_item_update_staged_body<uint32_t, VEC, G, K, FULL, OPT>(ia, (int)blockIdx.x - n_user_blocks,
+                                                                   (int)gridDim.x - n_user_blocks);
 }
 
 static int bits_for(int64_t n) {
@@ -680,7 +790,7 @@ int trs_item_bits_for(int64_t n_items) { return bits_for(n_items); }
 int trs_launch_sorted_updates_fused(const trs_tables* tables, const void* keys_step, const void* vals_step,
                                     int64_t batch, int64_t item_bits, const float* gz, float lr, const float* ustage,
                                     const void* ukeys_step, const void* uvals_step, int64_t q0, const float* du,
-                                    hipStream_t s) {
+                                    const OptArgs* opt, int parity, hipStream_t s) {
   SortedArgs ia = {};
   ia.T = *tables;
   ia.keys = keys_step;
@@ -700,6 +810,12 @@ int trs_launch_sorted_updates_fused(const trs_tables* tables, const void* keys_s
   ua.du = du;
   ua.gz = gz;
   ua.lr = lr;
+  const int kind = opt ? opt->kind : OPT_SGD;
+  if (opt) {
+    ia.o = *opt;
+    ua.o = *opt;
+  }
+  ia.parity = parity & 1;
   RowCfg c;
   if (!pick_row_cfg(tables->D, c)) {
     trs_set_error("unsupported n_factors D=%d", tables->D);
@@ -707,13 +823,23 @@ int trs_launch_sorted_updates_fused(const trs_tables* tables, const void* keys_s
   }
   const int nu = trs_grid((batch + TRS_WAVE - 1) / TRS_WAVE, TRS_BLOCK / TRS_WAVE);
   const int ni = trs_grid((2 * batch + RUN_CHUNK - 1) / RUN_CHUNK, 1);
-  const dim3 gr(nu + ni), bl(TRS_BLOCK);
+  const dim3 gr(nu + ni), bl(TRS_BLOCK), gc(64);
+  const trs_tables T = *tables;
+#define TRS_FUSED(V, GG, KK, FULL)                                                                                \
+  {                                                                                                              \
+    if (kind == OPT_ADAM) {                                                                                      \
+      hipLaunchKernelGGL((sorted_updates_fused_kernel<V, GG, KK, FULL, OPT_ADAM>), gr, bl, 0, s, ia, ua, nu);     \
+      hipLaunchKernelGGL((cut_rows_apply_kernel<V, GG, KK, FULL, OPT_ADAM>), gc, bl, 0, s, T, ia.o, ia.parity);   \
+    } else if (kind == OPT_ADAGRAD) {                                                                            \
+      hipLaunchKernelGGL((sorted_updates_fused_kernel<V, GG, KK, FULL, OPT_ADAGRAD>), gr, bl, 0, s, ia, ua, nu);  \
+      hipLaunchKernelGGL((cut_rows_apply_kernel<V, GG, KK, FULL, OPT_ADAGRAD>), gc, bl, 0, s, T, ia.o, ia.parity); \
+    } else {                                                                                                     \
+      hipLaunchKernelGGL((sorted_updates_fused_kernel<V, GG, KK, FULL>), gr, bl, 0, s, ia, ua, nu);               \
+    }                                                                                                            \
+  }
 #define TRS_CASE(V, GG, KK)                                                                                      \
   if (c.vec == V && c.g == GG && c.k == KK) {                                                                    \
-    if (V * GG * KK == tables->D)                                                                                \
-      hipLaunchKernelGGL((sorted_updates_fused_kernel<V, GG, KK, true>), gr, bl, 0, s, ia, ua, nu);              \
-    else                                                                                                         \
-      hipLaunchKernelGGL((sorted_updates_fused_kernel<V, GG, KK, false>), gr, bl, 0, s, ia, ua, nu);             \
+    if (V * GG * KK == tables->D) TRS_FUSED(V, GG, KK, true) else TRS_FUSED(V, GG, KK, false)                     \
     TRS_CHECK_LAUNCH("sorted_updates_fused_kernel");                                                             \
     return TRS_OK;                                                                                               \
   }
@@ -730,6 +856,7 @@ int trs_launch_sorted_updates_fused(const trs_tables* tables, const void* keys_s
   TRS_CASE(1, 64, 1)
   TRS_CASE(1, 64, 4)
 #undef TRS_CASE
+#undef TRS_FUSED
   trs_set_error("internal: no kernel for D=%d", tables->D);
   return TRS_E_ARG;
 }

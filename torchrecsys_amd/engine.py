@@ -110,10 +110,14 @@ class SparseScorerTrainer:
         self.kernel_events = None  # bench.py: {"kernel name": [(start_event, end_event), ...]} on the launch stream
         # specialised exact 3-kernel SGD step (csrc/fast_step.hip): no metadata, plain SGD with one learning rate
         self.fast_lr = None
-        if self.kind == "sgd" and self.M == 0:
-            lrs = {_group_of(optimizer, p)["lr"] for p in self.params}
-            if len(lrs) == 1:
-                self.fast_lr = lrs.pop()
+        self.fast_kind = None  # "sgd": C step loop on every path; "sparse_adam" / "adagrad": on the presorted path only
+        hyper = {"sgd": ("lr",), "sparse_adam": ("lr", "betas", "eps"),
+                 "adagrad": ("lr", "lr_decay", "eps", "initial_accumulator_value")}.get(self.kind)
+        if hyper is not None and self.M == 0:
+            lrs = {tuple(_group_of(optimizer, p).get(k) for k in hyper) for p in self.params}
+            if len(lrs) == 1:  # one rule for the four tables
+                self.fast_kind = self.kind
+                self.fast_lr = _group_of(optimizer, self.params[0])["lr"]
                 self.gz = torch.empty((2, batch_capacity), dtype=torch.float32, device=dev)
                 self.du = torch.empty((batch_capacity, self.D), dtype=torch.float32, device=dev)
                 self.id_bufs = [torch.empty(batch_capacity, dtype=torch.int32, device=dev) for _ in range(3)]
@@ -122,6 +126,10 @@ class SparseScorerTrainer:
         self.row_state = {}
         if self.kind in ("sparse_adam", "adagrad"):
             self.row_state = {id(p): RowState(p) for p in self.params}
+        if self.fast_kind in ("sparse_adam", "adagrad"):
+            # item runs cut at a chunk boundary: at most one per 64-reference chunk (+ slack)
+            self.cut_rows = torch.empty(2 * batch_capacity // 64 + 64, dtype=torch.int32, device=dev)
+            self.cut_count = torch.zeros(2, dtype=torch.int32, device=dev)
         # presorted epoch slices (csrc/presort.hip): two buffer sets, the one being built on the side stream and the one
         # the step kernels read
         self.ustage = None            # (capacity, D) pre-update user rows staged by K1 for the item update
@@ -261,15 +269,51 @@ class SparseScorerTrainer:
         ids, sk, sv, udup, usorted = ps.step_args(b_in_slice)
         if self.ustage is None:
             self.ustage = torch.empty_like(self.du)  # pre-update user rows staged by K1 for the item update
+        opt = self._adaptive_rule(n_steps) if self.fast_kind != "sgd" else None
         ops.train_steps_sgd(self.net.NET, self.net.tables(), None, None, 0, 0, 0, batch, n_steps, self.fast_lr, *ids,
                             self.gz, self.du, loss_sums, self.err, self.scratch, self._stamps(n_steps), evs, sk, sv,
-                            ps.key_bytes, udup, self.ustage, usorted)
+                            ps.key_bytes, udup, self.ustage, usorted, opt)
         if te is not None:
             # 32-bit keys: item and duplicated-user updates are ONE launch, and the last two events are recorded back to
             # back — that interval is the cost of an event record itself
             fused = ps.key_bytes == 4 and ps.ukey_bytes == 4
             self._collect_events(te, ns, ("fwd_stage_kernel", "sorted_updates_fused_kernel", "event_overhead") if fused
                                  else ("fwd_stage_kernel", "sorted_item_update_kernel", "sorted_user_dup_update_kernel"))
+
+    def _adaptive_rule(self, n_steps):
+        """_lib.TrsOpt of the next n_steps SparseAdam / Adagrad steps; moments live in optimizer.state[p] under torch's
+        own key names (created on first use like torch does) and the step counters are advanced here."""
+        from . import _lib
+        g = _group_of(self.opt, self.params[0])
+        sts = []
+        for p in self.params:
+            st = self.opt.state[p]
+            if self.kind == "sparse_adam" and "exp_avg" not in st:
+                st["step"] = torch.tensor(0.0) if type(self.opt) is torch.optim.Adam else 0
+                st["exp_avg"] = torch.zeros_like(p.data)
+                st["exp_avg_sq"] = torch.zeros_like(p.data)
+            if self.kind == "adagrad" and "sum" not in st:
+                st["step"] = torch.tensor(0.0)
+                st["sum"] = torch.full_like(p.data, g.get("initial_accumulator_value", 0.0))
+            sts.append(st)
+        step0 = int(sts[0]["step"])
+        assert all(int(st["step"]) == step0 for st in sts), "embedding tables were stepped a different number of times"
+        o = _lib.TrsOpt()
+        o.lr, o.step0 = float(g["lr"]), step0
+        if self.kind == "sparse_adam":
+            o.kind, (o.beta1, o.beta2), o.eps = 1, g["betas"], float(g["eps"])
+            s1, s2 = [st["exp_avg"] for st in sts], [st["exp_avg_sq"] for st in sts]
+        else:
+            o.kind, o.eps, o.lr_decay = 2, float(g["eps"]), float(g["lr_decay"])
+            s1, s2 = [st["sum"] for st in sts], [None] * 4
+        o.user_s1, o.item_s1, o.user_lin_s1, o.item_lin_s1 = (ops.ptr(t) for t in s1)
+        o.user_s2, o.item_s2, o.user_lin_s2, o.item_lin_s2 = (ops.ptr(t) for t in s2)
+        # the generic path's (all-zero between steps) gradient accumulators double as the meeting point of cut runs
+        o.gacc, o.gacc_lin = ops.ptr(self.row_state[id(self.params[1])].acc), ops.ptr(self.row_state[id(self.params[3])].acc)
+        o.cut_rows, o.cut_count, o.cut_capacity = ops.ptr(self.cut_rows), ops.ptr(self.cut_count), self.cut_rows.numel()
+        for st in sts:
+            st["step"] += n_steps
+        return o
 
     def fast_array_steps(self, ep, first, batch, n_steps, loss_sums):
         """n_steps fused steps over consecutive batches of host-prepared epoch id arrays `ep` (dict user/pos/neg int32,
@@ -287,7 +331,7 @@ class SparseScorerTrainer:
         the SUM of the batch's hinge terms (caller divides by B)."""
         B = ids["user"].shape[0]
         net = self.net
-        if self.fast_lr is not None and auc_slot is None and ids["user"].dtype == torch.int32:
+        if self.fast_kind == "sgd" and auc_slot is None and ids["user"].dtype == torch.int32:
             te, evs, ns = self._make_events(1) if self.kernel_events is not None else (None, None, 0)
             ops.train_steps_sgd(net.NET, net.tables(), None, None, 0, 0, 0, B, 1, self.fast_lr, ids["user"],
                                 ids["pos"], ids["neg"], self.gz, self.du, loss_slot, self.err, self.scratch,

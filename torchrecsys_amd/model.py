@@ -396,7 +396,9 @@ class FitRunner:
         """Run the next k steps of the current epoch (stops at the epoch's end).  Returns the number of steps run."""
         m, B = self.m, self.batch_size
         done = 0
-        fast = getattr(self.trainer, "fast_lr", None) is not None
+        kind = getattr(self.trainer, "fast_kind", None)
+        # the C step loop: SGD on every path, SparseAdam / Adagrad on the presorted path only
+        fast = kind == "sgd" or (kind is not None and self.trainer.wants_presort(B))
         if fast and m.rng == 'reference':
             fast = self.ep['user'].dtype == torch.int32
         if fast:  # whole batches, step loop in C (csrc/fast_step.hip): from the resident stream, or from the epoch's
