@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--steps", type=int, default=1024)
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--optimizer", default="sgd", choices=["sgd", "sparse_adam", "adagrad"],
+                    help="sgd = BASELINE.json's primary optimiser; sparse_adam (lazy Adam) / adagrad = secondary")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-kernel HIP event timing")
     args = ap.parse_args()
@@ -122,7 +124,15 @@ def main():
                                          use_amp=cfg["amp"], rng="device", seed=7 + rank, pre_sharded=True, **kw)
         # pre_sharded: every rank generated its own interaction shard
     del users, items
-    opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+    if args.optimizer == "sgd":
+        opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+    elif args.optimizer == "sparse_adam":
+        assert net != "mlp", "SparseAdam takes no dense parameters: use torch.optim.Adam for the MLP"
+        opt = torch.optim.SparseAdam(list(model.parameters()), lr=1e-3)
+    else:
+        opt = torch.optim.Adagrad(model.parameters(), lr=1e-2)
+    if args.optimizer != "sgd":
+        desc = desc.replace("SGD(lr=1e-2)", {"sparse_adam": "SparseAdam(lr=1e-3)", "adagrad": "Adagrad(lr=1e-2)"}[args.optimizer])
     runner = model.make_runner(opt, B)
     model.net.train()
 
@@ -175,6 +185,8 @@ def main():
     M = len(cfg["meta"])
     R = 3 + 2 * M
     step_bytes = 16 + 2 * R * (4 * D + 4)  # FM/Linear fused SGD step, rows read once + written once
+    state_rows = {"sgd": 0, "sparse_adam": 2, "adagrad": 1}[args.optimizer]  # state tables read + written per row
+    step_bytes += 2 * state_rows * R * (4 * D + 4)
     dtype = "bf16" if cfg["amp"] else "f32"
     out = {
         "metric": "training interactions/sec (pos+neg)", "value": value, "unit": "interactions/s",
@@ -223,10 +235,10 @@ def main():
         per_triple = {"score_kernel<fwd_bwd>": 16 + R * row + 8, "score_sgd_update_kernel": 12 + R * row,
                       # fast path (csrc/fast_step.hip): K1 reads the ids + R rows; on the presorted path it also writes
                       # the user row (users referenced once per batch are updated in place by K1)
-                      "fwd_stage_kernel": 16 + R * row + 8 + (row if inline_user else 0),
-                      # item updates: write the 2 item rows, need the user row
+                      "fwd_stage_kernel": 16 + R * row + 8 + ((1 + 2 * state_rows) * row if inline_user else 0),
+                      # item updates: write the 2 item rows (+ read and write their state rows), need the user row
                       "item_update_kernel": 12 + 3 * row, "sorted_item_update_kernel": 12 + 3 * row,
-                      "sorted_updates_fused_kernel": 12 + 3 * row,
+                      "sorted_updates_fused_kernel": 12 + 3 * row + 2 * 2 * state_rows * row,
                       "user_update_kernel": 4 + row, "sorted_user_dup_update_kernel": 4 + row}
         ach = per_triple[dom] * B / (mean_ms[dom] * 1e-3) / 1e9
         # measured HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
@@ -249,7 +261,8 @@ def main():
         cores = min(16, len(os.sched_getaffinity(0)))  # the one-GPU box share (oversubscribing collapses torch CPU ops)
         n_rows = min(n_inter, 4_000_000)
         res = cpu_fit.time_steps(net, n_users, n_items, D, B, n_rows=n_rows, steps=100, warmup=1, dynamic=dynamic,
-                                 threads=cores, max_seconds=20.0, meta_cats=cfg["meta"], hidden=cfg["hidden"])
+                                 threads=cores, max_seconds=20.0, meta_cats=cfg["meta"], hidden=cfg["hidden"],
+                                 optimizer=args.optimizer)
         out["cpu_baseline"] = {"value": res["interactions_per_s"], "unit": "interactions/s", "cores": res["threads"],
                                "kind": "port",
                                "sample": f"{res['steps']} steps of batch {B} ({res['seconds']:.1f} s) on full-size "

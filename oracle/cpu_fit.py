@@ -83,7 +83,7 @@ def _sample_loop(pos_list, n_items):
 
 
 def time_steps(net_type, n_users, n_items, D, batch_size, n_rows, steps, warmup=1, dynamic=True, lr=1e-2, threads=None,
-               seed=7, max_seconds=30.0, meta_cats=(), hidden=None):
+               seed=7, max_seconds=30.0, meta_cats=(), hidden=None, optimizer="sgd"):
     """Run `warmup` + up to `steps` training steps on a synthetic stream of `n_rows` interactions and return
     {"interactions_per_s", "steps", "seconds", "threads"}.  Stops early once `max_seconds` of timed work is reached."""
     if threads:
@@ -100,7 +100,8 @@ def time_steps(net_type, n_users, n_items, D, batch_size, n_rows, steps, warmup=
             torch.zeros((n_items, 0), dtype=torch.long)
     else:
         net = _Tables(net_type, n_users, n_items, D)
-    opt = torch.optim.SGD(net.parameters(), lr=lr)
+    opt = {"sgd": lambda ps: torch.optim.SGD(ps, lr=lr), "sparse_adam": lambda ps: torch.optim.SparseAdam(list(ps), lr=lr),
+           "adagrad": lambda ps: torch.optim.Adagrad(ps, lr=lr)}[optimizer](net.parameters())
     perm = torch.randperm(n_rows)
     done, t_total, i = 0, 0.0, 0
     for s in range(warmup + steps):
