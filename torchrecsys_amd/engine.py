@@ -153,6 +153,8 @@ class SparseScorerTrainer:
         if self.stamp + n >= 0xFFFFFFF0:
             self.scratch.zero_()
             self.stamp = 1
+            if self.fast_kind in ("sparse_adam", "adagrad"):
+                self.cut_count.zero_()  # the cut-run counters alternate by stamp parity
         first = self.stamp
         self.stamp += n
         return first
