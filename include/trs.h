@@ -299,12 +299,15 @@ int trs_gemm_bf16(int transA, int transB, int64_t M, int64_t N, int64_t K, float
  * operands k-contiguous (forward with W, dgrad with the transposed weight image); tn = 1: C(M,N) = alpha * A(K,M)^T
  * B(K,N) (wgrad dW = dy^T x: both operands "one row per sample"; fragments come out of the transposing LDS read
  * ds_read_b64_tr_b16).  M, N multiples of 128, K a multiple of 64, 16-byte aligned rows (lda, ldb in bf16 elements,
- * multiples of 8).  Replaces the reference's autocast `linear` (model.py:86-88,192-195; SURVEY 8a7: bf16 inputs, fp32
+ * multiples of 8).  Output: C_dev (fp32) or, when C_dev is NULL, C_bf16_dev (the value rounded to bf16: the forward
+ * outputs y_l and the input gradients dx_l of the bf16-resident path, like autocast's half-precision linear outputs;
+ * the fused BatchNorm statistics still come from the fp32 accumulators).  Replaces the reference's autocast `linear` (model.py:86-88,192-195; SURVEY 8a7: bf16 inputs, fp32
  * accumulate, no loss scaling). */
 int64_t trs_gemm_bf16in_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int trs_gemm_bf16in(int tn, int64_t M, int64_t N, int64_t K, float alpha, const void* A_dev, int64_t lda,
-                    const void* B_dev, int64_t ldb, float beta, float* C_dev, int64_t ldc, const float* bias_dev,
-                    float* bn_part_dev, void* workspace_dev, int64_t workspace_bytes, void* stream);
+                    const void* B_dev, int64_t ldb, float beta, float* C_dev, void* C_bf16_dev, int64_t ldc,
+                    const float* bias_dev, float* bn_part_dev, void* workspace_dev, int64_t workspace_bytes,
+                    void* stream);
 /* dst (rows, cols) bf16 copy and/or dst_t (cols, rows) transposed bf16 copy of an fp32 matrix (either may be NULL):
  * the per-step refresh of the weight images the bf16-resident GEMMs read. */
 int trs_f32_to_bf16(const float* src_dev, int64_t rows, int64_t cols, int64_t ld, void* dst_dev, void* dst_t_dev,
@@ -328,8 +331,9 @@ int trs_bn_stats_finalize(const float* part_dev, int64_t rows_per_pass, int32_t 
 /* out = relu(((y - mean) / sqrt(var + eps)) * gamma + beta)  (use_bn = 0: out = relu(y)); statistics indexed per
  * pass when stat_passes == passes, shared when stat_passes == 1 (eval mode: running statistics).  out_dev (fp32)
  * and/or out_bf16_dev (bf16 image for the bf16-resident GEMMs; needs H % 4 == 0), same row stride ldo in elements.
+ * y_bf16 != 0: y_dev is a bf16 image (written by trs_gemm_bf16in), else fp32.
  * (collaborative/mlp.py:108-112) */
-int trs_bn_relu_forward(const float* y_dev, int64_t rows_per_pass, int32_t passes, int32_t H, int64_t ld,
+int trs_bn_relu_forward(const void* y_dev, int32_t y_bf16, int64_t rows_per_pass, int32_t passes, int32_t H, int64_t ld,
                         int32_t use_bn, int32_t stat_passes, const float* mean_dev, const float* var_dev,
                         const float* gamma_dev, const float* beta_dev, float eps, float* out_dev, void* out_bf16_dev,
                         int64_t ldo, void* stream);
@@ -337,10 +341,12 @@ int trs_bn_relu_forward(const float* y_dev, int64_t rows_per_pass, int32_t passe
 /* Backward of relu(bn(y)) in train mode from dx = dL/d(out): dy (same shape), dgamma/dbeta (H) summed over both
  * passes.  use_bn = 0: dy = dx * [y > 0].  dy_colsum_dev (H, may be NULL): column sums of dy = the gradient of the
  * preceding Linear's bias, summed per pass first like trs_colsum.  dy_dev (fp32) and/or dy_bf16_dev (bf16 image for
- * the bf16-resident GEMMs; needs H % 4 == 0), row stride ldd elements.  workspace:
+ * the bf16-resident GEMMs; needs H % 4 == 0), row stride ldd elements.  y_bf16 / dx_bf16 != 0: that input is a bf16
+ * image (row strides ld / ldd in elements).  workspace:
  * trs_bn_backward_workspace_floats(...) floats. */
 int64_t trs_bn_backward_workspace_floats(int64_t rows_per_pass, int32_t H, int32_t passes);
-int trs_bn_relu_backward(const float* y_dev, const float* dx_dev, int64_t rows_per_pass, int32_t passes, int32_t H,
+int trs_bn_relu_backward(const void* y_dev, int32_t y_bf16, const void* dx_dev, int32_t dx_bf16, int64_t rows_per_pass,
+                         int32_t passes, int32_t H,
                          int64_t ld, int64_t ldd, int32_t use_bn, const float* mean_dev, const float* var_dev,
                          const float* gamma_dev, const float* beta_dev, float eps, float* dy_dev, void* dy_bf16_dev,
                          float* dgamma_dev, float* dbeta_dev, float* dy_colsum_dev, float* workspace_dev, void* stream);

@@ -109,17 +109,17 @@ PROTOTYPES = {
     "trs_gemm_bf16": (C.c_int, [C.c_int, C.c_int, _i64, _i64, _i64, _f, _vp, _i64, _vp, _i64, _f, _vp, _i64, _vp, _vp,
                                 _vp, _i64, _vp]),
     "trs_gemm_bf16in_workspace_bytes": (C.c_int64, [_i64, _i64, _i64]),
-    "trs_gemm_bf16in": (C.c_int, [_i32, _i64, _i64, _i64, _f, _vp, _i64, _vp, _i64, _f, _vp, _i64, _vp, _vp, _vp, _i64,
-                                  _vp]),
+    "trs_gemm_bf16in": (C.c_int, [_i32, _i64, _i64, _i64, _f, _vp, _i64, _vp, _i64, _f, _vp, _vp, _i64, _vp, _vp, _vp,
+                                  _i64, _vp]),
     "trs_f32_to_bf16": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "trs_bn_stats_finalize": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _f, _vp, _vp, _vp, _vp, _vp]),
     "trs_bn_workspace_floats": (C.c_int64, [_i64, _i32, _i32]),
     "trs_bn_batch_stats": (C.c_int, [_vp, _i64, _i32, _i64, _i32, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "trs_bn_relu_forward": (C.c_int, [_vp, _i64, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i64,
-                                      _vp]),
+    "trs_bn_relu_forward": (C.c_int, [_vp, _i32, _i64, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _f, _vp, _vp,
+                                      _i64, _vp]),
     "trs_bn_backward_workspace_floats": (C.c_int64, [_i64, _i32, _i32]),
-    "trs_bn_relu_backward": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _f, _vp, _vp,
-                                       _vp, _vp, _vp, _vp, _vp]),
+    "trs_bn_relu_backward": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _i32, _i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _f,
+                                       _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "trs_colsum_workspace_floats": (C.c_int64, [_i64, _i32, _i32]),
     "trs_colsum": (C.c_int, [_vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
     "trs_rowdot": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),

@@ -41,6 +41,7 @@ struct GemmArgs {
   // and the sum of squared deviations from that mean, laid out (row tile, 2, N) — the chunk partials that
   // trs_bn_stats_finalize combines (Chan).  NULL = off.  Requires splits == 1.
   float* bn_part;
+  unsigned short* C16;  // bf16 output instead of C (bf16-resident path, no split-K): row stride ldc elements
 };
 
 // Global -> registers for one 128 x 32 operand tile.  KC: source is k-contiguous.
@@ -143,7 +144,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
           v = g.alpha * v + bv;
           if (g.beta != 0.f) v += g.beta * out[row * ldo + col];
         }
-        out[row * ldo + col] = v;
+        if (!split && g.C16) g.C16[row * ldo + col] = __builtin_bit_cast(unsigned short, (__bf16)v);
+        else out[row * ldo + col] = v;
       }
     }
 }
@@ -426,6 +428,7 @@ struct Gemm16Args {
   float* slabs;
   int gx, gy, splits;
   float* bn_part;
+  unsigned short* C16;
 };
 
 // one 128 x 64 (NT) or 64 x 128 (TN) bf16 tile = 1024 16-byte chunks, 4 per thread
@@ -533,7 +536,7 @@ __global__ __launch_bounds__(256) void gemm_bf16in_kernel(const Gemm16Args g) {
   }
   GemmArgs e = {};
   e.C = g.C; e.bias = g.bias; e.M = g.M; e.N = g.N; e.K = g.K; e.ldc = g.ldc; e.alpha = g.alpha; e.beta = g.beta;
-  e.slabs = g.slabs; e.splits = g.splits; e.bn_part = g.bn_part;
+  e.slabs = g.slabs; e.splits = g.splits; e.bn_part = g.bn_part; e.C16 = g.C16;
   gemm_epilogue(e, acc, m0, n0, wm, wn, lr, lk, bz);
   if (g.bn_part) gemm_tile_bn_stats(e, acc, reinterpret_cast<float*>(&As[0][0]), m0, n0, wm, wn, lr, lk, by);
 }
@@ -617,6 +620,7 @@ static int gemm_impl(bool bf16, int transA, int transB, int64_t M, int64_t N, in
   g.k_per_split = ((kt + splits - 1) / splits) * BK;
   g.slabs = (float*)workspace_dev;
   g.bn_part = bn_part_dev;
+  g.C16 = nullptr;
   g.vecA = (((uintptr_t)A_dev & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
   g.vecB = (((uintptr_t)B_dev & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
   const int64_t gx = (N + BN - 1) / BN, gy = (M + BM - 1) / BM;
@@ -683,17 +687,18 @@ extern "C" int64_t trs_gemm_bf16in_workspace_bytes(int64_t M, int64_t N, int64_t
 }
 
 extern "C" int trs_gemm_bf16in(int tn, int64_t M, int64_t N, int64_t K, float alpha, const void* A_dev, int64_t lda,
-                               const void* B_dev, int64_t ldb, float beta, float* C_dev, int64_t ldc,
+                               const void* B_dev, int64_t ldb, float beta, float* C_dev, void* C_bf16_dev, int64_t ldc,
                                const float* bias_dev, float* bn_part_dev, void* workspace_dev,
                                int64_t workspace_bytes, void* stream) {
-  TRS_REQUIRE(A_dev && B_dev && C_dev, "trs_gemm_bf16in: NULL operand");
+  TRS_REQUIRE(A_dev && B_dev && (C_dev || C_bf16_dev), "trs_gemm_bf16in: NULL operand");
+  TRS_REQUIRE(!C_bf16_dev || (beta == 0.f && !C_dev), "trs_gemm_bf16in: the bf16 output replaces C and needs beta == 0");
   TRS_REQUIRE(M > 0 && N > 0 && K > 0 && M % BM == 0 && N % BN == 0 && K % BK2 == 0,
               "trs_gemm_bf16in: needs M, N multiples of 128 and K a multiple of 64 (got %lld x %lld x %lld)",
               (long long)M, (long long)N, (long long)K);
   TRS_REQUIRE(lda >= (tn ? M : K) && ldb >= (tn ? N : K) && ldc >= N, "trs_gemm_bf16in: leading dimension too small");
   TRS_REQUIRE((((uintptr_t)A_dev | (uintptr_t)B_dev) & 15) == 0 && lda % 8 == 0 && ldb % 8 == 0,
               "trs_gemm_bf16in: operands must be 16-byte aligned with leading dimensions that are multiples of 8");
-  int splits = bn_part_dev ? 1 : pick_splits(M, N, K);
+  int splits = (bn_part_dev || C_bf16_dev) ? 1 : pick_splits(M, N, K);
   const int64_t kt = K / BK2;
   if (splits > kt) splits = (int)kt;
   int64_t per = (kt + splits - 1) / splits;
@@ -707,6 +712,7 @@ extern "C" int trs_gemm_bf16in(int tn, int64_t M, int64_t N, int64_t K, float al
   g.k_per_split = per * BK2;
   g.slabs = (float*)workspace_dev;
   g.bn_part = bn_part_dev;
+  g.C16 = (unsigned short*)C_bf16_dev;
   const int64_t gx = N / BN, gy = M / BM;
   TRS_REQUIRE(gx * gy * splits < ((int64_t)1 << 31), "trs_gemm_bf16in: problem too large for the launch grid");
   g.gx = (int)gx; g.gy = (int)gy; g.splits = splits;

@@ -198,6 +198,7 @@ struct BnFwdArgs {
   int H, passes, stat_passes, use_bn;
   const float *mean, *var, *gamma, *beta;
   float eps;
+  const unsigned short* y16;  // bf16 image of y (bf16-resident path) when y is NULL
 };
 
 __global__ __launch_bounds__(TRS_BLOCK) void bn_relu_fwd_kernel(const BnFwdArgs a) {
@@ -254,6 +255,8 @@ struct BnBwdArgs {
   const float* sums;  // (passes, 2, H) final s1, s2 (apply kernel)
   float* cs_part;     // optional (passes, n_chunks, H): per-chunk column sums of dy (the layer's bias gradient)
   unsigned short* dy16;  // optional bf16 copy of dy (row stride ldd elements): what the bf16-resident GEMMs read
+  const unsigned short* y16;   // bf16 images of y / dx when the fp32 pointers are NULL (bf16-resident path)
+  const unsigned short* dx16;
 };
 
 __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
@@ -437,7 +440,18 @@ static V4Shape v4_shape(int H) {
 static bool v4_ok(const void* p, int H, int64_t ld) { return H % 4 == 0 && ld % 4 == 0 && ((uintptr_t)p & 15) == 0; }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// four consecutive elements at offset `off` of an fp32 image or (H16) of a bf16 image of the same shape
+template <bool H16>
+__device__ __forceinline__ float4 ld4t(const float* p32, const unsigned short* p16, int64_t off) {
+  if (H16) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p16 + off);
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                       __uint_as_float(v.y & 0xffff0000u));
+  }
+  return *reinterpret_cast<const float4*>(p32 + off);
+}
 
+template <bool Y16, bool DX16>
 __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_reduce_v4_kernel(const BnBwdArgs a, int tpr) {
   __shared__ float4 sh[2][TRS_BLOCK];
   const int tc = threadIdx.x % tpr, rl = threadIdx.x / tpr, nrl = TRS_BLOCK / tpr;
@@ -466,8 +480,8 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_reduce_v4_kernel(const BnBwd
     for (int u = 0; u < U; ++u) {
       const int64_t rr = r + (int64_t)u * nrl;
       const int64_t rc = rr < r1 ? rr : r1 - 1;
-      yv[u] = ld4(a.y + (base + rc) * a.ld + cc);
-      dv[u] = ld4(a.dx + (base + rc) * a.ldd + cc);
+      yv[u] = ld4t<Y16>(a.y, a.y16, (base + rc) * a.ld + cc);
+      dv[u] = ld4t<DX16>(a.dx, a.dx16, (base + rc) * a.ldd + cc);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -500,6 +514,7 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_reduce_v4_kernel(const BnBwd
 }
 
 // out = relu(bn(y)): thread = 4 fixed columns (scale/shift folded once), rows streamed four at a time.
+template <bool Y16>
 __global__ __launch_bounds__(TRS_BLOCK) void bn_relu_fwd_v4_kernel(const BnFwdArgs a, int tpr) {
   const int tc = threadIdx.x % tpr, rl = threadIdx.x / tpr, nrl = TRS_BLOCK / tpr;
   const int col = (blockIdx.x * tpr + tc) * 4;
@@ -523,7 +538,7 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_relu_fwd_v4_kernel(const BnFwdAr
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t rr = r + (int64_t)u * nrl;
-      yv[u] = ld4(a.y + (base + (rr < r1 ? rr : r1 - 1)) * a.ld + col);
+      yv[u] = ld4t<Y16>(a.y, a.y16, (base + (rr < r1 ? rr : r1 - 1)) * a.ld + col);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -543,6 +558,7 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_relu_fwd_v4_kernel(const BnFwdAr
 }
 
 // dy from (y, dx, final sums) with the same thread-owns-columns layout; optionally the per-chunk column sums of dy.
+template <bool Y16, bool DX16>
 __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_apply_v4_kernel(const BnBwdArgs a, int tpr) {
   __shared__ float4 sh[TRS_BLOCK];
   const int tc = threadIdx.x % tpr, rl = threadIdx.x / tpr, nrl = TRS_BLOCK / tpr;
@@ -572,8 +588,8 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_apply_v4_kernel(const BnBwdA
     for (int u = 0; u < U; ++u) {
       const int64_t rr = r + (int64_t)u * nrl;
       const int64_t rc = rr < r1 ? rr : r1 - 1;
-      yv[u] = ld4(a.y + (base + rc) * a.ld + cc);
-      dv[u] = ld4(a.dx + (base + rc) * a.ldd + cc);
+      yv[u] = ld4t<Y16>(a.y, a.y16, (base + rc) * a.ld + cc);
+      dv[u] = ld4t<DX16>(a.dx, a.dx16, (base + rc) * a.ldd + cc);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -732,24 +748,28 @@ extern "C" int trs_bn_stats_finalize(const float* part_dev, int64_t rows_per_pas
   return TRS_OK;
 }
 
-extern "C" int trs_bn_relu_forward(const float* y_dev, int64_t rows_per_pass, int32_t passes, int32_t H, int64_t ld,
-                                   int32_t use_bn, int32_t stat_passes, const float* mean_dev, const float* var_dev,
-                                   const float* gamma_dev, const float* beta_dev, float eps, float* out_dev,
-                                   void* out_bf16_dev, int64_t ldo, void* stream) {
+extern "C" int trs_bn_relu_forward(const void* y_dev, int32_t y_bf16, int64_t rows_per_pass, int32_t passes, int32_t H,
+                                   int64_t ld, int32_t use_bn, int32_t stat_passes, const float* mean_dev,
+                                   const float* var_dev, const float* gamma_dev, const float* beta_dev, float eps,
+                                   float* out_dev, void* out_bf16_dev, int64_t ldo, void* stream) {
   TRS_REQUIRE(y_dev && (out_dev || out_bf16_dev), "trs_bn_relu_forward: NULL argument");
   TRS_REQUIRE(rows_per_pass >= 0 && H > 0 && ld >= H && ldo >= H && passes >= 1, "trs_bn_relu_forward: bad shape");
   TRS_REQUIRE(!use_bn || (mean_dev && var_dev && gamma_dev && beta_dev), "trs_bn_relu_forward: BN tensors are NULL");
   TRS_REQUIRE(stat_passes == 1 || stat_passes == passes, "trs_bn_relu_forward: stat_passes must be 1 or passes");
   if (rows_per_pass == 0) return TRS_OK;
-  BnFwdArgs a = {y_dev, out_dev, (unsigned short*)out_bf16_dev, rows_per_pass, ld, ldo, H, passes, stat_passes, use_bn,
-                 mean_dev, var_dev, gamma_dev, beta_dev, eps};
-  const bool v4 = v4_ok(y_dev, H, ld) && (!out_dev || v4_ok(out_dev, H, ldo)) &&
+  BnFwdArgs a = {y_bf16 ? nullptr : (const float*)y_dev, out_dev, (unsigned short*)out_bf16_dev, rows_per_pass, ld,
+                 ldo, H, passes, stat_passes, use_bn, mean_dev, var_dev, gamma_dev, beta_dev, eps,
+                 y_bf16 ? (const unsigned short*)y_dev : nullptr};
+  const bool v4 = H % 4 == 0 && ld % 4 == 0 && ((uintptr_t)y_dev & (y_bf16 ? 7 : 15)) == 0 &&
+                  (!out_dev || v4_ok(out_dev, H, ldo)) &&
                   (!out_bf16_dev || (ldo % 4 == 0 && ((uintptr_t)out_bf16_dev & 7) == 0));
-  TRS_REQUIRE(v4 || (out_dev && !out_bf16_dev), "trs_bn_relu_forward: the bf16 output needs H %% 4 == 0 and aligned rows");
+  TRS_REQUIRE(v4 || (out_dev && !out_bf16_dev && !y_bf16),
+              "trs_bn_relu_forward: bf16 images need H %% 4 == 0 and aligned rows");
   if (v4) {
     const V4Shape v = v4_shape(H);
-    hipLaunchKernelGGL(bn_relu_fwd_v4_kernel, dim3(v.gx, n_chunks_of(rows_per_pass), passes), dim3(TRS_BLOCK), 0,
-                       (hipStream_t)stream, a, v.tpr);
+    const dim3 gr(v.gx, n_chunks_of(rows_per_pass), passes);
+    if (y_bf16) hipLaunchKernelGGL(bn_relu_fwd_v4_kernel<true>, gr, dim3(TRS_BLOCK), 0, (hipStream_t)stream, a, v.tpr);
+    else hipLaunchKernelGGL(bn_relu_fwd_v4_kernel<false>, gr, dim3(TRS_BLOCK), 0, (hipStream_t)stream, a, v.tpr);
   } else {
     const int64_t total = rows_per_pass * passes * ((H + 3) / 4);
     hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3(trs_grid(total, TRS_BLOCK)), dim3(TRS_BLOCK), 0, (hipStream_t)stream, a);
@@ -758,7 +778,8 @@ extern "C" int trs_bn_relu_forward(const float* y_dev, int64_t rows_per_pass, in
   return TRS_OK;
 }
 
-extern "C" int trs_bn_relu_backward(const float* y_dev, const float* dx_dev, int64_t rows_per_pass, int32_t passes,
+extern "C" int trs_bn_relu_backward(const void* y_dev, int32_t y_bf16, const void* dx_dev, int32_t dx_bf16,
+                                    int64_t rows_per_pass, int32_t passes,
                                     int32_t H, int64_t ld, int64_t ldd, int32_t use_bn, const float* mean_dev,
                                     const float* var_dev, const float* gamma_dev, const float* beta_dev, float eps,
                                     float* dy_dev, void* dy_bf16_dev, float* dgamma_dev, float* dbeta_dev,
@@ -772,12 +793,30 @@ extern "C" int trs_bn_relu_backward(const float* y_dev, const float* dx_dev, int
   hipStream_t s = (hipStream_t)stream;
   float* sums = workspace_dev + (int64_t)passes * nc * 2 * H;  // (passes,2,H) behind the partials
   float* cs_part = sums + (int64_t)passes * 2 * H;             // (passes,nc,H) column-sum partials of dy
-  BnBwdArgs a = {y_dev, dx_dev, dy_dev, rows_per_pass, ld, ldd, H, passes, use_bn, nc, mean_dev, var_dev, gamma_dev,
-                 beta_dev, eps, workspace_dev, sums, dy_colsum_dev ? cs_part : nullptr, (unsigned short*)dy_bf16_dev};
+  const bool h16 = y_bf16 || dx_bf16;
+  BnBwdArgs a = {y_bf16 ? nullptr : (const float*)y_dev, dx_bf16 ? nullptr : (const float*)dx_dev, dy_dev,
+                 rows_per_pass, ld, ldd, H, passes, use_bn, nc, mean_dev, var_dev, gamma_dev, beta_dev, eps,
+                 workspace_dev, sums, dy_colsum_dev ? cs_part : nullptr, (unsigned short*)dy_bf16_dev,
+                 y_bf16 ? (const unsigned short*)y_dev : nullptr, dx_bf16 ? (const unsigned short*)dx_dev : nullptr};
+  const bool v4in = H % 4 == 0 && ld % 4 == 0 && ldd % 4 == 0 && ((uintptr_t)y_dev & (y_bf16 ? 7 : 15)) == 0 &&
+                    ((uintptr_t)dx_dev & (dx_bf16 ? 7 : 15)) == 0 && v4_ok(workspace_dev, H, 4);
+  const bool v4a = v4in && (!dy_dev || v4_ok(dy_dev, H, ldd)) && (!dy_bf16_dev || ((uintptr_t)dy_bf16_dev & 7) == 0);
+  TRS_REQUIRE(v4a || (dy_dev && !dy_bf16_dev && !h16),
+              "trs_bn_relu_backward: bf16 images need H %% 4 == 0 and aligned rows");
+  const V4Shape v = v4_shape(H % 4 == 0 ? H : 4);
+  const dim3 g4(v.gx, nc, passes), bl(TRS_BLOCK);
+  // (y, dx) image types of the bf16-resident path: (bf16, bf16) inside the net, (bf16, fp32) at the last hidden layer
+  // (its dx comes from the fp32 H -> 1 output layer)
+#define TRS_BWD(KERNEL)                                                                     \
+  {                                                                                         \
+    if (y_bf16 && dx_bf16) hipLaunchKernelGGL((KERNEL<true, true>), g4, bl, 0, s, a, v.tpr); \
+    else if (y_bf16) hipLaunchKernelGGL((KERNEL<true, false>), g4, bl, 0, s, a, v.tpr);      \
+    else hipLaunchKernelGGL((KERNEL<false, false>), g4, bl, 0, s, a, v.tpr);                 \
+  }
+  TRS_REQUIRE(!dx_bf16 || y_bf16, "trs_bn_relu_backward: a bf16 dx comes with a bf16 y");
   if (use_bn) {
-    if (v4_ok(y_dev, H, ld) && v4_ok(dx_dev, H, ldd) && v4_ok(workspace_dev, H, 4)) {
-      const V4Shape v = v4_shape(H);
-      hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel, dim3(v.gx, nc, passes), dim3(TRS_BLOCK), 0, s, a, v.tpr);
+    if (v4in) {
+      TRS_BWD(bn_bwd_reduce_v4_kernel)
     } else {
       hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(gx, nc, passes), dim3(TRS_BLOCK), 0, s, a);
     }
@@ -786,12 +825,8 @@ extern "C" int trs_bn_relu_backward(const float* y_dev, const float* dx_dev, int
                        dgamma_dev, dbeta_dev);
     TRS_CHECK_LAUNCH("bn_bwd_final_kernel");
   }
-  const bool v4a = v4_ok(y_dev, H, ld) && v4_ok(dx_dev, H, ldd) && (!dy_dev || v4_ok(dy_dev, H, ldd)) &&
-                   v4_ok(workspace_dev, H, 4) && (!dy_bf16_dev || ((uintptr_t)dy_bf16_dev & 7) == 0);
-  TRS_REQUIRE(v4a || (dy_dev && !dy_bf16_dev), "trs_bn_relu_backward: the bf16 output needs H %% 4 == 0 and aligned rows");
   if (v4a) {
-    const V4Shape v = v4_shape(H);
-    hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3(v.gx, nc, passes), dim3(TRS_BLOCK), 0, s, a, v.tpr);
+    TRS_BWD(bn_bwd_apply_v4_kernel)
     TRS_CHECK_LAUNCH("bn_bwd_apply_kernel");
   } else {
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(trs_grid(rows_per_pass * passes * H, TRS_BLOCK)), dim3(TRS_BLOCK), 0,
@@ -803,6 +838,7 @@ extern "C" int trs_bn_relu_backward(const float* y_dev, const float* dx_dev, int
       TRS_CHECK_LAUNCH("colsum_partial_kernel");
     }
   }
+#undef TRS_BWD
   if (dy_colsum_dev) {
     hipLaunchKernelGGL(colsum_final_kernel, dim3((H + FIN_COLS - 1) / FIN_COLS), dim3(TRS_BLOCK), 0, s, cs_part, H, nc,
                        passes, dy_colsum_dev);

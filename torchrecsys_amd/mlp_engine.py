@@ -108,7 +108,10 @@ class MLPCompute:
                 n_tiles = (rows + ops.GEMM_TILE_ROWS - 1) // ops.GEMM_TILE_ROWS
                 part = torch.empty((n_tiles, 2, fc.out_features), dtype=torch.float32, device=dev)
             if res:
-                y = self._gemm16(False, x, self.w16[l], bias=fc.bias.data, bn_part=part)
+                # y_l rounded to bf16 when its statistics come from the fp32 accumulators of the same launch (or there
+                # is no BatchNorm): what autocast's half-precision linear output is
+                y = self._gemm16(False, x, self.w16[l], bias=fc.bias.data, bn_part=part,
+                                 out_bf16=fuse_stats or not use_bn)
             else:
                 y = self._gemm(False, True, x, fc.weight.data, bias=fc.bias.data, bf16=net.use_bf16, bn_part=part)
             ctx["y"].append(y)
@@ -136,7 +139,7 @@ class MLPCompute:
                 xn = torch.empty(y.shape, dtype=torch.bfloat16, device=dev)
                 ops.bn_relu_forward(y, B, passes, use_bn, stat_passes, mean, var, gamma, beta, BN_EPS, out16=xn)
             else:
-                xn = torch.empty_like(y)
+                xn = torch.empty(y.shape, dtype=torch.float32, device=dev)
                 ops.bn_relu_forward(y, B, passes, use_bn, stat_passes, mean, var, gamma, beta, BN_EPS, xn)
             x = xn
             ctx["x"].append(x)
@@ -184,7 +187,10 @@ class MLPCompute:
                                      dy_colsum=slot(fc.bias), dy16=dy16)  # db = column sums of dy, from the same kernel
             if res:
                 self._gemm16(True, dy16, ctx["x"][l], out=slot(fc.weight))   # dW = dy^T x (transposing LDS reads)
-                dx = self._gemm16(False, dy16, self.w16t[l])                 # dx = dy W through the W^T image
+                # dx = dy W through the W^T image: bf16 between layers (when the layer below keeps a bf16 y), fp32 for the
+                # embedding gradient d x0
+                dx = self._gemm16(False, dy16, self.w16t[l],
+                                  out_bf16=l > 0 and ctx["y"][l - 1].dtype == torch.bfloat16)
             else:
                 self._gemm(True, False, dy, ctx["x"][l], out=slot(fc.weight), bf16=net.use_bf16)  # dW = dy^T x (split-K)
                 dx = self._gemm(False, False, dy, fc.weight.data, bf16=net.use_bf16)      # dx = dy W

@@ -359,9 +359,10 @@ def gemm(transA, transB, A, B, out=None, bias=None, alpha=1.0, beta=0.0, bf16=Fa
     return out
 
 
-def gemm_bf16in(tn, A, B, out=None, bias=None, bn_part=None):
+def gemm_bf16in(tn, A, B, out=None, bias=None, bn_part=None, out_bf16=False):
     """bf16-resident GEMM: tn False: out(M,N) = A(M,K) B(N,K)^T; tn True: out(M,N) = A(K,M)^T B(K,N).  A, B bfloat16 GPU
-    tensors with a contiguous last dimension; fp32 accumulation and output."""
+    tensors with a contiguous last dimension; fp32 accumulation; fp32 output, or bfloat16 when out_bf16 (or `out` is a
+    bfloat16 tensor)."""
     lib = _lib.load()
     for t in (A, B):
         if t.dtype != torch.bfloat16 or t.stride(-1) != 1 or not t.is_cuda:
@@ -375,11 +376,13 @@ def gemm_bf16in(tn, A, B, out=None, bias=None, bn_part=None):
     if K != Kb:
         raise ValueError(f"gemm_bf16in: inner dimensions differ ({K} vs {Kb})")
     if out is None:
-        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
-    wsb = 0 if bn_part is not None else lib.trs_gemm_bf16in_workspace_bytes(M, N, K)
+        out = torch.empty((M, N), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=A.device)
+    o16 = out.dtype == torch.bfloat16
+    wsb = 0 if (bn_part is not None or o16) else lib.trs_gemm_bf16in_workspace_bytes(M, N, K)
     ws = _workspace(A.device, wsb) if wsb else None
-    check(lib.trs_gemm_bf16in(int(tn), M, N, K, 1.0, ptr(A), A.stride(0), ptr(B), B.stride(0), 0.0, ptr(out),
-                              out.stride(0), ptr(bias), ptr(bn_part), ptr(ws), wsb, _stream()), "trs_gemm_bf16in")
+    check(lib.trs_gemm_bf16in(int(tn), M, N, K, 1.0, ptr(A), A.stride(0), ptr(B), B.stride(0), 0.0,
+                              None if o16 else ptr(out), ptr(out) if o16 else None, out.stride(0), ptr(bias),
+                              ptr(bn_part), ptr(ws), wsb, _stream()), "trs_gemm_bf16in")
     return out
 
 
@@ -415,7 +418,8 @@ def bn_relu_forward(y, rows_per_pass, passes, use_bn, stat_passes, mean, var, ga
     """out: fp32 and/or out16: bfloat16 image of relu(bn(y)) (same row stride in elements)."""
     H = y.shape[1]
     ldo = (out if out is not None else out16).stride(0)
-    check(_lib.load().trs_bn_relu_forward(ptr(y), rows_per_pass, passes, H, y.stride(0), int(use_bn), stat_passes,
+    check(_lib.load().trs_bn_relu_forward(ptr(y), int(y.dtype == torch.bfloat16), rows_per_pass, passes, H, y.stride(0),
+                                          int(use_bn), stat_passes,
                                           ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps), ptr(out), ptr(out16),
                                           ldo, _stream()), "trs_bn_relu_forward")
 
@@ -425,7 +429,8 @@ def bn_relu_backward(y, dx, rows_per_pass, passes, use_bn, mean, var, gamma, bet
     lib = _lib.load()
     H = y.shape[1]
     ws = _workspace(y.device, 4 * lib.trs_bn_backward_workspace_floats(rows_per_pass, H, passes))
-    check(lib.trs_bn_relu_backward(ptr(y), ptr(dx), rows_per_pass, passes, H, y.stride(0), dx.stride(0), int(use_bn),
+    check(lib.trs_bn_relu_backward(ptr(y), int(y.dtype == torch.bfloat16), ptr(dx), int(dx.dtype == torch.bfloat16),
+                                   rows_per_pass, passes, H, y.stride(0), dx.stride(0), int(use_bn),
                                    ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps), ptr(dy), ptr(dy16),
                                    ptr(dgamma), ptr(dbeta), ptr(dy_colsum), ptr(ws), _stream()), "trs_bn_relu_backward")
 
