@@ -152,8 +152,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
 
 // Per-tile column statistics of the values the epilogue stores (alpha*acc + bias): each column of the 128-row tile is
 // spread over 2 waves (wm) x 2 lane halves x 32 accumulator registers; sums meet through a lane-half shuffle and LDS.
+// A 256-row workgroup tile (bf16-resident kernel, 8 waves) is two independent 128-row halves: half = wm >> 1 has its own
+// LDS cells and its own partial (the chunk size of the statistics stays 128 rows).
 __device__ __forceinline__ void gemm_tile_bn_stats(const GemmArgs& g, const f32x16 (&acc)[2][2], float* __restrict__ lds,
-                                                   int64_t m0, int64_t n0, int wm, int wn, int lr, int lk, int by) {
+                                                   int64_t m0, int64_t n0, int wm, int wn, int lr, int lk, int by,
+                                                   int halves = 1) {
+  const int half = wm >> 1, wmh = wm & 1;
+  m0 += half * BM;
+  by = by * halves + half;
+  lds += half * 256;  // 2 (wn) x 2 (j) x 32 (lr) x 2 (wmh) cells per half
+  wm = wmh;
   const int64_t rows_left = g.M - m0;
   const float n_rows = (float)(rows_left < BM ? rows_left : BM);
   float mean[2];
@@ -431,33 +439,43 @@ struct Gemm16Args {
   unsigned short* C16;
 };
 
-// one 128 x 64 (NT) or 64 x 128 (TN) bf16 tile = 1024 16-byte chunks, 4 per thread
-template <bool TN>
-__device__ __forceinline__ void tile16_load(i32x4 (&r)[4], const unsigned short* __restrict__ P, int64_t ld,
-                                            int64_t row0, int64_t k0, int tid) {
+// one ROWS x 64 (NT) or 64 x ROWS (TN) bf16 tile = ROWS * 8 16-byte chunks, NCH = ROWS * 8 / THREADS per thread;
+// TROW = LDS row stride of the TN image (ROWS + 32: 16 dwords mod 64 banks for ROWS = 128 and 256)
+template <bool TN, int ROWS, int THREADS>
+__device__ __forceinline__ void tile16_load(i32x4 (&r)[ROWS * 8 / THREADS], const unsigned short* __restrict__ P,
+                                            int64_t ld, int64_t row0, int64_t k0, int tid) {
+  constexpr int CPR = ROWS / 8;  // chunks per k-row of the TN form
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int c = tid + 256 * it;
-    const unsigned short* p = TN ? P + (k0 + (c >> 4)) * ld + row0 + ((c & 15) << 3)   // 16 chunks per k-row of 128
+  for (int it = 0; it < ROWS * 8 / THREADS; ++it) {
+    const int c = tid + THREADS * it;
+    const unsigned short* p = TN ? P + (k0 + c / CPR) * ld + row0 + ((c % CPR) << 3)
                                  : P + (row0 + (c >> 3)) * ld + k0 + ((c & 7) << 3);   // 8 chunks per row of 64 k
     r[it] = *reinterpret_cast<const i32x4*>(p);
   }
 }
-template <bool TN>
-__device__ __forceinline__ void tile16_store(const i32x4 (&r)[4], unsigned short* __restrict__ S, int tid) {
+template <bool TN, int ROWS, int THREADS>
+__device__ __forceinline__ void tile16_store(const i32x4 (&r)[ROWS * 8 / THREADS], unsigned short* __restrict__ S,
+                                             int tid) {
+  constexpr int CPR = ROWS / 8, TROW = ROWS + 32;
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int c = tid + 256 * it;
-    unsigned short* d = TN ? S + (c >> 4) * TN_ROW + ((c & 15) << 3) : S + (c >> 3) * NT_ROW + ((c & 7) << 3);
+  for (int it = 0; it < ROWS * 8 / THREADS; ++it) {
+    const int c = tid + THREADS * it;
+    unsigned short* d = TN ? S + (c / CPR) * TROW + ((c % CPR) << 3) : S + (c >> 3) * NT_ROW + ((c & 7) << 3);
     *reinterpret_cast<i32x4*>(d) = r[it];
   }
 }
 
-template <bool TN>
-__global__ __launch_bounds__(256) void gemm_bf16in_kernel(const Gemm16Args g) {
-  constexpr int IMG = TN ? BK2 * TN_ROW : BM * NT_ROW;  // bf16 elements per operand image
-  __shared__ __attribute__((aligned(16))) unsigned short As[2][IMG];
-  __shared__ __attribute__((aligned(16))) unsigned short Bs[2][IMG];
+// BMT = 128: 4 waves (2 x 2), two workgroups per CU.  BMT = 256: 8 waves (4 x 2), one workgroup per CU — the A tile is
+// shared by twice as many MFMAs, which matters because with 128 x 128 tiles the operand stream from L2 (~30 B/clk/CU),
+// not the matrix cores, bounds the kernel.
+template <bool TN, int BMT>
+__global__ __launch_bounds__(BMT * 2) void gemm_bf16in_kernel(const Gemm16Args g) {
+  constexpr int THREADS = BMT * 2;
+  constexpr int TROW_A = BMT + 32;  // TN image row strides (bf16): 16 dwords mod 64 banks
+  constexpr int IMG_A = TN ? BK2 * TROW_A : BMT * NT_ROW;
+  constexpr int IMG_B = TN ? BK2 * TN_ROW : BN * NT_ROW;
+  __shared__ __attribute__((aligned(16))) unsigned short As[2][IMG_A];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[2][IMG_B];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   int64_t lid = blockIdx.x;
@@ -466,7 +484,7 @@ __global__ __launch_bounds__(256) void gemm_bf16in_kernel(const Gemm16Args g) {
   const int bx = (int)(lid % g.gx);
   const int by = (int)((lid / g.gx) % g.gy);
   const int bz = (int)(lid / ((int64_t)g.gx * g.gy));
-  const int64_t m0 = (int64_t)by * BM, n0 = (int64_t)bx * BN;
+  const int64_t m0 = (int64_t)by * BMT, n0 = (int64_t)bx * BN;
   const int64_t kbeg = (int64_t)bz * g.k_per_split;
   const int64_t kend = (kbeg + g.k_per_split < g.K) ? kbeg + g.k_per_split : g.K;
   const int64_t nk = (kend - kbeg) / BK2;
@@ -483,32 +501,33 @@ __global__ __launch_bounds__(256) void gemm_bf16in_kernel(const Gemm16Args g) {
   // TN fragment addressing: 16-lane group gq = lane / 16 reads m-columns (gq & 1) * 16 .. +15 and k-rows
   // (gq >> 1) * 8 .. +7 in two blocks of 4 rows; lane 4q + p of the group supplies row q, columns 4p .. 4p+3
   const int gq = lane >> 4, li = lane & 15;
-  const int tr_off = (((gq >> 1) * 8 + (li >> 2)) * TN_ROW + (gq & 1) * 16 + ((li & 3) << 2));
+  const int tr_a = (((gq >> 1) * 8 + (li >> 2)) * TROW_A + (gq & 1) * 16 + ((li & 3) << 2));
+  const int tr_b = (((gq >> 1) * 8 + (li >> 2)) * TN_ROW + (gq & 1) * 16 + ((li & 3) << 2));
 
-  i32x4 ra[4], rb[4];
-  tile16_load<TN>(ra, g.A, g.lda, m0, kbeg, tid);
-  tile16_load<TN>(rb, g.B, g.ldb, n0, kbeg, tid);
-  tile16_store<TN>(ra, As[0], tid);
-  tile16_store<TN>(rb, Bs[0], tid);
+  i32x4 ra[BMT * 8 / THREADS], rb[BN * 8 / THREADS];
+  tile16_load<TN, BMT, THREADS>(ra, g.A, g.lda, m0, kbeg, tid);
+  tile16_load<TN, BN, THREADS>(rb, g.B, g.ldb, n0, kbeg, tid);
+  tile16_store<TN, BMT, THREADS>(ra, As[0], tid);
+  tile16_store<TN, BN, THREADS>(rb, Bs[0], tid);
   __syncthreads();
   for (int64_t kt = 0; kt < nk; ++kt) {
     const int cur = (int)(kt & 1);
     const int64_t kn = kbeg + (kt + 1 < nk ? kt + 1 : kt) * BK2;
-    tile16_load<TN>(ra, g.A, g.lda, m0, kn, tid);
-    tile16_load<TN>(rb, g.B, g.ldb, n0, kn, tid);
+    tile16_load<TN, BMT, THREADS>(ra, g.A, g.lda, m0, kn, tid);
+    tile16_load<TN, BN, THREADS>(rb, g.B, g.ldb, n0, kn, tid);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < BK2 / 16; ++ks) {
       bf16x8 a0, a1, b0, b1;
       if (TN) {
         using lds_v4 = __attribute__((address_space(3))) i16x4;
-        const unsigned short* ab = As[cur] + ks * 16 * TN_ROW + wm * 64 + tr_off;
-        const unsigned short* bb = Bs[cur] + ks * 16 * TN_ROW + wn * 64 + tr_off;
+        const unsigned short* ab = As[cur] + ks * 16 * TROW_A + wm * 64 + tr_a;
+        const unsigned short* bb = Bs[cur] + ks * 16 * TN_ROW + wn * 64 + tr_b;
         i16x4 t[8];
         t[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(ab));
-        t[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(ab + 4 * TN_ROW));
+        t[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(ab + 4 * TROW_A));
         t[2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(ab + 32));
-        t[3] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(ab + 32 + 4 * TN_ROW));
+        t[3] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(ab + 32 + 4 * TROW_A));
         t[4] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(bb));
         t[5] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(bb + 4 * TN_ROW));
         t[6] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(bb + 32));
@@ -530,15 +549,16 @@ __global__ __launch_bounds__(256) void gemm_bf16in_kernel(const Gemm16Args g) {
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
     }
-    tile16_store<TN>(ra, As[cur ^ 1], tid);
-    tile16_store<TN>(rb, Bs[cur ^ 1], tid);
+    tile16_store<TN, BMT, THREADS>(ra, As[cur ^ 1], tid);
+    tile16_store<TN, BN, THREADS>(rb, Bs[cur ^ 1], tid);
     __syncthreads();
   }
   GemmArgs e = {};
   e.C = g.C; e.bias = g.bias; e.M = g.M; e.N = g.N; e.K = g.K; e.ldc = g.ldc; e.alpha = g.alpha; e.beta = g.beta;
   e.slabs = g.slabs; e.splits = g.splits; e.bn_part = g.bn_part; e.C16 = g.C16;
   gemm_epilogue(e, acc, m0, n0, wm, wn, lr, lk, bz);
-  if (g.bn_part) gemm_tile_bn_stats(e, acc, reinterpret_cast<float*>(&As[0][0]), m0, n0, wm, wn, lr, lk, by);
+  if (g.bn_part)
+    gemm_tile_bn_stats(e, acc, reinterpret_cast<float*>(&As[0][0]), m0, n0, wm, wn, lr, lk, by, BMT / BM);
 }
 
 // fp32 (rows, cols) -> bf16 copy (same layout) and, optionally, the transposed bf16 copy (cols, rows): the per-step
@@ -713,13 +733,19 @@ extern "C" int trs_gemm_bf16in(int tn, int64_t M, int64_t N, int64_t K, float al
   g.slabs = (float*)workspace_dev;
   g.bn_part = bn_part_dev;
   g.C16 = (unsigned short*)C_bf16_dev;
-  const int64_t gx = N / BN, gy = M / BM;
+  // 256-row tiles when they still give every CU a workgroup (TRS_GEMM16_BM = 128 | 256 overrides: tuning knob)
+  static const int bm_env = getenv("TRS_GEMM16_BM") ? atoi(getenv("TRS_GEMM16_BM")) : 0;
+  const bool big = bm_env ? bm_env == 256 : (M % 256 == 0 && (M / 256) * (N / BN) * splits >= 256);
+  TRS_REQUIRE(!big || M % 256 == 0, "trs_gemm_bf16in: TRS_GEMM16_BM=256 needs M %% 256 == 0");
+  const int64_t gx = N / BN, gy = M / (big ? 256 : BM);
   TRS_REQUIRE(gx * gy * splits < ((int64_t)1 << 31), "trs_gemm_bf16in: problem too large for the launch grid");
   g.gx = (int)gx; g.gy = (int)gy; g.splits = splits;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)(gx * gy * splits));
-  if (tn) hipLaunchKernelGGL((gemm_bf16in_kernel<true>), grid, dim3(256), 0, s, g);
-  else hipLaunchKernelGGL((gemm_bf16in_kernel<false>), grid, dim3(256), 0, s, g);
+  if (tn && big) hipLaunchKernelGGL((gemm_bf16in_kernel<true, 256>), grid, dim3(512), 0, s, g);
+  else if (tn) hipLaunchKernelGGL((gemm_bf16in_kernel<true, 128>), grid, dim3(256), 0, s, g);
+  else if (big) hipLaunchKernelGGL((gemm_bf16in_kernel<false, 256>), grid, dim3(512), 0, s, g);
+  else hipLaunchKernelGGL((gemm_bf16in_kernel<false, 128>), grid, dim3(256), 0, s, g);
   TRS_CHECK_LAUNCH("gemm_bf16in_kernel");
   if (splits > 1) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(trs_grid(M * N, 256)), dim3(256), 0, s, g.slabs, splits, M, N,
