@@ -320,6 +320,31 @@ def test_gemm_split_k_wgrad_shape_and_strided_views():
     assert rel_err(out_f.cpu().numpy(), dy.astype(np.float64).T @ x.astype(np.float64)) < 3e-6
 
 
+@pytest.mark.parametrize("tile", ["128", "256", "512"])
+@pytest.mark.parametrize("B,K,H", [(256, 128, 256), (512, 256, 512)])
+def test_gemm_bf16_resident_tiles_and_fused_bn_statistics(tile, B, K, H, monkeypatch):
+    """The three workgroup tiles of the bf16-resident kernel (128x128, 256x128, 256x256; forced through
+    TRS_GEMM16_TILE) give the same product, bf16 output and per-128-row BatchNorm partials."""
+    ops = _ops()
+    monkeypatch.setenv("TRS_GEMM16_TILE", tile)
+    rs = np.random.RandomState(B + K)
+    rows = 2 * B
+    x = torch.from_numpy(rs.normal(0, 1, (rows, K)).astype(np.float32)).to(DEV).to(torch.bfloat16)
+    w = torch.from_numpy(rs.normal(0, 1, (H, K)).astype(np.float32)).to(DEV).to(torch.bfloat16)
+    bias = torch.from_numpy(rs.normal(0, 1, H).astype(np.float32)).to(DEV)
+    ref = x.double().cpu().numpy() @ w.double().cpu().numpy().T + bias.cpu().numpy()[None, :]
+    part = torch.empty((rows // 128, 2, H), dtype=torch.float32, device=DEV)
+    y = ops.gemm_bf16in(False, x, w, bias=bias, bn_part=part)
+    assert rel_err(y.cpu().numpy(), ref) < 2e-6
+    r3 = ref.reshape(rows // 128, 128, H)
+    assert rel_err(part[:, 0].cpu().numpy(), r3.mean(axis=1)) < 1e-5
+    assert rel_err(part[:, 1].cpu().numpy(), ((r3 - r3.mean(axis=1, keepdims=True)) ** 2).sum(axis=1)) < 1e-5
+    y16 = ops.gemm_bf16in(False, x, w, bias=bias, out_bf16=True)
+    assert torch.equal(y16, y.to(torch.bfloat16))
+    out_t = ops.gemm_bf16in(True, x, x)  # (K,K) = x^T x, both operands one row per k
+    assert rel_err(out_t.cpu().numpy(), x.double().cpu().numpy().T @ x.double().cpu().numpy()) < 2e-6
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (384, 256, 448), (128, 384, 64 * 37)])
 def test_gemm_bf16_resident_nt_and_tn(M, N, K):
     """bf16 operands in HBM, fp32 accumulate: exact products of the bf16 values, so the fp64 product of the SAME rounded

@@ -156,11 +156,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
 // LDS cells and its own partial (the chunk size of the statistics stays 128 rows).
 __device__ __forceinline__ void gemm_tile_bn_stats(const GemmArgs& g, const f32x16 (&acc)[2][2], float* __restrict__ lds,
                                                    int64_t m0, int64_t n0, int wm, int wn, int lr, int lk, int by,
-                                                   int halves = 1) {
+                                                   int halves = 1, int wn_count = 2) {
   const int half = wm >> 1, wmh = wm & 1;
   m0 += half * BM;
   by = by * halves + half;
-  lds += half * 256;  // 2 (wn) x 2 (j) x 32 (lr) x 2 (wmh) cells per half
+  lds += half * wn_count * 128;  // wn_count (wn) x 2 (j) x 32 (lr) x 2 (wmh) cells per half
   wm = wmh;
   const int64_t rows_left = g.M - m0;
   const float n_rows = (float)(rows_left < BM ? rows_left : BM);
@@ -419,8 +419,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
 //               banks): the four rows of a block cover the 64 banks exactly once.
 // Interior tiles only (M, N % 128 == 0, K % 64 == 0 per split, 16-B aligned rows): checked on the host.
 constexpr int BK2 = 64;
-constexpr int NT_ROW = 72;    // bf16 per LDS row of an [m][k] image (64 + 8 pad)
-constexpr int TN_ROW = 160;   // bf16 per LDS row of a [k][m] image (128 + 32 pad)
+constexpr int NT_ROW = 72;    // bf16 per LDS row of an [m][k] image (64 + 8 pad); [k][m] images: rows of (tile width + 32)
 using i16x4 = __attribute__((ext_vector_type(4))) short;
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 
@@ -468,23 +467,24 @@ __device__ __forceinline__ void tile16_store(const i32x4 (&r)[ROWS * 8 / THREADS
 // BMT = 128: 4 waves (2 x 2), two workgroups per CU.  BMT = 256: 8 waves (4 x 2), one workgroup per CU — the A tile is
 // shared by twice as many MFMAs, which matters because with 128 x 128 tiles the operand stream from L2 (~30 B/clk/CU),
 // not the matrix cores, bounds the kernel.
-template <bool TN, int BMT>
-__global__ __launch_bounds__(BMT * 2) void gemm_bf16in_kernel(const Gemm16Args g) {
-  constexpr int THREADS = BMT * 2;
-  constexpr int TROW_A = BMT + 32;  // TN image row strides (bf16): 16 dwords mod 64 banks
+template <bool TN, int BMT, int BNT = BN>
+__global__ __launch_bounds__(BMT * BNT / 64) void gemm_bf16in_kernel(const Gemm16Args g) {
+  constexpr int THREADS = BMT * BNT / 64;  // one wave per 64 x 64 block of the tile
+  constexpr int WN = BNT / 64;
+  constexpr int TROW_A = BMT + 32, TROW_B = BNT + 32;  // TN image row strides (bf16): 16 dwords mod 64 banks
   constexpr int IMG_A = TN ? BK2 * TROW_A : BMT * NT_ROW;
-  constexpr int IMG_B = TN ? BK2 * TN_ROW : BN * NT_ROW;
+  constexpr int IMG_B = TN ? BK2 * TROW_B : BNT * NT_ROW;
   __shared__ __attribute__((aligned(16))) unsigned short As[2][IMG_A];
   __shared__ __attribute__((aligned(16))) unsigned short Bs[2][IMG_B];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   int64_t lid = blockIdx.x;
   const int64_t nwg = gridDim.x;
   if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);  // XCD-aware tile order (see gemm_f32_kernel)
   const int bx = (int)(lid % g.gx);
   const int by = (int)((lid / g.gx) % g.gy);
   const int bz = (int)(lid / ((int64_t)g.gx * g.gy));
-  const int64_t m0 = (int64_t)by * BMT, n0 = (int64_t)bx * BN;
+  const int64_t m0 = (int64_t)by * BMT, n0 = (int64_t)bx * BNT;
   const int64_t kbeg = (int64_t)bz * g.k_per_split;
   const int64_t kend = (kbeg + g.k_per_split < g.K) ? kbeg + g.k_per_split : g.K;
   const int64_t nk = (kend - kbeg) / BK2;
@@ -502,19 +502,19 @@ __global__ __launch_bounds__(BMT * 2) void gemm_bf16in_kernel(const Gemm16Args g
   // (gq >> 1) * 8 .. +7 in two blocks of 4 rows; lane 4q + p of the group supplies row q, columns 4p .. 4p+3
   const int gq = lane >> 4, li = lane & 15;
   const int tr_a = (((gq >> 1) * 8 + (li >> 2)) * TROW_A + (gq & 1) * 16 + ((li & 3) << 2));
-  const int tr_b = (((gq >> 1) * 8 + (li >> 2)) * TN_ROW + (gq & 1) * 16 + ((li & 3) << 2));
+  const int tr_b = (((gq >> 1) * 8 + (li >> 2)) * TROW_B + (gq & 1) * 16 + ((li & 3) << 2));
 
-  i32x4 ra[BMT * 8 / THREADS], rb[BN * 8 / THREADS];
+  i32x4 ra[BMT * 8 / THREADS], rb[BNT * 8 / THREADS];
   tile16_load<TN, BMT, THREADS>(ra, g.A, g.lda, m0, kbeg, tid);
-  tile16_load<TN, BN, THREADS>(rb, g.B, g.ldb, n0, kbeg, tid);
+  tile16_load<TN, BNT, THREADS>(rb, g.B, g.ldb, n0, kbeg, tid);
   tile16_store<TN, BMT, THREADS>(ra, As[0], tid);
-  tile16_store<TN, BN, THREADS>(rb, Bs[0], tid);
+  tile16_store<TN, BNT, THREADS>(rb, Bs[0], tid);
   __syncthreads();
   for (int64_t kt = 0; kt < nk; ++kt) {
     const int cur = (int)(kt & 1);
     const int64_t kn = kbeg + (kt + 1 < nk ? kt + 1 : kt) * BK2;
     tile16_load<TN, BMT, THREADS>(ra, g.A, g.lda, m0, kn, tid);
-    tile16_load<TN, BN, THREADS>(rb, g.B, g.ldb, n0, kn, tid);
+    tile16_load<TN, BNT, THREADS>(rb, g.B, g.ldb, n0, kn, tid);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < BK2 / 16; ++ks) {
@@ -522,16 +522,16 @@ __global__ __launch_bounds__(BMT * 2) void gemm_bf16in_kernel(const Gemm16Args g
       if (TN) {
         using lds_v4 = __attribute__((address_space(3))) i16x4;
         const unsigned short* ab = As[cur] + ks * 16 * TROW_A + wm * 64 + tr_a;
-        const unsigned short* bb = Bs[cur] + ks * 16 * TN_ROW + wn * 64 + tr_b;
+        const unsigned short* bb = Bs[cur] + ks * 16 * TROW_B + wn * 64 + tr_b;
         i16x4 t[8];
         t[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(ab));
         t[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(ab + 4 * TROW_A));
         t[2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(ab + 32));
         t[3] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(ab + 32 + 4 * TROW_A));
         t[4] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(bb));
-        t[5] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(bb + 4 * TN_ROW));
+        t[5] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(bb + 4 * TROW_B));
         t[6] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(bb + 32));
-        t[7] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(bb + 32 + 4 * TN_ROW));
+        t[7] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(bb + 32 + 4 * TROW_B));
         a0 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(t[0], t[1], 0, 1, 2, 3, 4, 5, 6, 7));
         a1 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(t[2], t[3], 0, 1, 2, 3, 4, 5, 6, 7));
         b0 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(t[4], t[5], 0, 1, 2, 3, 4, 5, 6, 7));
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(BMT * 2) void gemm_bf16in_kernel(const Gemm16Args g
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
     }
     tile16_store<TN, BMT, THREADS>(ra, As[cur ^ 1], tid);
-    tile16_store<TN, BN, THREADS>(rb, Bs[cur ^ 1], tid);
+    tile16_store<TN, BNT, THREADS>(rb, Bs[cur ^ 1], tid);
     __syncthreads();
   }
   GemmArgs e = {};
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(BMT * 2) void gemm_bf16in_kernel(const Gemm16Args g
   e.slabs = g.slabs; e.splits = g.splits; e.bn_part = g.bn_part; e.C16 = g.C16;
   gemm_epilogue(e, acc, m0, n0, wm, wn, lr, lk, bz);
   if (g.bn_part)
-    gemm_tile_bn_stats(e, acc, reinterpret_cast<float*>(&As[0][0]), m0, n0, wm, wn, lr, lk, by, BMT / BM);
+    gemm_tile_bn_stats(e, acc, reinterpret_cast<float*>(&As[0][0]), m0, n0, wm, wn, lr, lk, by, BMT / BM, WN);
 }
 
 // fp32 (rows, cols) -> bf16 copy (same layout) and, optionally, the transposed bf16 copy (cols, rows): the per-step
@@ -734,15 +734,22 @@ extern "C" int trs_gemm_bf16in(int tn, int64_t M, int64_t N, int64_t K, float al
   g.bn_part = bn_part_dev;
   g.C16 = (unsigned short*)C_bf16_dev;
   // 256-row tiles when they still give every CU a workgroup (TRS_GEMM16_BM = 128 | 256 overrides: tuning knob)
-  static const int bm_env = getenv("TRS_GEMM16_BM") ? atoi(getenv("TRS_GEMM16_BM")) : 0;
-  const bool big = bm_env ? bm_env == 256 : (M % 256 == 0 && (M / 256) * (N / BN) * splits >= 256);
-  TRS_REQUIRE(!big || M % 256 == 0, "trs_gemm_bf16in: TRS_GEMM16_BM=256 needs M %% 256 == 0");
-  const int64_t gx = N / BN, gy = M / (big ? 256 : BM);
+  // Tile selection (TRS_GEMM16_TILE = 128 | 256 | 512 forces 128x128 | 256x128 | 256x256 where the shape allows: tests,
+  // tuning).  The kernel is bound by the vector L1's miss path (TCP_PENDING_STALL ~ 50 % of the cycles at 128x128), so
+  // the tile that moves the fewest operand bytes per MAC wins as long as every CU still gets a workgroup.
+  const char* tile_env = getenv("TRS_GEMM16_TILE");
+  const int tile = tile_env ? atoi(tile_env) : 0;
+  const bool can_big = M % 256 == 0, can_wide = can_big && N % 256 == 0;
+  const bool wide = tile ? (tile == 512 && can_wide) : (can_wide && (M / 256) * (N / 256) * splits >= 256);
+  const bool big = wide || (tile ? (tile == 256 && can_big) : (can_big && (M / 256) * (N / BN) * splits >= 256));
+  const int64_t gx = N / (wide ? 256 : BN), gy = M / (big ? 256 : BM);
   TRS_REQUIRE(gx * gy * splits < ((int64_t)1 << 31), "trs_gemm_bf16in: problem too large for the launch grid");
   g.gx = (int)gx; g.gy = (int)gy; g.splits = splits;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)(gx * gy * splits));
-  if (tn && big) hipLaunchKernelGGL((gemm_bf16in_kernel<true, 256>), grid, dim3(512), 0, s, g);
+  if (wide && tn) hipLaunchKernelGGL((gemm_bf16in_kernel<true, 256, 256>), grid, dim3(1024), 0, s, g);
+  else if (wide) hipLaunchKernelGGL((gemm_bf16in_kernel<false, 256, 256>), grid, dim3(1024), 0, s, g);
+  else if (tn && big) hipLaunchKernelGGL((gemm_bf16in_kernel<true, 256>), grid, dim3(512), 0, s, g);
   else if (tn) hipLaunchKernelGGL((gemm_bf16in_kernel<true, 128>), grid, dim3(256), 0, s, g);
   else if (big) hipLaunchKernelGGL((gemm_bf16in_kernel<false, 256>), grid, dim3(512), 0, s, g);
   else hipLaunchKernelGGL((gemm_bf16in_kernel<false, 128>), grid, dim3(256), 0, s, g);
