@@ -102,3 +102,38 @@ def test_presorted_step_random_shapes(case):
     assert err.item() == 0
     if kind != "sgd":
         assert float(gacc.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("n,batch,slice_batches,net_type", [(1000, 256, 2, "fm"), (1000, 999, 4, "linear"),
+                                                            (777, 64, 3, "fm"), (300, 512, 8, "fm"),
+                                                            (5000, 100, 7, "linear"), (2049, 1024, 1, "fm"),
+                                                            (130, 1, 16, "fm")])
+def test_fit_presorted_path_equals_ownership_path_random_sizes(n, batch, slice_batches, net_type, monkeypatch):
+    """fit() over odd stream lengths / batch sizes / slice lengths (partial last batch, batch larger than the stream,
+    batch of one, one-batch slices): the presorted two-launch path and the four-launch ownership path train the same
+    model on the same reference-RNG batches."""
+    import contextlib
+    import io
+    import pandas as pd
+    from torchrecsys_amd.engine import SparseScorerTrainer
+    from torchrecsys_amd.model import TorchRecSys
+    rs = np.random.RandomState(n + batch)
+    n_u, n_i = 50, 23
+    df = pd.DataFrame({"user": np.concatenate([np.arange(n_u), rs.randint(0, n_u, n - n_u)]),
+                       "item": np.concatenate([np.arange(n_i), rs.randint(0, n_i, n - n_i)])})
+    out = {}
+    monkeypatch.setattr(SparseScorerTrainer, "SLICE_BATCHES", slice_batches)
+    for path in ("presorted", "ownership"):
+        if path == "ownership":
+            monkeypatch.setattr(SparseScorerTrainer, "wants_presort", lambda self, b: False)
+        torch.manual_seed(3)
+        np.random.seed(3)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            model = TorchRecSys(dataset=df, user_id_col="user", item_id_col="item", n_factors=8, net_type=net_type,
+                                dynamic_neg_sampling=True)
+            model.fit(optimizer=torch.optim.SGD(model.parameters(), lr=0.1), epochs=3, batch_size=batch)
+        out[path] = ({k: v.cpu().numpy() for k, v in model.state_dict().items()}, buf.getvalue())
+    assert out["presorted"][1] == out["ownership"][1]  # printed epoch losses (4 decimals)
+    for k, v in out["ownership"][0].items():
+        assert rel_err(out["presorted"][0][k], v) < 1e-5, k
