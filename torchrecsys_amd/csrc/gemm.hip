@@ -252,20 +252,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
       __builtin_amdgcn_sched_barrier(0);  // keep the loads above the MFMA block (the scheduler sinks them to their use)
       const float* as = As[cur] + wm * 64 + lr;
       const float* bs = Bs[cur] + wn * 64 + lr;
-      // fragments one k-step ahead: the LDS reads of step k2+1 are in flight while the four MFMAs of step k2 run
-      float a0 = as[lk * LDA_S], a1 = as[lk * LDA_S + 32];
-      float b0 = bs[lk * LDB_S], b1 = bs[lk * LDB_S + 32];
 #pragma unroll
       for (int k2 = 0; k2 < BK / 2; ++k2) {
-        const int kn = 2 * (k2 + 1 < BK / 2 ? k2 + 1 : k2) + lk;
-        const float na0 = as[kn * LDA_S], na1 = as[kn * LDA_S + 32];
-        const float nb0 = bs[kn * LDB_S], nb1 = bs[kn * LDB_S + 32];
-        __builtin_amdgcn_sched_barrier(0);  // keep the reads above this step's MFMAs (the scheduler sinks them back)
+        const int k = 2 * k2 + lk;
+        const float a0 = as[k * LDA_S], a1 = as[k * LDA_S + 32];
+        const float b0 = bs[k * LDB_S], b1 = bs[k * LDB_S + 32];
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
       }
       tile_store<AKC>(ra, As[cur ^ 1], tid);
       tile_store<BKC>(rb, Bs[cur ^ 1], tid);
