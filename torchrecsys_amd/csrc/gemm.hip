@@ -123,6 +123,7 @@ __device__ __forceinline__ void tile_store(const float4 (&r)[4], float* __restri
 
 // epilogue shared by the fp32 and bf16 kernels: C/D map of the 32x32 MFMA (dtype-independent on gfx950):
 // col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+template <bool OUT16 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&acc)[2][2], int64_t m0, int64_t n0,
                                               int wm, int wn, int lr, int lk, int bz) {
   const bool split = g.splits > 1;
@@ -144,7 +145,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
           v = g.alpha * v + bv;
           if (g.beta != 0.f) v += g.beta * out[row * ldo + col];
         }
-        if (!split && g.C16) g.C16[row * ldo + col] = __builtin_bit_cast(unsigned short, (__bf16)v);
+        if (OUT16) g.C16[row * ldo + col] = __builtin_bit_cast(unsigned short, (__bf16)v);  // never with split-K
         else out[row * ldo + col] = v;
       }
     }
@@ -556,7 +557,8 @@ __global__ __launch_bounds__(BMT * BNT / 64) void gemm_bf16in_kernel(const Gemm1
   GemmArgs e = {};
   e.C = g.C; e.bias = g.bias; e.M = g.M; e.N = g.N; e.K = g.K; e.ldc = g.ldc; e.alpha = g.alpha; e.beta = g.beta;
   e.slabs = g.slabs; e.splits = g.splits; e.bn_part = g.bn_part; e.C16 = g.C16;
-  gemm_epilogue(e, acc, m0, n0, wm, wn, lr, lk, bz);
+  if (g.C16) gemm_epilogue<true>(e, acc, m0, n0, wm, wn, lr, lk, bz);
+  else gemm_epilogue<false>(e, acc, m0, n0, wm, wn, lr, lk, bz);
   if (g.bn_part)
     gemm_tile_bn_stats(e, acc, reinterpret_cast<float*>(&As[0][0]), m0, n0, wm, wn, lr, lk, by, BMT / BM, WN);
 }
