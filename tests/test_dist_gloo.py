@@ -66,8 +66,9 @@ def _worker(rank, world, port, ret):
         data = {"user_id": torch.arange(10), "pos_item_id": torch.arange(10)}
         m = TorchRecSys.__new__(TorchRecSys)
         m._dev_cache = {}
-        s10, e10 = tdist.shard_bounds(10, rank, world)
+        s10, e10 = tdist.equal_shard_bounds(10, rank, world)
         assert torch.equal(m._rank_rows(data)["user_id"], torch.arange(10)[s10:e10])
+        assert tdist.equal_shard_bounds(11, rank, world) == (rank * 5, rank * 5 + 5)  # same length on every rank
         m.pre_sharded = True
         assert m._rank_rows(data) is data
         ret[rank] = "ok"

@@ -28,6 +28,13 @@ def shard_bounds(n, rank, world):
     return start, start + base + (1 if rank < rem else 0)
 
 
+def equal_shard_bounds(n, rank, world):
+    """[start, end) of equally long shards (n // world rows each; the n % world last rows are left out): every rank
+    then runs the same number of steps, which the per-step collectives of the MLP path require."""
+    per = n // world
+    return rank * per, rank * per + per
+
+
 def shard_stream(user_ids, item_ids, rank=None, world=None, by_user=False):
     """This rank's rows of the interaction stream.  by_user=True partitions by user_id % world (every user row is then
     owned by exactly one rank — the largest table never drifts between replicas)."""

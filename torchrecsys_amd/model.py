@@ -198,14 +198,16 @@ class TorchRecSys(torch.nn.Module):
         return {k: v.to(dt).contiguous().to(dev, non_blocking=True) for k, v in ep.items()}
 
     def _rank_rows(self, data):
-        """This rank's contiguous shard of a split under data parallelism (the whole split in a single process)."""
+        """This rank's contiguous shard of a split under data parallelism (the whole split in a single process).  Shards
+        are equally long (at most world-1 rows of the split are left out), so every rank runs the same number of steps:
+        a rank with one batch more would wait forever in the MLP's per-step gradient all-reduce."""
         rank, world = tdist.world_info()
         if world == 1 or getattr(self, "pre_sharded", False):
             return data
         key = id(data)
         if self._dev_cache.get('shard_key') != key:
             n = data['user_id'].shape[0]
-            s, e = tdist.shard_bounds(n, rank, world)
+            s, e = tdist.equal_shard_bounds(n, rank, world)
             self._dev_cache['shard_key'] = key
             self._dev_cache['shard'] = {k: v[s:e] for k, v in data.items()}
         return self._dev_cache['shard']
