@@ -175,6 +175,18 @@ typedef struct trs_opt {
   int32_t* cut_count;  /* [2] zero-initialised once; the steps alternate between the two counters */
   int32_t cut_capacity; /* >= 2*batch/64 + the number of rows with more than 64 references (2*batch is always enough) */
 } trs_opt;
+/* Metadata scorers (tables->M > 0) on the presorted step, plain SGD: K1 is the generic scorer in a staging mode that
+ * looks the metadata ids up in item_meta_tab, applies the user update in place, stages the rows the sorted item update
+ * multiplies (FM: the per-pass field sums, Linear: the user row) and the metadata fields' gradients; user and item rows
+ * then go through the sorted runs as without metadata, the (small, heavily shared) metadata tables through an atomic
+ * scatter of the staged fields. */
+typedef struct trs_meta_stage {
+  const int32_t* item_meta_tab; /* (n_items, M) metadata ids of every item */
+  float* xstage;                /* FM: (2, batch, D); Linear: (batch, D) */
+  float* grad_rows;             /* (3 + 2M, batch, D): fields 3.. are written */
+  float* grad_lin;              /* (3 + 2M, batch) */
+  int32_t* meta_ids;            /* (2, batch, M) */
+} trs_meta_stage;
 int64_t trs_train_scratch_bytes(int64_t n_users, int64_t n_items, int64_t batch, int32_t D);
 int trs_train_steps_sgd(int net, const trs_tables* tables, const int32_t* stream_ui_dev,
                         const int32_t* neg_static_dev, int64_t N,
@@ -184,7 +196,8 @@ int trs_train_steps_sgd(int net, const trs_tables* tables, const int32_t* stream
                         void* scratch_dev, uint32_t first_stamp, const void* sorted_keys_dev,
                         const void* sorted_vals_dev, int32_t key_bytes, const uint8_t* user_dup_flags_dev,
                         float* ustage_buf_dev, const void* sorted_ukeys_dev, const void* sorted_uvals_dev,
-                        int32_t ukey_bytes, int64_t slice_pos0, const trs_opt* opt, void** events, void* stream);
+                        int32_t ukey_bytes, int64_t slice_pos0, const trs_opt* opt, const trs_meta_stage* meta,
+                        void** events, void* stream);
 
 /* Epoch-level grouping of the item references by row.  trs_epoch_presort covers n_batches whole batches starting at
  * epoch position first_pos: it writes the triples' ids (generated from the resident stream exactly as

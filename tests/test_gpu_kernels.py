@@ -702,6 +702,59 @@ def test_presorted_adaptive_rules_match_the_oracle(net, D, skew, kind):
     assert err.item() == 0
 
 
+@pytest.mark.parametrize("net,D,M,skew", [("fm", 64, 1, False), ("fm", 16, 3, True), ("linear", 32, 1, True),
+                                          ("linear", 8, 2, False), ("fm", 10, 1, True)])
+def test_presorted_step_with_metadata_matches_oracle(net, D, M, skew):
+    """Metadata scorers on the presorted step (SGD): K1 = the scorer's staging mode (ids from the item -> metadata
+    table, user update in place, FM: per-pass field sums staged), user / item rows through the sorted runs (FM: w +=
+    sum(c*S) - sum(c)*w), metadata tables through the atomic scatter of the staged fields: 3 batches == oracle steps."""
+    from torchrecsys_amd import _lib
+    ops = _ops()
+    rs = np.random.RandomState(D + M + skew)
+    NU, NI, B, nb, lr = 300, 57, 512, 3, 0.05
+    p, _, _ = make_case(net, D, M, 8, NU=NU, NI=NI, seed=2)
+    sizes = [p[f"metadata.{m}.weight"].shape[0] for m in range(M)]
+    item_meta = np.stack([rs.randint(0, sizes[m], NI) for m in range(M)], axis=1).astype(np.int32)
+    u, i, j = rs.randint(0, NU, nb * B), rs.randint(0, NI, nb * B), rs.randint(0, NI, nb * B)
+    if skew:
+        i[rs.rand(nb * B) < 0.4] = 7
+        j[rs.rand(nb * B) < 0.4] = 7
+    lin = ("user_bias.weight", "item_bias.weight") if net == "linear" else ("linear_user.weight", "linear_item.weight")
+    t = {k: torch.from_numpy(v.copy()).to(DEV) for k, v in p.items()}
+    metas = [t[f"metadata.{m}.weight"] for m in range(M)]
+    meta_lins = [t[f"linear_metadata.{m}.weight"] for m in range(M)] if net == "fm" else []
+    T, keep = ops.make_tables(t["user.weight"], t["item.weight"], t[lin[0]], t[lin[1]], metas, meta_lins)
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ps = ops.EpochPresort(nb, B, NU, NI, DEV)
+    ps.run(None, None, 0, 0, 0, err, given_ids=[torch.from_numpy(a.astype(np.int32)).to(DEV) for a in (u, i, j)])
+    ids, sk, sv, udup, usorted = ps.step_args(0)
+    R = 3 + 2 * M
+    gz, du = torch.empty((2, B), device=DEV), torch.empty((B, D), device=DEV)
+    xstage = torch.empty((2 if net == "fm" else 1, B, D), device=DEV)
+    grad_rows, grad_lin = torch.empty((R, B, D), device=DEV), torch.zeros((R, B), device=DEV)
+    meta_ids = torch.empty((2, B, M), dtype=torch.int32, device=DEV)
+    tab = torch.from_numpy(item_meta).to(DEV)
+    ms = _lib.TrsMetaStage()
+    ms.item_meta_tab, ms.xstage, ms.meta_ids = ops.ptr(tab), ops.ptr(xstage), ops.ptr(meta_ids)
+    ms.grad_rows, ms.grad_lin = ops.ptr(grad_rows), ops.ptr(grad_lin)
+    losses = torch.zeros(nb, device=DEV)
+    ops.train_steps_sgd(net, T, None, None, 0, 0, 0, B, nb, lr, *ids, gz, du, losses, err,
+                        ops.train_scratch(NU, NI, B, D, DEV), 1, None, sk, sv, ps.key_bytes, udup,
+                        torch.empty((B, D), device=DEV), usorted, None, ms)
+    torch.cuda.synchronize()
+    ref = {k: v.copy() for k, v in p.items()}
+    for b in range(nb):
+        sl = slice(b * B, (b + 1) * B)
+        batch = {"user_id": u[sl], "pos_item_id": i[sl], "neg_item_id": j[sl],
+                 "pos_metadata_id": item_meta[i[sl]].astype(np.int64), "neg_metadata_id": item_meta[j[sl]].astype(np.int64)}
+        _, _, loss, grads = onets.train_forward_backward(net, ref, batch)
+        ooptim.sgd_step(ref, grads, lr)
+        assert abs(losses[b].item() / B - float(loss)) <= TOL * max(abs(float(loss)), 1e-3)
+    for k, v in ref.items():
+        assert rel_err(t[k].cpu().numpy(), v) < TOL, k
+    assert err.item() == 0
+
+
 def test_presort_generates_the_same_batches_as_batch_prepare():
     ops = _ops()
     rs = np.random.RandomState(1)

@@ -137,3 +137,37 @@ def test_fit_presorted_path_equals_ownership_path_random_sizes(n, batch, slice_b
     assert out["presorted"][1] == out["ownership"][1]  # printed epoch losses (4 decimals)
     for k, v in out["ownership"][0].items():
         assert rel_err(out["presorted"][0][k], v) < 1e-5, k
+
+
+@pytest.mark.parametrize("net_type,n_meta_cols", [("fm", 1), ("linear", 2), ("fm", 3)])
+def test_fit_with_metadata_presorted_path_equals_generic_path(net_type, n_meta_cols, monkeypatch):
+    """fit() of a metadata scorer (DataFrame front-end, reference RNG): the presorted step with the scorer's staging mode
+    trains the same model as the generic staged path (TRS_META_FAST=0) on the same batches."""
+    import contextlib
+    import io
+    import pandas as pd
+    from torchrecsys_amd.model import TorchRecSys
+    rs = np.random.RandomState(11)
+    n, n_u, n_i = 3000, 80, 37
+    items = np.concatenate([np.arange(n_i), rs.randint(0, n_i, n - n_i)])
+    df = pd.DataFrame({"user": np.concatenate([np.arange(n_u), rs.randint(0, n_u, n - n_u)]), "item": items})
+    cols = []
+    for c in range(n_meta_cols):
+        cat_of_item = rs.randint(0, 5 + c, n_i)
+        cat_of_item[:5 + c] = np.arange(5 + c)
+        df[f"cat{c}"] = cat_of_item[items]
+        cols.append(f"cat{c}")
+    out = {}
+    for path in ("presorted", "generic"):
+        monkeypatch.setenv("TRS_META_FAST", "1" if path == "presorted" else "0")
+        torch.manual_seed(3)
+        np.random.seed(3)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            model = TorchRecSys(dataset=df, user_id_col="user", item_id_col="item", metadata_id_col=cols, n_factors=16,
+                                net_type=net_type, dynamic_neg_sampling=True)
+            model.fit(optimizer=torch.optim.SGD(model.parameters(), lr=0.1), epochs=3, batch_size=128)
+        out[path] = ({k: v.cpu().numpy() for k, v in model.state_dict().items()}, buf.getvalue())
+    assert out["presorted"][1] == out["generic"][1]
+    for k, v in out["generic"][0].items():
+        assert rel_err(out["presorted"][0][k], v) < 1e-5, k

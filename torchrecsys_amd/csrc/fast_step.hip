@@ -768,7 +768,10 @@ int trs_item_bits_for(int64_t n_items);
 int trs_launch_sorted_updates_fused(const trs_tables* tables, const void* keys_step, const void* vals_step,
                                     int64_t batch, int64_t item_bits, const float* gz, float lr, const float* ustage,
                                     const void* ukeys_step, const void* uvals_step, int64_t q0, const float* du,
-                                    const OptArgs* opt, int parity, hipStream_t s);
+                                    const OptArgs* opt, int parity, int64_t xpass, int fmsub, hipStream_t s);
+// rows.hip
+int trs_launch_sgd_fields(int net, const trs_tables* tables, const trs_batch* batch, const float* grad_rows_dev,
+                          const float* grad_lin_dev, float lr, int f_begin, void* stream);
 int trs_launch_sorted_user_dup_update(const trs_tables* tables, const void* ukeys_step, const void* uvals_step,
                                       int key_bytes, int64_t batch, int64_t q0, const float* du, const float* gz,
                                       float lr, hipStream_t s);
@@ -787,9 +790,11 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
                                    const void* sorted_keys_dev, const void* sorted_vals_dev, int32_t key_bytes,
                                    const uint8_t* user_dup_flags_dev, float* ustage_buf_dev,
                                    const void* sorted_ukeys_dev, const void* sorted_uvals_dev, int32_t ukey_bytes,
-                                   int64_t slice_pos0, const trs_opt* opt, void** events, void* stream) {
+                                   int64_t slice_pos0, const trs_opt* opt, const trs_meta_stage* meta, void** events,
+                                   void* stream) {
   TRS_REQUIRE(net == TRS_NET_LINEAR || net == TRS_NET_FM, "trs_train_steps_sgd: bad net");
-  TRS_REQUIRE(tables && tables->M == 0, "trs_train_steps_sgd: only scorers without metadata (M == 0)");
+  TRS_REQUIRE(tables && tables->M >= 0 && tables->M <= TRS_MAX_META, "trs_train_steps_sgd: bad M");
+  TRS_REQUIRE((tables->M > 0) == (meta != nullptr), "trs_train_steps_sgd: metadata tables need the metadata staging");
   TRS_REQUIRE(tables->user && tables->item && tables->user_lin && tables->item_lin, "trs_train_steps_sgd: NULL table");
   TRS_REQUIRE(batch > 0 && batch < ((int64_t)1 << 30) && n_steps >= 0, "trs_train_steps_sgd: bad batch / n_steps");
   TRS_REQUIRE(user_buf_dev && pos_buf_dev && neg_buf_dev && gz_buf_dev && du_buf_dev && loss_sums_dev,
@@ -806,6 +811,15 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
                 "trs_train_steps_sgd: user-duplicate flags need the staging buffer and the slice's sorted (batch,user) pairs");
   }
   const bool adaptive = opt && opt->kind != TRS_OPT_SGD;
+  if (meta) {
+    TRS_REQUIRE(sorted_keys_dev && user_dup_flags_dev && key_bytes == 4 && ukey_bytes == 4 && !adaptive,
+                "trs_train_steps_sgd: metadata scorers run on the presorted step with plain SGD only");
+    TRS_REQUIRE(meta->item_meta_tab && meta->xstage && meta->grad_rows && meta->grad_lin && meta->meta_ids,
+                "trs_train_steps_sgd: metadata staging buffer is NULL");
+    for (int m = 0; m < tables->M; ++m)
+      TRS_REQUIRE(tables->meta[m] && (net != TRS_NET_FM || tables->meta_lin[m]),
+                  "trs_train_steps_sgd: metadata table %d is NULL", m);
+  }
   if (adaptive) {
     TRS_REQUIRE(opt->kind == TRS_OPT_SPARSE_ADAM || opt->kind == TRS_OPT_ADAGRAD, "trs_train_steps_sgd: bad opt->kind");
     TRS_REQUIRE(inl && key_bytes == 4 && ukey_bytes == 4,
@@ -881,7 +895,26 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
     hipEvent_t* ev = events ? (hipEvent_t*)events + 4 * (int64_t)st : nullptr;  // K1 | K2a+K2b | K3 boundaries
     if (ev && !ev[0]) ev = nullptr;  // a step whose four handles are NULL is not timed (sampled timing)
     if (ev) (void)hipEventRecord(ev[0], s);
-    int rc = net == TRS_NET_FM ? launch_fwd_stage<TRS_NET_FM>(a, s) : launch_fwd_stage<TRS_NET_LINEAR>(a, s);
+    int rc;
+    if (meta) {  // K1 = the generic scorer in its staging mode (score_kernels.h MODE 2)
+      ScoreArgs sa = {};
+      sa.T = *tables;
+      sa.Bt.user = a.user; sa.Bt.pos = a.pos; sa.Bt.neg = a.neg;
+      sa.Bt.B = batch; sa.Bt.idx_bytes = 4; sa.Bt.err_flag_dev = err_flag_dev;
+      sa.inv_B = a.inv_B;
+      sa.loss_sum = a.loss_sum;
+      sa.grad_rows = meta->grad_rows;
+      sa.grad_lin = meta->grad_lin;
+      sa.iota_user = -1;
+      sa.item_meta_tab = meta->item_meta_tab;
+      sa.gz = a.gz; sa.du = a.du; sa.xstage = meta->xstage;
+      sa.udup_pos = a.udup_pos;
+      sa.lr = a.lr;
+      sa.meta_ids_out = meta->meta_ids;
+      rc = net == TRS_NET_FM ? launch_score<TRS_NET_FM, 2>(sa, s) : launch_score<TRS_NET_LINEAR, 2>(sa, s);
+    } else {
+      rc = net == TRS_NET_FM ? launch_fwd_stage<TRS_NET_FM>(a, s) : launch_fwd_stage<TRS_NET_LINEAR>(a, s);
+    }
     if (rc) return rc;
     if (ev) (void)hipEventRecord(ev[1], s);
     if (sorted) {  // K2: per-run owner update from the presorted references, then K3
@@ -890,10 +923,21 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
       if (inl && key_bytes == 4 && ukey_bytes == 4) {  // item + duplicated-user updates in one launch
         const char* uk = (const char*)sorted_ukeys_dev + (int64_t)st * batch * 4;
         const char* uv = (const char*)sorted_uvals_dev + (int64_t)st * batch * 4;
-        rc = trs_launch_sorted_updates_fused(tables, ks, vs, batch, item_bits, a.gz, a.lr, a.ustage, uk, uv,
+        const bool fm_meta = meta && net == TRS_NET_FM;
+        rc = trs_launch_sorted_updates_fused(tables, ks, vs, batch, item_bits, a.gz, a.lr,
+                                             meta ? meta->xstage : a.ustage, uk, uv,
                                              slice_pos0 + (int64_t)st * batch, a.du, adaptive ? &a.o : nullptr,
-                                             (int)(a.stamp & 1u), s);
+                                             (int)(a.stamp & 1u), fm_meta ? batch : 0, fm_meta ? 1 : 0, s);
         if (rc) return rc;
+        if (meta) {  // the metadata fields staged by K1: atomic scatter into their (small) tables
+          trs_batch mb = {};
+          mb.user = a.user; mb.pos = a.pos; mb.neg = a.neg;
+          mb.pos_meta = meta->meta_ids;
+          mb.neg_meta = meta->meta_ids + batch * tables->M;
+          mb.B = batch; mb.idx_bytes = 4; mb.err_flag_dev = err_flag_dev;
+          rc = trs_launch_sgd_fields(net, tables, &mb, meta->grad_rows, meta->grad_lin, a.lr, 3, s);
+          if (rc) return rc;
+        }
         if (ev) {
           (void)hipEventRecord(ev[2], s);
           (void)hipEventRecord(ev[3], s);

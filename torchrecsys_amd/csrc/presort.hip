@@ -116,6 +116,11 @@ struct SortedArgs {
   const float* ustage;  // (B,D) pre-update user rows staged by K1 (indexed by t), or NULL: read the user table
   OptArgs o;            // staged form: update rule (OPT_SGD: lr above); adaptive rules coalesce whole runs first
   int parity;           // step parity: which cut-run counter this step appends to
+  // metadata scorers (staged form, SGD): the staged rows are X(t, which) = ustage[which * xpass + t]; FM with metadata
+  // stages the per-pass field sums S (xpass = B) and the run applies w += sum(c*S) - sum(c)*w (gradient g*(S - w) of
+  // every reference, w = the pre-update row); Linear / FM without metadata stage the user row (xpass = 0, fmsub = 0)
+  int64_t xpass;
+  int fmsub;
 };
 
 constexpr int RUN_CHUNK = 64;  // runs are cut at multiples of this many references
@@ -231,6 +236,7 @@ __device__ __forceinline__ void sorted_item_update_staged_body(const SortedArgs&
     const KeyT knext = keys[base + RUN_CHUNK < n ? base + RUN_CHUNK : n - 1];  // first key of the next chunk
     const RefPayload me = a.vals[il];
     const int t = (int)(me.tw >> 1);
+    const int xrow = t + (int)(me.tw & 1u) * (int)a.xpass;  // row of the staged image this reference multiplies
     // SGD is linear in the gradient: the learning rate is folded into the coefficient.  The adaptive rules need the
     // coalesced gradient itself: c = gz.
     const float gzv = a.gz[(int64_t)(me.tw & 1u) * a.B + t];
@@ -279,7 +285,7 @@ __device__ __forceinline__ void sorted_item_update_staged_body(const SortedArgs&
 #pragma unroll
         for (int j = 0; j < SI_MEMB; ++j) {
           const int src = l[s] + j < 64 ? l[s] + j : 63;
-          const int tj = __shfl(t, src, 64);
+          const int tj = __shfl(xrow, src, 64);
           const float cj = __shfl(c, src, 64);
           cm[s][j] = (has[s] && j < len[s]) ? cj : 0.f;
           row_load<VEC, G, K, FULL>(u[s][j], a.ustage, (int64_t)tj, D, lig);
@@ -307,7 +313,7 @@ __device__ __forceinline__ void sorted_item_update_staged_body(const SortedArgs&
           const float gj = a.gz[(int64_t)(pl.tw & 1u) * a.B + tj];
           const float cj = OPT == OPT_SGD ? -a.lr * gj : gj;
           RowReg<VEC, K> uj;
-          row_load<VEC, G, K, FULL>(uj, a.ustage, (int64_t)tj, D, lig);
+          row_load<VEC, G, K, FULL>(uj, a.ustage, (int64_t)tj + (int64_t)(pl.tw & 1u) * a.xpass, D, lig);
 #pragma unroll
           for (int q = 0; q < N; ++q) acc.v[q] += cj * uj.v[q];
           lin += cj;
@@ -316,8 +322,9 @@ __device__ __forceinline__ void sorted_item_update_staged_body(const SortedArgs&
         float* irow = T.item + row[s] * (int64_t)D;
         if (hd[s] != 0 && !cut_tail) {
           if (OPT == OPT_SGD) {
+            const float sub = a.fmsub ? lin : 0.f;  // FM with metadata: -sum(c) * w, the "- v" of g*(S - v)
 #pragma unroll
-            for (int q = 0; q < N; ++q) w[s].v[q] += acc.v[q];
+            for (int q = 0; q < N; ++q) w[s].v[q] += a.fmsub ? acc.v[q] - sub * w[s].v[q] : acc.v[q];
             row_store<VEC, G, K>(w[s], irow, D, lig);
             if (lig == 0) T.item_lin[row[s]] = wl[s] + lin;
           } else {  // the run is the row's whole gradient: apply the rule once, state rows beside the weights
@@ -351,12 +358,15 @@ __device__ __forceinline__ void sorted_item_update_staged_body(const SortedArgs&
             }
           }
         } else {  // a cut piece of a long segment (hot row): several groups add into the row
+          // (fmsub: the piece subtracts sum(c)*w with the w it loaded; another piece may already have added into the
+          // row, which changes this term only in second order of the step size)
 #pragma unroll
           for (int kk = 0; kk < K; ++kk) {
             const int e = (kk * G + lig) * VEC;
 #pragma unroll
             for (int q = 0; q < VEC; ++q)
-              if (e + q < D) atomicAdd(irow + e + q, acc.v[kk * VEC + q]);
+              if (e + q < D)
+                atomicAdd(irow + e + q, a.fmsub ? acc.v[kk * VEC + q] - lin * w[s].v[kk * VEC + q] : acc.v[kk * VEC + q]);
           }
           if (lig == 0) atomicAdd(T.item_lin + row[s], lin);
         }
@@ -790,7 +800,7 @@ int trs_item_bits_for(int64_t n_items) { return bits_for(n_items); }
 int trs_launch_sorted_updates_fused(const trs_tables* tables, const void* keys_step, const void* vals_step,
                                     int64_t batch, int64_t item_bits, const float* gz, float lr, const float* ustage,
                                     const void* ukeys_step, const void* uvals_step, int64_t q0, const float* du,
-                                    const OptArgs* opt, int parity, hipStream_t s) {
+                                    const OptArgs* opt, int parity, int64_t xpass, int fmsub, hipStream_t s) {
   SortedArgs ia = {};
   ia.T = *tables;
   ia.keys = keys_step;
@@ -816,6 +826,8 @@ int trs_launch_sorted_updates_fused(const trs_tables* tables, const void* keys_s
     ua.o = *opt;
   }
   ia.parity = parity & 1;
+  ia.xpass = xpass;
+  ia.fmsub = fmsub;
   RowCfg c;
   if (!pick_row_cfg(tables->D, c)) {
     trs_set_error("unsupported n_factors D=%d", tables->D);

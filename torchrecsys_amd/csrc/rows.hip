@@ -63,6 +63,7 @@ struct SgdArgs {
   const float* grad_lin;   // (R,B)
   float lr;
   int has_lin_meta;  // FM: metadata fields own 1-wide tables too
+  int f_begin;       // first field to apply (0: all; 3: metadata fields only — user / item rows went the presorted way)
 };
 
 __device__ __forceinline__ void field_lookup(const SgdArgs& a, int f, float*& tab, float*& lin, const void*& idx,
@@ -96,10 +97,11 @@ __global__ __launch_bounds__(TRS_BLOCK) void score_sgd_update_kernel(const SgdAr
   const int64_t wave = ((int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x) >> 6;
   const int64_t nwave = ((int64_t)gridDim.x * TRS_BLOCK) >> 6;
   const int64_t n = (int64_t)R * B;
-  const int64_t niter = (n + EPW - 1) / EPW;
+  const int64_t e0 = (int64_t)a.f_begin * B;
+  const int64_t niter = (n - e0 + EPW - 1) / EPW;
   const float alpha = -a.lr;
   for (int64_t it = wave; it < niter; it += nwave) {
-    const int64_t e = it * EPW + lane / LPR;
+    const int64_t e = e0 + it * EPW + lane / LPR;
     if (e >= n) continue;
     const int f = (int)(e / B);
     const int64_t t = e - (int64_t)f * B;
@@ -216,8 +218,18 @@ extern "C" int trs_rows_scatter_add(float* table_dev, int64_t n_rows, int32_t D,
   return TRS_OK;
 }
 
+int trs_launch_sgd_fields(int net, const trs_tables* tables, const trs_batch* batch, const float* grad_rows_dev,
+                          const float* grad_lin_dev, float lr, int f_begin, void* stream);
+
 extern "C" int trs_score_sgd_update(int net, const trs_tables* tables, const trs_batch* batch,
                                     const float* grad_rows_dev, const float* grad_lin_dev, float lr, void* stream) {
+  return trs_launch_sgd_fields(net, tables, batch, grad_rows_dev, grad_lin_dev, lr, 0, stream);
+}
+
+// Atomic SGD scatter of the staged gradient fields [f_begin, R): f_begin = 3 applies the metadata fields only
+// (csrc/fast_step.hip: metadata scorers on the presorted step).
+int trs_launch_sgd_fields(int net, const trs_tables* tables, const trs_batch* batch, const float* grad_rows_dev,
+                          const float* grad_lin_dev, float lr, int f_begin, void* stream) {
   TRS_REQUIRE(tables && batch, "trs_score_sgd_update: tables/batch is NULL");
   TRS_REQUIRE(net == TRS_NET_LINEAR || net == TRS_NET_FM, "trs_score_sgd_update: bad net");
   TRS_REQUIRE(tables->M >= 0 && tables->M <= TRS_MAX_META, "trs_score_sgd_update: bad M");
@@ -233,8 +245,10 @@ extern "C" int trs_score_sgd_update(int net, const trs_tables* tables, const trs
   a.grad_lin = grad_lin_dev;
   a.lr = lr;
   a.has_lin_meta = net == TRS_NET_FM;
+  a.f_begin = f_begin;
   const int D = tables->D;
-  const int64_t n = (int64_t)(3 + 2 * tables->M) * batch->B;
+  const int64_t n = (int64_t)(3 + 2 * tables->M - f_begin) * batch->B;
+  if (n <= 0) return TRS_OK;
   hipStream_t s = (hipStream_t)stream;
 #define TRS_SGD(L)                                                                                  \
   {                                                                                                 \

@@ -93,6 +93,18 @@ struct ScoreArgs {
   int64_t iota_user;
   int64_t iota_item0;
   const int32_t* iota_item_meta;
+  // MODE 2 (metadata scorers on the presorted step, csrc/fast_step.hip): metadata ids are looked up from the item ->
+  // metadata table; the kernel writes gz (2,B), the rows the sorted item update needs (xstage: FM (2,B,D) = the per-pass
+  // field sums S+ / S-, Linear (B,D) = the user row), applies the SGD update of users referenced once in the batch in
+  // place (udup_pos[t] == 0) or stages their gradient (du), stages the metadata fields' gradients in grad_rows /
+  // grad_lin (fields 3..) and their ids in meta_ids_out (2,B,M) for the atomic scatter of those small tables.
+  const int32_t* item_meta_tab;  // (n_items, M) int32
+  float* gz;
+  float* du;
+  float* xstage;
+  const uint8_t* udup_pos;
+  float lr;
+  int32_t* meta_ids_out;
 };
 
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
@@ -192,13 +204,14 @@ __global__ __launch_bounds__(TRS_BLOCK) void score_kernel(const ScoreArgs a) {
     row_load<VEC, G, K>(u, T.user, uid, D, lig);
     const float u_lin = T.user_lin ? T.user_lin[uid] : 0.f;
     float pi_lin, ni_lin = 0.f, lin_p, lin_n = 0.f;
-    const float sp = pass_forward<NET, VEC, G, K>(T, u, u_lin, pid, iota ? (const void*)a.iota_item_meta : a.Bt.pos_meta,
-                                                  iota ? 4 : ib, iota ? pid : tc, valid, lig, pi, Sp, pi_lin, lin_p,
-                                                  ok);
+    constexpr bool TAB = MODE == 2;  // metadata ids from the item -> metadata table, indexed by the item id
+    const float sp = pass_forward<NET, VEC, G, K>(
+        T, u, u_lin, pid, iota ? (const void*)a.iota_item_meta : (TAB ? (const void*)a.item_meta_tab : a.Bt.pos_meta),
+        (iota || TAB) ? 4 : ib, (iota || TAB) ? pid : tc, valid, lig, pi, Sp, pi_lin, lin_p, ok);
     float sn = 0.f;
     if (has_neg)
-      sn = pass_forward<NET, VEC, G, K>(T, u, u_lin, nid, a.Bt.neg_meta, ib, tc, valid, lig, ni, Sn, ni_lin, lin_n,
-                                        ok);
+      sn = pass_forward<NET, VEC, G, K>(T, u, u_lin, nid, TAB ? (const void*)a.item_meta_tab : a.Bt.neg_meta,
+                                        TAB ? 4 : ib, TAB ? nid : tc, valid, lig, ni, Sn, ni_lin, lin_n, ok);
     if (valid && !ok && lig == 0 && a.Bt.err_flag_dev) atomicOr(a.Bt.err_flag_dev, 1);
     const bool live = valid && ok;
 
@@ -296,9 +309,74 @@ __global__ __launch_bounds__(TRS_BLOCK) void score_kernel(const ScoreArgs a) {
         }
       }
     }
+    if (MODE == 2) {
+      const float h = sn - sp + 1.0f;
+      const float act = (live && h >= 0.f) ? 1.f : 0.f;
+      float gp = -act * a.inv_B, gn = act * a.inv_B;
+      if (live && lig == 0) loss_acc += fmaxf(h, 0.f);
+      if (NET == TRS_NET_FM) {
+        gp = gp * ((1.0f - sp) * sp);
+        gn = gn * ((1.0f - sn) * sn);
+      }
+      if (valid) {
+        const int M = T.M;
+        const int64_t BD = B * (int64_t)D;
+        RowReg<VEC, K> g;
+        // rows the sorted item update multiplies by its coefficients: FM needs S of the reference's own pass (the
+        // gradient of a field row v is g*(S - v), and v is the row the run kernel holds), Linear the user row
+        if (NET == TRS_NET_FM) {
+          row_store<VEC, G, K>(Sp, a.xstage + t * (int64_t)D, D, lig);
+          row_store<VEC, G, K>(Sn, a.xstage + BD + t * (int64_t)D, D, lig);
+#pragma unroll
+          for (int n = 0; n < N; ++n) g.v[n] = gp * (Sp.v[n] - u.v[n]) + gn * (Sn.v[n] - u.v[n]);
+        } else {
+          row_store<VEC, G, K>(u, a.xstage + t * (int64_t)D, D, lig);
+#pragma unroll
+          for (int n = 0; n < N; ++n) g.v[n] = gp * Sp.v[n] + gn * Sn.v[n];
+        }
+        if (a.udup_pos[t] || !live) {
+          row_store<VEC, G, K>(g, a.du + t * (int64_t)D, D, lig);
+        } else {
+          RowReg<VEC, K> un;
+#pragma unroll
+          for (int n = 0; n < N; ++n) un.v[n] = u.v[n] + (-a.lr) * g.v[n];
+          row_store<VEC, G, K>(un, T.user + uid * (int64_t)D, D, lig);
+          if (lig == 0 && T.user_lin) T.user_lin[uid] = u_lin + (-a.lr) * (gp + gn);
+        }
+        // metadata fields: staged gradients (as MODE 1 stages them) + their ids
+        for (int m = 0; m < M; ++m) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const float gs = s ? gn : gp;
+            const RowReg<VEC, K>& S = s ? Sn : Sp;
+            int64_t mid = a.item_meta_tab[(s ? nid : pid) * M + m];
+            if ((uint64_t)mid >= (uint64_t)T.n_meta[m]) mid = 0;
+            if (NET == TRS_NET_FM) {
+              RowReg<VEC, K> mr;
+              row_load<VEC, G, K>(mr, T.meta[m], mid, D, lig);
+#pragma unroll
+              for (int n = 0; n < N; ++n) g.v[n] = gs * (S.v[n] - mr.v[n]);
+            } else {
+#pragma unroll
+              for (int n = 0; n < N; ++n) g.v[n] = gs * u.v[n];
+            }
+            row_store<VEC, G, K>(g, a.grad_rows + (int64_t)(3 + 2 * m + s) * BD + t * (int64_t)D, D, lig);
+            if (lig == 0) {
+              a.meta_ids_out[((int64_t)s * B + t) * M + m] = (int32_t)mid;  // a dead triple carries zero gradients
+              if (a.grad_lin) a.grad_lin[(int64_t)(3 + 2 * m + s) * B + t] = NET == TRS_NET_FM ? gs : 0.f;
+            }
+          }
+        }
+        if (lig == 0) {
+          a.gz[t] = gp;
+          a.gz[B + t] = gn;
+        }
+      }
+    }
+
   }
 
-  if (MODE == 1 && a.loss_sum) {
+  if (MODE != 0 && a.loss_sum) {
     __shared__ float s_loss[TRS_BLOCK / TRS_WAVE];
     __shared__ int s_auc[TRS_BLOCK / TRS_WAVE];
     const float wl = trs_wave_sum(loss_acc);

@@ -113,9 +113,10 @@ class SparseScorerTrainer:
         self.fast_kind = None  # "sgd": C step loop on every path; "sparse_adam" / "adagrad": on the presorted path only
         hyper = {"sgd": ("lr",), "sparse_adam": ("lr", "betas", "eps"),
                  "adagrad": ("lr", "lr_decay", "eps", "initial_accumulator_value")}.get(self.kind)
-        if hyper is not None and self.M == 0:
+        # metadata scorers: plain SGD only (their small tables take an atomic scatter of staged gradients)
+        if hyper is not None and (self.M == 0 or self.kind == "sgd"):
             lrs = {tuple(_group_of(optimizer, p).get(k) for k in hyper) for p in self.params}
-            if len(lrs) == 1:  # one rule for the four tables
+            if len(lrs) == 1:  # one rule for all tables
                 self.fast_kind = self.kind
                 self.fast_lr = _group_of(optimizer, self.params[0])["lr"]
                 self.gz = torch.empty((2, batch_capacity), dtype=torch.float32, device=dev)
@@ -139,6 +140,7 @@ class SparseScorerTrainer:
         self._ps_done = [None, None]  # (slice view, completion event) of a prefetched set
         self._ps_cur = 1              # set the step kernels currently read
         self._ps_stream = None        # side HIP stream of the prefetch
+        self.xstage = self.meta_ids = None  # metadata scorers: staged field sums / user rows, metadata ids of a batch
 
     def _views(self, B):
         """Staging views for a batch of B <= capacity rows (contiguous (R,B,D) / (R,B) prefixes)."""
@@ -266,15 +268,32 @@ class SparseScorerTrainer:
         self._ps_cur = i
         return ps
 
-    def fast_sorted_steps(self, ps, b_in_slice, batch, n_steps, loss_sums):
+    def _meta_stage(self, batch, item_meta):
+        """_lib.TrsMetaStage of a metadata scorer: K1 looks the ids up in `item_meta` (n_items, M) int32."""
+        from . import _lib
+        if item_meta is None or item_meta.dtype != torch.int32:
+            raise ValueError("metadata scorers need the (n_items, M) int32 item -> metadata table on the device")
+        if self.xstage is None:
+            passes = 2 if self.net.NET == "fm" else 1
+            self.xstage = torch.empty((passes, self.cap, self.D), dtype=torch.float32, device=self.dev)
+            self.meta_ids = torch.empty((2, self.cap, self.M), dtype=torch.int32, device=self.dev)
+        if batch != self.cap:
+            raise ValueError("the C step loop runs whole batches of the trainer's capacity")
+        ms = _lib.TrsMetaStage()
+        ms.item_meta_tab, ms.xstage, ms.meta_ids = ops.ptr(item_meta), ops.ptr(self.xstage), ops.ptr(self.meta_ids)
+        ms.grad_rows, ms.grad_lin = ops.ptr(self.grad_rows), ops.ptr(self.grad_lin)
+        return ms
+
+    def fast_sorted_steps(self, ps, b_in_slice, batch, n_steps, loss_sums, item_meta=None):
         te, evs, ns = self._make_events(n_steps) if self.kernel_events is not None else (None, None, 0)
         ids, sk, sv, udup, usorted = ps.step_args(b_in_slice)
         if self.ustage is None:
             self.ustage = torch.empty_like(self.du)  # pre-update user rows staged by K1 for the item update
         opt = self._adaptive_rule(n_steps) if self.fast_kind != "sgd" else None
+        meta = self._meta_stage(batch, item_meta) if self.M > 0 else None
         ops.train_steps_sgd(self.net.NET, self.net.tables(), None, None, 0, 0, 0, batch, n_steps, self.fast_lr, *ids,
                             self.gz, self.du, loss_sums, self.err, self.scratch, self._stamps(n_steps), evs, sk, sv,
-                            ps.key_bytes, udup, self.ustage, usorted, opt)
+                            ps.key_bytes, udup, self.ustage, usorted, opt, meta)
         if te is not None:
             # 32-bit keys: item and duplicated-user updates are ONE launch, and the last two events are recorded back to
             # back — that interval is the cost of an event record itself
@@ -333,7 +352,7 @@ class SparseScorerTrainer:
         the SUM of the batch's hinge terms (caller divides by B)."""
         B = ids["user"].shape[0]
         net = self.net
-        if self.fast_kind == "sgd" and auc_slot is None and ids["user"].dtype == torch.int32:
+        if self.fast_kind == "sgd" and self.M == 0 and auc_slot is None and ids["user"].dtype == torch.int32:
             te, evs, ns = self._make_events(1) if self.kernel_events is not None else (None, None, 0)
             ops.train_steps_sgd(net.NET, net.tables(), None, None, 0, 0, 0, B, 1, self.fast_lr, ids["user"],
                                 ids["pos"], ids["neg"], self.gz, self.du, loss_slot, self.err, self.scratch,

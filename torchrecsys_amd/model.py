@@ -11,6 +11,7 @@ Same constructor keywords, same methods, same printed strings, same state_dict k
   seed : seed of the device-side generators (rng='device')
 """
 import math
+import os
 from typing import List
 
 import numpy as np
@@ -400,7 +401,10 @@ class FitRunner:
         done = 0
         kind = getattr(self.trainer, "fast_kind", None)
         # the C step loop: SGD on every path, SparseAdam / Adagrad on the presorted path only
-        fast = kind == "sgd" or (kind is not None and self.trainer.wants_presort(B))
+        has_meta = getattr(self.trainer, "M", 0) > 0  # metadata scorers: presorted path only (SGD)
+        if os.environ.get("TRS_META_FAST", "1") == "0" and has_meta:
+            kind = None  # tuning / fall-back knob: metadata scorers on the generic staged path
+        fast = (kind == "sgd" and not has_meta) or (kind is not None and self.trainer.wants_presort(B))
         if fast and m.rng == 'reference':
             fast = self.ep['user'].dtype == torch.int32
         if fast:  # whole batches, step loop in C (csrc/fast_step.hip): from the resident stream, or from the epoch's
@@ -421,7 +425,8 @@ class FitRunner:
                             self._presort(0, full, prefetch=True, next_epoch=True)
                     s0, ps = self._slice
                     n = min(n, s0 + ps.n_batches - b)
-                    self.trainer.fast_sorted_steps(ps, b - s0, B, n, self.loss_sums[b:b + n])
+                    self.trainer.fast_sorted_steps(ps, b - s0, B, n, self.loss_sums[b:b + n],
+                                                   m._item_meta_dev() if has_meta else None)
                 elif m.rng == 'device':
                     self.trainer.fast_stream_steps(self.st, self.shuffle_key, self.sample_seed, b * B, B, n,
                                                    self.loss_sums[b:b + n])

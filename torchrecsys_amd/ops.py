@@ -213,7 +213,7 @@ class EpochPresort:
 def train_steps_sgd(net, T, stream_ui, neg_static, shuffle_key, sample_seed, first_pos, batch, n_steps,
                     lr, user_buf, pos_buf, neg_buf, gz_buf, du_buf, loss_sums, err_flag, scratch=None, first_stamp=1,
                     events=None, sorted_keys=None, sorted_vals=None, key_bytes=0, user_dup=None, ustage=None,
-                    user_sorted=None, opt=None):
+                    user_sorted=None, opt=None, meta=None):
     """n_steps fused steps driven from C (trs_train_steps_sgd).  stream_ui None: the steps' ids are already in
     user/pos/neg_buf.  events: optional flat list of 4*n_steps raw hipEvent_t handles.  opt: None (SGD with lr) or a
     _lib.TrsOpt (SparseAdam / Adagrad on the presorted path; keep the tensors it points to alive)."""
@@ -227,7 +227,8 @@ def train_steps_sgd(net, T, stream_ui, neg_static, shuffle_key, sample_seed, fir
                                           ptr(gz_buf), ptr(du_buf), ptr(loss_sums), ptr(err_flag), ptr(scratch),
                                           int(first_stamp), sorted_keys, sorted_vals, int(key_bytes), ptr(user_dup),
                                           ptr(ustage), *(user_sorted or (None, None, 0, 0)),
-                                          C.byref(opt) if opt is not None else None, ev, _stream()),
+                                          C.byref(opt) if opt is not None else None,
+                                          C.byref(meta) if meta is not None else None, ev, _stream()),
           "trs_train_steps_sgd")
 
 
