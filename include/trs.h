@@ -186,7 +186,20 @@ typedef struct trs_meta_stage {
   float* grad_rows;             /* (3 + 2M, batch, D): fields 3.. are written */
   float* grad_lin;              /* (3 + 2M, batch) */
   int32_t* meta_ids;            /* (2, batch, M) */
+  /* Optional: every column's references sorted per batch (trs_epoch_presort_meta, offset to the call's first batch).
+   * Then the metadata tables are updated by sorted runs like the item table (no gradient staging, no atomics but for
+   * cut runs) and grad_rows / grad_lin / meta_ids may be NULL.  lin_scratch: max(n_meta) floats, used in place of the
+   * 1-wide metadata tables a Linear scorer does not have. */
+  const void* sorted_keys[TRS_MAX_META];
+  const void* sorted_vals[TRS_MAX_META];
+  float* lin_scratch;
 } trs_meta_stage;
+/* Sorted references of metadata column m of an epoch slice whose ids exist (trs_epoch_presort): buffers and sizes as
+ * trs_epoch_presort_sizes(n_batches, batch, n_cat, ...). */
+int trs_epoch_presort_meta(const int32_t* pos_dev, const int32_t* neg_dev, int64_t n_batches, int64_t batch,
+                           const int32_t* item_meta_dev, int32_t M, int32_t m, int64_t n_cat, void* keys_dev,
+                           void* vals_dev, void* temp_dev, int64_t temp_bytes, int32_t* err_flag_dev,
+                           void** sorted_keys_out, void** sorted_vals_out, void* stream);
 int64_t trs_train_scratch_bytes(int64_t n_users, int64_t n_items, int64_t batch, int32_t D);
 int trs_train_steps_sgd(int net, const trs_tables* tables, const int32_t* stream_ui_dev,
                         const int32_t* neg_static_dev, int64_t N,

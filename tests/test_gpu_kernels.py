@@ -704,7 +704,8 @@ def test_presorted_adaptive_rules_match_the_oracle(net, D, skew, kind):
 
 @pytest.mark.parametrize("net,D,M,skew", [("fm", 64, 1, False), ("fm", 16, 3, True), ("linear", 32, 1, True),
                                           ("linear", 8, 2, False), ("fm", 10, 1, True)])
-def test_presorted_step_with_metadata_matches_oracle(net, D, M, skew):
+@pytest.mark.parametrize("meta_sorted", [False, True])
+def test_presorted_step_with_metadata_matches_oracle(net, D, M, skew, meta_sorted):
     """Metadata scorers on the presorted step (SGD): K1 = the scorer's staging mode (ids from the item -> metadata
     table, user update in place, FM: per-pass field sums staged), user / item rows through the sorted runs (FM: w +=
     sum(c*S) - sum(c)*w), metadata tables through the atomic scatter of the staged fields: 3 batches == oracle steps."""
@@ -725,7 +726,9 @@ def test_presorted_step_with_metadata_matches_oracle(net, D, M, skew):
     meta_lins = [t[f"linear_metadata.{m}.weight"] for m in range(M)] if net == "fm" else []
     T, keep = ops.make_tables(t["user.weight"], t["item.weight"], t[lin[0]], t[lin[1]], metas, meta_lins)
     err = torch.zeros(1, dtype=torch.int32, device=DEV)
-    ps = ops.EpochPresort(nb, B, NU, NI, DEV)
+    tab = torch.from_numpy(item_meta).to(DEV)
+    # meta_sorted: every metadata column's references grouped by row too (sorted runs instead of the atomic scatter)
+    ps = ops.EpochPresort(nb, B, NU, NI, DEV, **(dict(item_meta=tab, n_meta=sizes) if meta_sorted else {}))
     ps.run(None, None, 0, 0, 0, err, given_ids=[torch.from_numpy(a.astype(np.int32)).to(DEV) for a in (u, i, j)])
     ids, sk, sv, udup, usorted = ps.step_args(0)
     R = 3 + 2 * M
@@ -733,10 +736,14 @@ def test_presorted_step_with_metadata_matches_oracle(net, D, M, skew):
     xstage = torch.empty((2 if net == "fm" else 1, B, D), device=DEV)
     grad_rows, grad_lin = torch.empty((R, B, D), device=DEV), torch.zeros((R, B), device=DEV)
     meta_ids = torch.empty((2, B, M), dtype=torch.int32, device=DEV)
-    tab = torch.from_numpy(item_meta).to(DEV)
     ms = _lib.TrsMetaStage()
     ms.item_meta_tab, ms.xstage, ms.meta_ids = ops.ptr(tab), ops.ptr(xstage), ops.ptr(meta_ids)
     ms.grad_rows, ms.grad_lin = ops.ptr(grad_rows), ops.ptr(grad_lin)
+    lin_scratch = torch.zeros(max(sizes), device=DEV)
+    if meta_sorted:
+        for m, (k_, v_) in enumerate(ps.meta_step_args(0)):
+            ms.sorted_keys[m], ms.sorted_vals[m] = k_, v_
+        ms.lin_scratch = ops.ptr(lin_scratch)
     losses = torch.zeros(nb, device=DEV)
     ops.train_steps_sgd(net, T, None, None, 0, 0, 0, B, nb, lr, *ids, gz, du, losses, err,
                         ops.train_scratch(NU, NI, B, D, DEV), 1, None, sk, sv, ps.key_bytes, udup,

@@ -769,6 +769,9 @@ int trs_launch_sorted_updates_fused(const trs_tables* tables, const void* keys_s
                                     int64_t batch, int64_t item_bits, const float* gz, float lr, const float* ustage,
                                     const void* ukeys_step, const void* uvals_step, int64_t q0, const float* du,
                                     const OptArgs* opt, int parity, int64_t xpass, int fmsub, hipStream_t s);
+int trs_launch_sorted_meta_update(const trs_tables* tables, int m, float* lin_or_scratch, const void* keys_step,
+                                  const void* vals_step, int64_t batch, const float* gz, float lr, const float* xstage,
+                                  int64_t xpass, int fmsub, hipStream_t s);
 // rows.hip
 int trs_launch_sgd_fields(int net, const trs_tables* tables, const trs_batch* batch, const float* grad_rows_dev,
                           const float* grad_lin_dev, float lr, int f_begin, void* stream);
@@ -814,8 +817,13 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
   if (meta) {
     TRS_REQUIRE(sorted_keys_dev && user_dup_flags_dev && key_bytes == 4 && ukey_bytes == 4 && !adaptive,
                 "trs_train_steps_sgd: metadata scorers run on the presorted step with plain SGD only");
-    TRS_REQUIRE(meta->item_meta_tab && meta->xstage && meta->grad_rows && meta->grad_lin && meta->meta_ids,
-                "trs_train_steps_sgd: metadata staging buffer is NULL");
+    const bool meta_sorted = meta->sorted_keys[0] != nullptr;
+    TRS_REQUIRE(meta->item_meta_tab && meta->xstage, "trs_train_steps_sgd: metadata staging buffer is NULL");
+    TRS_REQUIRE(meta_sorted || (meta->grad_rows && meta->grad_lin && meta->meta_ids),
+                "trs_train_steps_sgd: metadata gradient staging is NULL");
+    for (int m = 0; m < tables->M && meta_sorted; ++m)
+      TRS_REQUIRE(meta->sorted_keys[m] && meta->sorted_vals[m] && (net == TRS_NET_FM || meta->lin_scratch),
+                  "trs_train_steps_sgd: sorted references of metadata column %d are NULL", m);
     for (int m = 0; m < tables->M; ++m)
       TRS_REQUIRE(tables->meta[m] && (net != TRS_NET_FM || tables->meta_lin[m]),
                   "trs_train_steps_sgd: metadata table %d is NULL", m);
@@ -903,8 +911,9 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
       sa.Bt.B = batch; sa.Bt.idx_bytes = 4; sa.Bt.err_flag_dev = err_flag_dev;
       sa.inv_B = a.inv_B;
       sa.loss_sum = a.loss_sum;
-      sa.grad_rows = meta->grad_rows;
-      sa.grad_lin = meta->grad_lin;
+      const bool meta_sorted = meta->sorted_keys[0] != nullptr;
+      sa.grad_rows = meta_sorted ? nullptr : meta->grad_rows;
+      sa.grad_lin = meta_sorted ? nullptr : meta->grad_lin;
       sa.iota_user = -1;
       sa.item_meta_tab = meta->item_meta_tab;
       sa.gz = a.gz; sa.du = a.du; sa.xstage = meta->xstage;
@@ -929,7 +938,16 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
                                              slice_pos0 + (int64_t)st * batch, a.du, adaptive ? &a.o : nullptr,
                                              (int)(a.stamp & 1u), fm_meta ? batch : 0, fm_meta ? 1 : 0, s);
         if (rc) return rc;
-        if (meta) {  // the metadata fields staged by K1: atomic scatter into their (small) tables
+        if (meta && meta->sorted_keys[0]) {  // one sorted-run launch per metadata column
+          for (int m = 0; m < tables->M; ++m) {
+            const char* mk = (const char*)meta->sorted_keys[m] + (int64_t)st * 2 * batch * 4;
+            const char* mv = (const char*)meta->sorted_vals[m] + (int64_t)st * 2 * batch * 4;
+            rc = trs_launch_sorted_meta_update(tables, m, net == TRS_NET_FM ? tables->meta_lin[m] : meta->lin_scratch, mk,
+                                               mv, batch, a.gz, a.lr, meta->xstage, fm_meta ? batch : 0, fm_meta ? 1 : 0,
+                                               s);
+            if (rc) return rc;
+          }
+        } else if (meta) {  // the metadata fields staged by K1: atomic scatter into their (small) tables
           trs_batch mb = {};
           mb.user = a.user; mb.pos = a.pos; mb.neg = a.neg;
           mb.pos_meta = meta->meta_ids;

@@ -121,6 +121,9 @@ struct SortedArgs {
   // every reference, w = the pre-update row); Linear / FM without metadata stage the user row (xpass = 0, fmsub = 0)
   int64_t xpass;
   int fmsub;
+  // the table the runs update: the item table (NULL: T.item / T.item_lin) or one metadata column's tables
+  float* tab;
+  float* tab_lin;  // never NULL with tab (a Linear scorer's metadata columns pass a scratch array)
 };
 
 constexpr int RUN_CHUNK = 64;  // runs are cut at multiples of this many references
@@ -220,6 +223,8 @@ __device__ __forceinline__ void sorted_item_update_staged_body(const SortedArgs&
   __shared__ unsigned char lead_lane[NW][TRS_WAVE];
   const trs_tables& T = a.T;
   const int D = T.D;
+  float* const tab = a.tab ? a.tab : T.item;
+  float* const tab_lin = a.tab ? a.tab_lin : T.item_lin;
   const int64_t n = 2 * a.B;
   const KeyT* keys = reinterpret_cast<const KeyT*>(a.keys);
   const KeyT row_mask = (KeyT)(((uint64_t)1 << a.item_bits) - 1);
@@ -271,8 +276,8 @@ __device__ __forceinline__ void sorted_item_update_staged_body(const SortedArgs&
         keyv[s] = (KeyT)key;
         hd[s] = __shfl((int)head, l[s], 64);
         row[s] = has[s] ? (int64_t)((KeyT)key & row_mask) : 0;
-        row_load<VEC, G, K, FULL>(w[s], T.item, row[s], D, lig);
-        wl[s] = T.item_lin[row[s]];
+        row_load<VEC, G, K, FULL>(w[s], tab, row[s], D, lig);
+        wl[s] = tab_lin[row[s]];
         ls1[s] = ls2[s] = 0.f;
         if (OPT != OPT_SGD) {
           row_load<VEC, G, K, FULL>(s1[s], a.o.item_s1, row[s], D, lig);
@@ -319,14 +324,14 @@ __device__ __forceinline__ void sorted_item_update_staged_body(const SortedArgs&
           lin += cj;
         }
         const bool cut_tail = (l[s] + len[s] == RUN_CHUNK) && (base + RUN_CHUNK < n) && knext == keyv[s];
-        float* irow = T.item + row[s] * (int64_t)D;
+        float* irow = tab + row[s] * (int64_t)D;
         if (hd[s] != 0 && !cut_tail) {
           if (OPT == OPT_SGD) {
             const float sub = a.fmsub ? lin : 0.f;  // FM with metadata: -sum(c) * w, the "- v" of g*(S - v)
 #pragma unroll
             for (int q = 0; q < N; ++q) w[s].v[q] += a.fmsub ? acc.v[q] - sub * w[s].v[q] : acc.v[q];
             row_store<VEC, G, K>(w[s], irow, D, lig);
-            if (lig == 0) T.item_lin[row[s]] = wl[s] + lin;
+            if (lig == 0) tab_lin[row[s]] = wl[s] + lin;
           } else {  // the run is the row's whole gradient: apply the rule once, state rows beside the weights
 #pragma unroll
             for (int q = 0; q < N; ++q) w[s].v[q] = opt_apply<OPT>(w[s].v[q], acc.v[q], s1[s].v[q], s2[s].v[q], a.o);
@@ -334,7 +339,7 @@ __device__ __forceinline__ void sorted_item_update_staged_body(const SortedArgs&
             row_store<VEC, G, K>(s1[s], a.o.item_s1 + row[s] * (int64_t)D, D, lig);
             if (OPT == OPT_ADAM) row_store<VEC, G, K>(s2[s], a.o.item_s2 + row[s] * (int64_t)D, D, lig);
             if (lig == 0) {
-              T.item_lin[row[s]] = opt_apply<OPT>(wl[s], lin, ls1[s], ls2[s], a.o);
+              tab_lin[row[s]] = opt_apply<OPT>(wl[s], lin, ls1[s], ls2[s], a.o);
               a.o.item_lin_s1[row[s]] = ls1[s];
               if (OPT == OPT_ADAM) a.o.item_lin_s2[row[s]] = ls2[s];
             }
@@ -368,7 +373,7 @@ __device__ __forceinline__ void sorted_item_update_staged_body(const SortedArgs&
               if (e + q < D)
                 atomicAdd(irow + e + q, a.fmsub ? acc.v[kk * VEC + q] - lin * w[s].v[kk * VEC + q] : acc.v[kk * VEC + q]);
           }
-          if (lig == 0) atomicAdd(T.item_lin + row[s], lin);
+          if (lig == 0) atomicAdd(tab_lin + row[s], lin);
         }
       }
     }
@@ -737,6 +742,61 @@ extern "C" int trs_epoch_user_dups(const int32_t* user_dev, int64_t n_batches, i
   return TRS_OK;
 }
 
+// References of one metadata column: key = metadata id of the reference's item, payload as for the item references.
+__global__ __launch_bounds__(TRS_BLOCK) void meta_refs_kernel(const int32_t* __restrict__ pos,
+                                                             const int32_t* __restrict__ neg, int64_t n_pos,
+                                                             int64_t batch, const int32_t* __restrict__ item_meta, int M,
+                                                             int m, int64_t n_cat, uint32_t* __restrict__ keys,
+                                                             RefPayload* __restrict__ vals, int32_t* err) {
+  const int64_t stride = (int64_t)gridDim.x * TRS_BLOCK;
+  for (int64_t q = (int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x; q < n_pos; q += stride) {
+    const uint32_t t = (uint32_t)(q % batch);
+    int64_t kp = item_meta[(int64_t)pos[q] * M + m], kn = item_meta[(int64_t)neg[q] * M + m];
+    if ((uint64_t)kp >= (uint64_t)n_cat || (uint64_t)kn >= (uint64_t)n_cat) {
+      if (err) atomicOr(err, 1);
+      if ((uint64_t)kp >= (uint64_t)n_cat) kp = 0;
+      if ((uint64_t)kn >= (uint64_t)n_cat) kn = 0;
+    }
+    keys[2 * q] = (uint32_t)kp;
+    keys[2 * q + 1] = (uint32_t)kn;
+    RefPayload v0 = {(t << 1)}, v1 = {(t << 1) | 1u};
+    vals[2 * q] = v0;
+    vals[2 * q + 1] = v1;
+  }
+}
+
+// Sorted references of metadata column m for an epoch slice whose ids (pos, neg: already validated item ids) exist:
+// same buffers / sizes as trs_epoch_presort with n_items := n_cat.
+extern "C" int trs_epoch_presort_meta(const int32_t* pos_dev, const int32_t* neg_dev, int64_t n_batches, int64_t batch,
+                                      const int32_t* item_meta_dev, int32_t M, int32_t m, int64_t n_cat,
+                                      void* keys_dev, void* vals_dev, void* temp_dev, int64_t temp_bytes,
+                                      int32_t* err_flag_dev, void** sorted_keys_out, void** sorted_vals_out,
+                                      void* stream) {
+  TRS_REQUIRE(pos_dev && neg_dev && item_meta_dev && keys_dev && vals_dev && temp_dev && sorted_keys_out &&
+                  sorted_vals_out, "trs_epoch_presort_meta: NULL argument");
+  TRS_REQUIRE(n_batches > 0 && batch > 0 && M > 0 && m >= 0 && m < M && n_cat > 0, "trs_epoch_presort_meta: bad sizes");
+  const int64_t n_pos = n_batches * batch;
+  TRS_REQUIRE(2 * n_pos < ((int64_t)1 << 32), "trs_epoch_presort_meta: slice too long");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = (size_t)(2 * n_pos);
+  uint32_t* kin = (uint32_t*)keys_dev;
+  RefPayload* vin = (RefPayload*)vals_dev;
+  hipLaunchKernelGGL(meta_refs_kernel, dim3(trs_grid(n_pos, TRS_BLOCK)), dim3(TRS_BLOCK), 0, s, pos_dev, neg_dev, n_pos,
+                     batch, item_meta_dev, M, m, n_cat, kin, vin, err_flag_dev);
+  TRS_CHECK_LAUNCH("meta_refs_kernel");
+  size_t temp = (size_t)temp_bytes;
+  hipError_t e = rocprim::segmented_radix_sort_pairs<ItemSortCfg>(
+      temp_dev, temp, kin, kin + n, vin, vin + n, n, (unsigned)n_batches, seg_it(0, (uint32_t)(2 * batch)),
+      seg_it(1, (uint32_t)(2 * batch)), 0u, (unsigned)bits_for(n_cat), s);
+  *sorted_keys_out = (void*)(kin + n);
+  *sorted_vals_out = (void*)(vin + n);
+  if (e != hipSuccess) {
+    trs_set_error("trs_epoch_presort_meta: rocprim::segmented_radix_sort_pairs failed: %s", hipGetErrorString(e));
+    return TRS_E_LAUNCH;
+  }
+  return TRS_OK;
+}
+
 // One launch of the sorted item update for a step (used by trs_train_steps_sgd's sorted mode).
 int trs_launch_sorted_item_update(const trs_tables* tables, const void* keys_step, const void* vals_step, int key_bytes,
                                   int64_t batch, int64_t n_batches_bits_items, const float* gz, float lr,
@@ -795,6 +855,55 @@ int trs_launch_sorted_item_update(const trs_tables* tables, const void* keys_ste
 }
 
 int trs_item_bits_for(int64_t n_items) { return bits_for(n_items); }
+
+// Sorted-run update of one metadata column (SGD): the staged item kernel pointed at that column's tables.
+int trs_launch_sorted_meta_update(const trs_tables* tables, int m, float* lin_or_scratch, const void* keys_step,
+                                  const void* vals_step, int64_t batch, const float* gz, float lr, const float* xstage,
+                                  int64_t xpass, int fmsub, hipStream_t s) {
+  SortedArgs a = {};
+  a.T = *tables;
+  a.keys = keys_step;
+  a.vals = (const RefPayload*)vals_step;
+  a.B = batch;
+  a.item_bits = bits_for(tables->n_meta[m]);
+  a.gz = gz;
+  a.lr = lr;
+  a.ustage = xstage;
+  a.xpass = xpass;
+  a.fmsub = fmsub;
+  a.tab = tables->meta[m];
+  a.tab_lin = lin_or_scratch;
+  RowCfg c;
+  if (!pick_row_cfg(tables->D, c)) {
+    trs_set_error("unsupported n_factors D=%d", tables->D);
+    return TRS_E_ARG;
+  }
+  const dim3 gs(trs_grid((2 * batch + RUN_CHUNK - 1) / RUN_CHUNK, 1)), bl(TRS_BLOCK);
+#define TRS_CASE(V, GG, KK)                                                                                          \
+  if (c.vec == V && c.g == GG && c.k == KK) {                                                                        \
+    if (V * GG * KK == tables->D)                                                                                    \
+      hipLaunchKernelGGL((sorted_item_update_staged_kernel<uint32_t, V, GG, KK, true>), gs, bl, 0, s, a);            \
+    else                                                                                                             \
+      hipLaunchKernelGGL((sorted_item_update_staged_kernel<uint32_t, V, GG, KK, false>), gs, bl, 0, s, a);           \
+    TRS_CHECK_LAUNCH("sorted_item_update_staged_kernel");                                                            \
+    return TRS_OK;                                                                                                   \
+  }
+  TRS_CASE(4, 2, 1)
+  TRS_CASE(4, 4, 1)
+  TRS_CASE(4, 8, 1)
+  TRS_CASE(4, 16, 1)
+  TRS_CASE(4, 32, 1)
+  TRS_CASE(4, 64, 1)
+  TRS_CASE(4, 64, 2)
+  TRS_CASE(4, 64, 4)
+  TRS_CASE(1, 4, 1)
+  TRS_CASE(1, 16, 1)
+  TRS_CASE(1, 64, 1)
+  TRS_CASE(1, 64, 4)
+#undef TRS_CASE
+  trs_set_error("internal: no kernel for D=%d", tables->D);
+  return TRS_E_ARG;
+}
 
 // Fused launch of the staged item update and the duplicated-user update (both with 32-bit keys).
 int trs_launch_sorted_updates_fused(const trs_tables* tables, const void* keys_step, const void* vals_step,

@@ -343,8 +343,9 @@ __global__ __launch_bounds__(TRS_BLOCK) void score_kernel(const ScoreArgs a) {
           row_store<VEC, G, K>(un, T.user + uid * (int64_t)D, D, lig);
           if (lig == 0 && T.user_lin) T.user_lin[uid] = u_lin + (-a.lr) * (gp + gn);
         }
-        // metadata fields: staged gradients (as MODE 1 stages them) + their ids
-        for (int m = 0; m < M; ++m) {
+        // metadata fields: staged gradients (as MODE 1 stages them) + their ids — unless the columns have sorted runs
+        // of their own (grad_rows == NULL: they read xstage like the item runs)
+        for (int m = 0; m < (a.grad_rows ? M : 0); ++m) {
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
             const float gs = s ? gn : gp;

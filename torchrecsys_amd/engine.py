@@ -141,6 +141,7 @@ class SparseScorerTrainer:
         self._ps_cur = 1              # set the step kernels currently read
         self._ps_stream = None        # side HIP stream of the prefetch
         self.xstage = self.meta_ids = None  # metadata scorers: staged field sums / user rows, metadata ids of a batch
+        self.item_meta = None               # (n_items, M) int32 item -> metadata table (set by the runner)
 
     def _views(self, B):
         """Staging views for a batch of B <= capacity rows (contiguous (R,B,D) / (R,B) prefixes)."""
@@ -207,7 +208,7 @@ class SparseScorerTrainer:
             return False
         memo = self._ps_fits
         if batch not in memo:  # decided once: two buffer sets (one being sorted while the other is read)
-            need = 2 * ops.EpochPresort.bytes_needed(self.SLICE_BATCHES, batch, n_items)
+            need = 2 * ops.EpochPresort.bytes_needed(self.SLICE_BATCHES, batch, n_items, self.M)
             free, _ = torch.cuda.mem_get_info(self.dev)
             memo[batch] = need < 0.3 * free
         return memo[batch]
@@ -216,8 +217,11 @@ class SparseScorerTrainer:
         sets = self._ps_sets
         ps = sets[i]
         if ps is None or ps.batch != batch or ps.n_batches < n_batches:
+            meta_kw = {}
+            if self.M > 0 and os.environ.get("TRS_META_SORTED", "1") != "0":  # knob: 0 = atomic scatter of staged fields
+                meta_kw = dict(item_meta=self.item_meta, n_meta=[p.shape[0] for p in self.params[4:4 + self.M]])
             ps = sets[i] = ops.EpochPresort(max(n_batches, min(self.SLICE_BATCHES, n_batches)), batch,
-                                            self.params[0].shape[0], self.params[1].shape[0], self.dev)
+                                            self.params[0].shape[0], self.params[1].shape[0], self.dev, **meta_kw)
         if ps.n_batches != n_batches:  # a shorter tail slice: same buffers, fewer batches
             full = ps
             ps = ops.EpochPresort.__new__(ops.EpochPresort)
@@ -268,7 +272,7 @@ class SparseScorerTrainer:
         self._ps_cur = i
         return ps
 
-    def _meta_stage(self, batch, item_meta):
+    def _meta_stage(self, batch, item_meta, meta_sorted=()):
         """_lib.TrsMetaStage of a metadata scorer: K1 looks the ids up in `item_meta` (n_items, M) int32."""
         from . import _lib
         if item_meta is None or item_meta.dtype != torch.int32:
@@ -282,6 +286,13 @@ class SparseScorerTrainer:
         ms = _lib.TrsMetaStage()
         ms.item_meta_tab, ms.xstage, ms.meta_ids = ops.ptr(item_meta), ops.ptr(self.xstage), ops.ptr(self.meta_ids)
         ms.grad_rows, ms.grad_lin = ops.ptr(self.grad_rows), ops.ptr(self.grad_lin)
+        for m, (k, v) in enumerate(meta_sorted):  # sorted references per column: runs instead of the atomic scatter
+            ms.sorted_keys[m], ms.sorted_vals[m] = k, v
+        if meta_sorted:
+            if getattr(self, "lin_scratch", None) is None:
+                self.lin_scratch = torch.zeros(max(p.shape[0] for p in self.params[4:4 + self.M]), dtype=torch.float32,
+                                               device=self.dev)
+            ms.lin_scratch = ops.ptr(self.lin_scratch)
         return ms
 
     def fast_sorted_steps(self, ps, b_in_slice, batch, n_steps, loss_sums, item_meta=None):
@@ -290,7 +301,7 @@ class SparseScorerTrainer:
         if self.ustage is None:
             self.ustage = torch.empty_like(self.du)  # pre-update user rows staged by K1 for the item update
         opt = self._adaptive_rule(n_steps) if self.fast_kind != "sgd" else None
-        meta = self._meta_stage(batch, item_meta) if self.M > 0 else None
+        meta = self._meta_stage(batch, item_meta, ps.meta_step_args(b_in_slice)) if self.M > 0 else None
         ops.train_steps_sgd(self.net.NET, self.net.tables(), None, None, 0, 0, 0, batch, n_steps, self.fast_lr, *ids,
                             self.gz, self.du, loss_sums, self.err, self.scratch, self._stamps(n_steps), evs, sk, sv,
                             ps.key_bytes, udup, self.ustage, usorted, opt, meta)

@@ -358,6 +358,8 @@ class FitRunner:
                                      metadata_id_cols=model.metadata_name) if model.rng == 'reference' else None
         self.num_batches = int(math.ceil(self.n_train / batch_size)) if self.n_train > 0 else 0
         self.trainer = model._make_trainer(optimizer, min(batch_size, max(self.n_train, 1)))
+        if getattr(self.trainer, "M", 0) > 0:
+            self.trainer.item_meta = model._item_meta_dev()  # metadata scorers: the presort groups each column too
         self.loss_sums = torch.zeros(max(self.num_batches, 1), dtype=torch.float32, device=self.dev)
         self.next_batch = 0
         self.ep = None

@@ -151,7 +151,8 @@ class EpochPresort:
     """Buffers + result of trs_epoch_presort for n_batches whole batches: id arrays and the item references of every
     batch sorted by row.  `step_args(b)` gives what trs_train_steps_sgd needs to start at batch b of the slice."""
 
-    def __init__(self, n_batches, batch, n_users, n_items, device):
+    def __init__(self, n_batches, batch, n_users, n_items, device, item_meta=None, n_meta=()):
+        """item_meta (n_items, M) int32 + n_meta (categories per column): also sort every metadata column's references."""
         lib = _lib.load()
         kb, ktot, vtot, tmp = (C.c_int64() for _ in range(4))
         check(lib.trs_epoch_presort_sizes(n_batches, batch, n_items, C.byref(kb), C.byref(ktot), C.byref(vtot),
@@ -171,14 +172,19 @@ class EpochPresort:
         self.temp = torch.empty(self.temp_bytes, dtype=torch.uint8, device=device)
         self.user_dup = torch.empty(n_pos, dtype=torch.uint8, device=device)  # 1: user has another reference in its batch
         self.sorted_keys = self.sorted_vals = None
+        self.item_meta, self.n_meta = item_meta, [int(c) for c in n_meta]
+        self.meta_keys = [torch.empty(ktot.value, dtype=torch.uint8, device=device) for _ in self.n_meta]
+        self.meta_vals = [torch.empty(vtot.value, dtype=torch.uint8, device=device) for _ in self.n_meta]
+        self.meta_sorted = []
 
     @staticmethod
-    def bytes_needed(n_batches, batch, n_items):
+    def bytes_needed(n_batches, batch, n_items, n_meta_cols=0):
         lib = _lib.load()
         kb, ktot, vtot, tmp = (C.c_int64() for _ in range(4))
         check(lib.trs_epoch_presort_sizes(n_batches, batch, n_items, C.byref(kb), C.byref(ktot), C.byref(vtot),
                                           C.byref(tmp)), "trs_epoch_presort_sizes")
-        return 12 * n_batches * batch + ktot.value + vtot.value + tmp.value + 17 * n_batches * batch
+        return (12 * n_batches * batch + (1 + n_meta_cols) * (ktot.value + vtot.value) + tmp.value
+                + 17 * n_batches * batch)
 
     def run(self, stream_ui, neg_static, shuffle_key, sample_seed, first_pos, err_flag, given_ids=None):
         """Generate (stream_ui given) or adopt (given_ids = (user, pos, neg) int32 tensors) the ids and sort the refs."""
@@ -200,6 +206,20 @@ class EpochPresort:
                                               ptr(self.user_dup), C.byref(uk), C.byref(uv), C.byref(ukb), _stream()),
               "trs_epoch_user_dups")
         self.sorted_ukeys, self.sorted_uvals, self.ukey_bytes = uk.value, uv.value, ukb.value
+        self.meta_sorted = []
+        for m, n_cat in enumerate(self.n_meta):  # metadata columns: the same grouping by row, per column
+            mk, mv = C.c_void_p(), C.c_void_p()
+            check(_lib.load().trs_epoch_presort_meta(ptr(self.ids[1]), ptr(self.ids[2]), self.n_batches, self.batch,
+                                                     ptr(self.item_meta), len(self.n_meta), m, n_cat,
+                                                     ptr(self.meta_keys[m]), ptr(self.meta_vals[m]), ptr(self.temp),
+                                                     self.temp_bytes, ptr(err_flag), C.byref(mk), C.byref(mv),
+                                                     _stream()), "trs_epoch_presort_meta")
+            self.meta_sorted.append((mk.value, mv.value))
+
+    def meta_step_args(self, b):
+        """[(sorted keys address, sorted vals address)] of every metadata column for the steps starting at batch b."""
+        o = b * self.batch
+        return [(k + 2 * o * 4, v + 2 * o * 4) for k, v in self.meta_sorted]
 
     def step_args(self, b):
         """(user, pos, neg id views, sorted keys address, sorted vals address, user-duplicate flags view) for the steps
