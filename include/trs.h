@@ -193,13 +193,19 @@ typedef struct trs_meta_stage {
   const void* sorted_keys[TRS_MAX_META];
   const void* sorted_vals[TRS_MAX_META];
   float* lin_scratch;
+  /* Optional: the slice's metadata ids by position, (n_steps * batch, M) int32 each, offset to the call's first batch
+   * (written by trs_epoch_presort_meta): K1 reads them instead of looking them up behind the item ids. */
+  const int32_t* pos_meta_ids;
+  const int32_t* neg_meta_ids;
 } trs_meta_stage;
 /* Sorted references of metadata column m of an epoch slice whose ids exist (trs_epoch_presort): buffers and sizes as
- * trs_epoch_presort_sizes(n_batches, batch, n_cat, ...). */
+ * trs_epoch_presort_sizes(n_batches, batch, n_cat, ...).  pos/neg_meta_out_dev (both or neither; (n_pos, M) int32): the
+ * looked-up ids of column m, written for K1 (trs_meta_stage.pos_meta_ids / neg_meta_ids). */
 int trs_epoch_presort_meta(const int32_t* pos_dev, const int32_t* neg_dev, int64_t n_batches, int64_t batch,
                            const int32_t* item_meta_dev, int32_t M, int32_t m, int64_t n_cat, void* keys_dev,
                            void* vals_dev, void* temp_dev, int64_t temp_bytes, int32_t* err_flag_dev,
-                           void** sorted_keys_out, void** sorted_vals_out, void* stream);
+                           void** sorted_keys_out, void** sorted_vals_out, int32_t* pos_meta_out_dev,
+                           int32_t* neg_meta_out_dev, void* stream);
 int64_t trs_train_scratch_bytes(int64_t n_users, int64_t n_items, int64_t batch, int32_t D);
 int trs_train_steps_sgd(int net, const trs_tables* tables, const int32_t* stream_ui_dev,
                         const int32_t* neg_static_dev, int64_t N,

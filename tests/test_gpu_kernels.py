@@ -744,6 +744,9 @@ def test_presorted_step_with_metadata_matches_oracle(net, D, M, skew, meta_sorte
         for m, (k_, v_) in enumerate(ps.meta_step_args(0)):
             ms.sorted_keys[m], ms.sorted_vals[m] = k_, v_
         ms.lin_scratch = ops.ptr(lin_scratch)
+        if D != 16:  # one case keeps the table look-up inside K1
+            pm, nm = ps.meta_id_args(0)
+            ms.pos_meta_ids, ms.neg_meta_ids = ops.ptr(pm), ops.ptr(nm)
     losses = torch.zeros(nb, device=DEV)
     ops.train_steps_sgd(net, T, None, None, 0, 0, 0, B, nb, lr, *ids, gz, du, losses, err,
                         ops.train_scratch(NU, NI, B, D, DEV), 1, None, sk, sv, ps.key_bytes, udup,

@@ -69,7 +69,8 @@ class TrsMetaStage(C.Structure):
     """struct trs_meta_stage (include/trs.h): staging of metadata scorers on the presorted step."""
     _fields_ = [("item_meta_tab", C.c_void_p), ("xstage", C.c_void_p), ("grad_rows", C.c_void_p),
                 ("grad_lin", C.c_void_p), ("meta_ids", C.c_void_p), ("sorted_keys", C.c_void_p * TRS_MAX_META),
-                ("sorted_vals", C.c_void_p * TRS_MAX_META), ("lin_scratch", C.c_void_p)]
+                ("sorted_vals", C.c_void_p * TRS_MAX_META), ("lin_scratch", C.c_void_p),
+                ("pos_meta_ids", C.c_void_p), ("neg_meta_ids", C.c_void_p)]
 
 
 _vp, _i32, _i64, _u64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
@@ -99,7 +100,7 @@ PROTOTYPES = {
                                       _vp, _vp, _vp, _vp, _vp, C.c_uint32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32,
                                       _i64, C.POINTER(TrsOpt), C.POINTER(TrsMetaStage), _vp, _vp]),
     "trs_epoch_presort_meta": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _i64, _vp,
-                                         C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp]),
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp, _vp, _vp]),
     "trs_epoch_user_dups_sizes": (C.c_int, [_i64, _i64, _i64, c_int64_p, c_int64_p, c_int64_p]),
     "trs_epoch_user_dups": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, C.POINTER(C.c_void_p),
                                       C.POINTER(C.c_void_p), c_int32_p, _vp]),

@@ -909,6 +909,10 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
       sa.T = *tables;
       sa.Bt.user = a.user; sa.Bt.pos = a.pos; sa.Bt.neg = a.neg;
       sa.Bt.B = batch; sa.Bt.idx_bytes = 4; sa.Bt.err_flag_dev = err_flag_dev;
+      if (meta->pos_meta_ids && meta->neg_meta_ids) {
+        sa.Bt.pos_meta = (void*)(meta->pos_meta_ids + (int64_t)st * batch * tables->M);
+        sa.Bt.neg_meta = (void*)(meta->neg_meta_ids + (int64_t)st * batch * tables->M);
+      }
       sa.inv_B = a.inv_B;
       sa.loss_sum = a.loss_sum;
       const bool meta_sorted = meta->sorted_keys[0] != nullptr;

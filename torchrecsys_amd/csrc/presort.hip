@@ -747,7 +747,9 @@ __global__ __launch_bounds__(TRS_BLOCK) void meta_refs_kernel(const int32_t* __r
                                                              const int32_t* __restrict__ neg, int64_t n_pos,
                                                              int64_t batch, const int32_t* __restrict__ item_meta, int M,
                                                              int m, int64_t n_cat, uint32_t* __restrict__ keys,
-                                                             RefPayload* __restrict__ vals, int32_t* err) {
+                                                             RefPayload* __restrict__ vals, int32_t* err,
+                                                             int32_t* __restrict__ pos_meta_out,
+                                                             int32_t* __restrict__ neg_meta_out) {
   const int64_t stride = (int64_t)gridDim.x * TRS_BLOCK;
   for (int64_t q = (int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x; q < n_pos; q += stride) {
     const uint32_t t = (uint32_t)(q % batch);
@@ -762,6 +764,10 @@ __global__ __launch_bounds__(TRS_BLOCK) void meta_refs_kernel(const int32_t* __r
     RefPayload v0 = {(t << 1)}, v1 = {(t << 1) | 1u};
     vals[2 * q] = v0;
     vals[2 * q + 1] = v1;
+    if (pos_meta_out) {  // (n_pos, M) id arrays for K1: contiguous reads instead of a lookup behind the item id
+      pos_meta_out[q * M + m] = (int32_t)kp;
+      neg_meta_out[q * M + m] = (int32_t)kn;
+    }
   }
 }
 
@@ -771,7 +777,8 @@ extern "C" int trs_epoch_presort_meta(const int32_t* pos_dev, const int32_t* neg
                                       const int32_t* item_meta_dev, int32_t M, int32_t m, int64_t n_cat,
                                       void* keys_dev, void* vals_dev, void* temp_dev, int64_t temp_bytes,
                                       int32_t* err_flag_dev, void** sorted_keys_out, void** sorted_vals_out,
-                                      void* stream) {
+                                      int32_t* pos_meta_out_dev, int32_t* neg_meta_out_dev, void* stream) {
+  TRS_REQUIRE((pos_meta_out_dev == nullptr) == (neg_meta_out_dev == nullptr), "trs_epoch_presort_meta: id outputs");
   TRS_REQUIRE(pos_dev && neg_dev && item_meta_dev && keys_dev && vals_dev && temp_dev && sorted_keys_out &&
                   sorted_vals_out, "trs_epoch_presort_meta: NULL argument");
   TRS_REQUIRE(n_batches > 0 && batch > 0 && M > 0 && m >= 0 && m < M && n_cat > 0, "trs_epoch_presort_meta: bad sizes");
@@ -782,7 +789,7 @@ extern "C" int trs_epoch_presort_meta(const int32_t* pos_dev, const int32_t* neg
   uint32_t* kin = (uint32_t*)keys_dev;
   RefPayload* vin = (RefPayload*)vals_dev;
   hipLaunchKernelGGL(meta_refs_kernel, dim3(trs_grid(n_pos, TRS_BLOCK)), dim3(TRS_BLOCK), 0, s, pos_dev, neg_dev, n_pos,
-                     batch, item_meta_dev, M, m, n_cat, kin, vin, err_flag_dev);
+                     batch, item_meta_dev, M, m, n_cat, kin, vin, err_flag_dev, pos_meta_out_dev, neg_meta_out_dev);
   TRS_CHECK_LAUNCH("meta_refs_kernel");
   size_t temp = (size_t)temp_bytes;
   hipError_t e = rocprim::segmented_radix_sort_pairs<ItemSortCfg>(

@@ -204,7 +204,8 @@ __global__ __launch_bounds__(TRS_BLOCK) void score_kernel(const ScoreArgs a) {
     row_load<VEC, G, K>(u, T.user, uid, D, lig);
     const float u_lin = T.user_lin ? T.user_lin[uid] : 0.f;
     float pi_lin, ni_lin = 0.f, lin_p, lin_n = 0.f;
-    constexpr bool TAB = MODE == 2;  // metadata ids from the item -> metadata table, indexed by the item id
+    // MODE 2: metadata ids from the item -> metadata table (indexed by the item id) unless the presort wrote them out
+    const bool TAB = MODE == 2 && a.Bt.pos_meta == nullptr;
     const float sp = pass_forward<NET, VEC, G, K>(
         T, u, u_lin, pid, iota ? (const void*)a.iota_item_meta : (TAB ? (const void*)a.item_meta_tab : a.Bt.pos_meta),
         (iota || TAB) ? 4 : ib, (iota || TAB) ? pid : tc, valid, lig, pi, Sp, pi_lin, lin_p, ok);
@@ -350,7 +351,8 @@ __global__ __launch_bounds__(TRS_BLOCK) void score_kernel(const ScoreArgs a) {
           for (int s = 0; s < 2; ++s) {
             const float gs = s ? gn : gp;
             const RowReg<VEC, K>& S = s ? Sn : Sp;
-            int64_t mid = a.item_meta_tab[(s ? nid : pid) * M + m];
+            int64_t mid = a.Bt.pos_meta ? trs_ld_idx(s ? a.Bt.neg_meta : a.Bt.pos_meta, ib, t * M + m)
+                                        : (int64_t)a.item_meta_tab[(s ? nid : pid) * M + m];
             if ((uint64_t)mid >= (uint64_t)T.n_meta[m]) mid = 0;
             if (NET == TRS_NET_FM) {
               RowReg<VEC, K> mr;

@@ -272,7 +272,7 @@ class SparseScorerTrainer:
         self._ps_cur = i
         return ps
 
-    def _meta_stage(self, batch, item_meta, meta_sorted=()):
+    def _meta_stage(self, batch, item_meta, meta_sorted=(), meta_ids=(None, None)):
         """_lib.TrsMetaStage of a metadata scorer: K1 looks the ids up in `item_meta` (n_items, M) int32."""
         from . import _lib
         if item_meta is None or item_meta.dtype != torch.int32:
@@ -293,6 +293,7 @@ class SparseScorerTrainer:
                 self.lin_scratch = torch.zeros(max(p.shape[0] for p in self.params[4:4 + self.M]), dtype=torch.float32,
                                                device=self.dev)
             ms.lin_scratch = ops.ptr(self.lin_scratch)
+            ms.pos_meta_ids, ms.neg_meta_ids = ops.ptr(meta_ids[0]), ops.ptr(meta_ids[1])
         return ms
 
     def fast_sorted_steps(self, ps, b_in_slice, batch, n_steps, loss_sums, item_meta=None):
@@ -301,7 +302,8 @@ class SparseScorerTrainer:
         if self.ustage is None:
             self.ustage = torch.empty_like(self.du)  # pre-update user rows staged by K1 for the item update
         opt = self._adaptive_rule(n_steps) if self.fast_kind != "sgd" else None
-        meta = self._meta_stage(batch, item_meta, ps.meta_step_args(b_in_slice)) if self.M > 0 else None
+        meta = (self._meta_stage(batch, item_meta, ps.meta_step_args(b_in_slice), ps.meta_id_args(b_in_slice))
+                if self.M > 0 else None)
         ops.train_steps_sgd(self.net.NET, self.net.tables(), None, None, 0, 0, 0, batch, n_steps, self.fast_lr, *ids,
                             self.gz, self.du, loss_sums, self.err, self.scratch, self._stamps(n_steps), evs, sk, sv,
                             ps.key_bytes, udup, self.ustage, usorted, opt, meta)

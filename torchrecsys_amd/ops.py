@@ -176,6 +176,9 @@ class EpochPresort:
         self.meta_keys = [torch.empty(ktot.value, dtype=torch.uint8, device=device) for _ in self.n_meta]
         self.meta_vals = [torch.empty(vtot.value, dtype=torch.uint8, device=device) for _ in self.n_meta]
         self.meta_sorted = []
+        M = len(self.n_meta)
+        self.pos_meta = torch.empty((n_pos, M), dtype=torch.int32, device=device) if M else None
+        self.neg_meta = torch.empty((n_pos, M), dtype=torch.int32, device=device) if M else None
 
     @staticmethod
     def bytes_needed(n_batches, batch, n_items, n_meta_cols=0):
@@ -213,13 +216,21 @@ class EpochPresort:
                                                      ptr(self.item_meta), len(self.n_meta), m, n_cat,
                                                      ptr(self.meta_keys[m]), ptr(self.meta_vals[m]), ptr(self.temp),
                                                      self.temp_bytes, ptr(err_flag), C.byref(mk), C.byref(mv),
-                                                     _stream()), "trs_epoch_presort_meta")
+                                                     ptr(self.pos_meta), ptr(self.neg_meta), _stream()),
+                  "trs_epoch_presort_meta")
             self.meta_sorted.append((mk.value, mv.value))
 
     def meta_step_args(self, b):
         """[(sorted keys address, sorted vals address)] of every metadata column for the steps starting at batch b."""
         o = b * self.batch
         return [(k + 2 * o * 4, v + 2 * o * 4) for k, v in self.meta_sorted]
+
+    def meta_id_args(self, b):
+        """(pos, neg) metadata id views (positions from batch b on, M) written by the presort, or (None, None)."""
+        if not self.meta_sorted:
+            return None, None
+        o = b * self.batch
+        return self.pos_meta[o:], self.neg_meta[o:]
 
     def step_args(self, b):
         """(user, pos, neg id views, sorted keys address, sorted vals address, user-duplicate flags view) for the steps
