@@ -704,15 +704,15 @@ def test_presorted_adaptive_rules_match_the_oracle(net, D, skew, kind):
 
 @pytest.mark.parametrize("net,D,M,skew", [("fm", 64, 1, False), ("fm", 16, 3, True), ("linear", 32, 1, True),
                                           ("linear", 8, 2, False), ("fm", 10, 1, True)])
-@pytest.mark.parametrize("meta_sorted", [False, True])
-def test_presorted_step_with_metadata_matches_oracle(net, D, M, skew, meta_sorted):
+@pytest.mark.parametrize("meta_sorted,B", [(False, 512), (True, 512), (True, 509), (True, 3)])
+def test_presorted_step_with_metadata_matches_oracle(net, D, M, skew, meta_sorted, B):
     """Metadata scorers on the presorted step (SGD): K1 = the scorer's staging mode (ids from the item -> metadata
     table, user update in place, FM: per-pass field sums staged), user / item rows through the sorted runs (FM: w +=
     sum(c*S) - sum(c)*w), metadata tables through the atomic scatter of the staged fields: 3 batches == oracle steps."""
     from torchrecsys_amd import _lib
     ops = _ops()
     rs = np.random.RandomState(D + M + skew)
-    NU, NI, B, nb, lr = 300, 57, 512, 3, 0.05
+    NU, NI, nb, lr = 300, 57, 3, 0.05
     p, _, _ = make_case(net, D, M, 8, NU=NU, NI=NI, seed=2)
     sizes = [p[f"metadata.{m}.weight"].shape[0] for m in range(M)]
     item_meta = np.stack([rs.randint(0, sizes[m], NI) for m in range(M)], axis=1).astype(np.int32)

@@ -626,6 +626,252 @@ __global__ __launch_bounds__(TRS_BLOCK) void user_update_kernel(const FastArgs a
   }
 }
 
+// K1 of a metadata scorer (MT = 1..4 columns, ids and metadata ids given by position): the arithmetic of
+// score_kernel<MODE 2> (score_kernels.h) with every gather of a triple — user, two items, 2*MT metadata rows and their
+// 1-wide terms — issued before anything is consumed (the generic scorer walks the columns in a loop and the two passes
+// one after the other: three dependent rounds of latency per triple).
+template <int MT>
+struct MetaIds {  // loads issued (raw) or clamped (final)
+  int32_t u, p, n, mp[MT], mn[MT];
+  uint8_t dup;
+  bool valid, ok;
+};
+template <int VEC, int K, int MT>
+struct MetaRows {
+  RowReg<VEC, K> u, pi, ni, rp[MT], rn[MT];
+  float ul, pl, nl, lp[MT], ln[MT];
+};
+
+template <int NET, int VEC, int G, int K, bool FULL, int MT>
+__global__ __launch_bounds__(TRS_BLOCK) void meta_stage_kernel(const ScoreArgs a) {
+  constexpr int N = K * VEC;
+  constexpr int TPW = TRS_WAVE / G;
+  const trs_tables& T = a.T;
+  const int D = T.D;
+  const int64_t B = a.Bt.B;
+  const int lane = threadIdx.x & 63;
+  const int lig = lane % G;
+  const int64_t wave = ((int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x) >> 6;
+  const int64_t nwave = ((int64_t)gridDim.x * TRS_BLOCK) >> 6;
+  const int64_t stride = nwave * TPW;
+  const int32_t* user = (const int32_t*)a.Bt.user;
+  const int32_t* pos = (const int32_t*)a.Bt.pos;
+  const int32_t* neg = (const int32_t*)a.Bt.neg;
+  const int32_t* pmeta = (const int32_t*)a.Bt.pos_meta;
+  const int32_t* nmeta = (const int32_t*)a.Bt.neg_meta;
+  float loss_acc = 0.f;
+
+  auto issue = [&](int64_t t) {  // only issues the id loads
+    MetaIds<MT> r;
+    r.valid = t < B;
+    const int64_t tc = r.valid ? t : B - 1;
+    r.u = user[tc]; r.p = pos[tc]; r.n = neg[tc];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      r.mp[m] = pmeta[tc * MT + m];
+      r.mn[m] = nmeta[tc * MT + m];
+    }
+    r.dup = a.udup_pos[tc];
+    r.ok = true;
+    return r;
+  };
+  auto finalize = [&](MetaIds<MT>& r) {  // consumes them: range checks, clamped ids
+    if ((uint32_t)r.u >= (uint64_t)T.n_users) { r.ok = false; r.u = 0; }
+    if ((uint32_t)r.p >= (uint64_t)T.n_items) { r.ok = false; r.p = 0; }
+    if ((uint32_t)r.n >= (uint64_t)T.n_items) { r.ok = false; r.n = 0; }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      if ((uint32_t)r.mp[m] >= (uint64_t)T.n_meta[m]) { r.ok = false; r.mp[m] = 0; }
+      if ((uint32_t)r.mn[m] >= (uint64_t)T.n_meta[m]) { r.ok = false; r.mn[m] = 0; }
+    }
+  };
+  auto gather = [&](MetaRows<VEC, K, MT>& r, const MetaIds<MT>& id) {  // every row of the triple, nothing consumed
+    row_load<VEC, G, K, FULL>(r.u, T.user, id.u, D, lig);
+    row_load<VEC, G, K, FULL>(r.pi, T.item, id.p, D, lig);
+    row_load<VEC, G, K, FULL>(r.ni, T.item, id.n, D, lig);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      row_load<VEC, G, K, FULL>(r.rp[m], T.meta[m], id.mp[m], D, lig);
+      row_load<VEC, G, K, FULL>(r.rn[m], T.meta[m], id.mn[m], D, lig);
+    }
+    r.ul = T.user_lin[id.u]; r.pl = T.item_lin[id.p]; r.nl = T.item_lin[id.n];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      r.lp[m] = NET == TRS_NET_FM ? T.meta_lin[m][id.mp[m]] : 0.f;
+      r.ln[m] = NET == TRS_NET_FM ? T.meta_lin[m][id.mn[m]] : 0.f;
+    }
+  };
+  auto reduce = [&](const MetaRows<VEC, K, MT>& r, const MetaIds<MT>& id, int64_t t) {
+    if (id.valid && !id.ok && lig == 0 && a.Bt.err_flag_dev) atomicOr(a.Bt.err_flag_dev, 1);
+    const bool live = id.valid && id.ok;
+    // the two passes, operation by operation as pass_forward (score_kernels.h) does them
+    RowReg<VEC, K> Sp, Sn;
+    float sqp[N], sqn[N], lin_p, lin_n;
+    if (NET == TRS_NET_FM) {
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        Sp.v[n] = r.u.v[n] + r.pi.v[n];
+        Sn.v[n] = r.u.v[n] + r.ni.v[n];
+        sqp[n] = r.u.v[n] * r.u.v[n] + r.pi.v[n] * r.pi.v[n];
+        sqn[n] = r.u.v[n] * r.u.v[n] + r.ni.v[n] * r.ni.v[n];
+      }
+      lin_p = r.ul + r.pl;
+      lin_n = r.ul + r.nl;
+    } else {
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        Sp.v[n] = r.pi.v[n];
+        Sn.v[n] = r.ni.v[n];
+      }
+      lin_p = lin_n = 0.f;
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        Sp.v[n] += r.rp[m].v[n];
+        Sn.v[n] += r.rn[m].v[n];
+        if (NET == TRS_NET_FM) {
+          sqp[n] += r.rp[m].v[n] * r.rp[m].v[n];
+          sqn[n] += r.rn[m].v[n] * r.rn[m].v[n];
+        }
+      }
+      if (NET == TRS_NET_FM) {
+        lin_p += r.lp[m];
+        lin_n += r.ln[m];
+      }
+    }
+    float pp = 0.f, pn = 0.f;
+    if (NET == TRS_NET_FM) {
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        pp += Sp.v[n] * Sp.v[n] - sqp[n];
+        pn += Sn.v[n] * Sn.v[n] - sqn[n];
+      }
+    } else {
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        pp += r.u.v[n] * Sp.v[n];
+        pn += r.u.v[n] * Sn.v[n];
+      }
+    }
+    pp = trs_group_sum<G>(pp);
+    pn = trs_group_sum<G>(pn);
+    const float sp = NET == TRS_NET_FM ? sigmoidf_(lin_p + 0.5f * pp) : (pp + r.ul) + r.pl;
+    const float sn = NET == TRS_NET_FM ? sigmoidf_(lin_n + 0.5f * pn) : (pn + r.ul) + r.nl;
+    const float h = sn - sp + 1.0f;
+    const float act = (live && h >= 0.f) ? 1.f : 0.f;
+    float gp = -act * a.inv_B, gn = act * a.inv_B;
+    if (live && lig == 0) loss_acc += fmaxf(h, 0.f);
+    if (NET == TRS_NET_FM) {
+      gp = gp * ((1.0f - sp) * sp);
+      gn = gn * ((1.0f - sn) * sn);
+    }
+    if (id.valid) {
+      const int64_t BD = B * (int64_t)D;
+      RowReg<VEC, K> g;
+      if (NET == TRS_NET_FM) {
+        row_store<VEC, G, K>(Sp, a.xstage + t * (int64_t)D, D, lig);
+        row_store<VEC, G, K>(Sn, a.xstage + BD + t * (int64_t)D, D, lig);
+#pragma unroll
+        for (int n = 0; n < N; ++n) g.v[n] = gp * (Sp.v[n] - r.u.v[n]) + gn * (Sn.v[n] - r.u.v[n]);
+      } else {
+        row_store<VEC, G, K>(r.u, a.xstage + t * (int64_t)D, D, lig);
+#pragma unroll
+        for (int n = 0; n < N; ++n) g.v[n] = gp * Sp.v[n] + gn * Sn.v[n];
+      }
+      if (id.dup || !live) {
+        row_store<VEC, G, K>(g, a.du + t * (int64_t)D, D, lig);
+      } else {
+        RowReg<VEC, K> un;
+#pragma unroll
+        for (int n = 0; n < N; ++n) un.v[n] = r.u.v[n] + (-a.lr) * g.v[n];
+        row_store<VEC, G, K>(un, T.user + id.u * (int64_t)D, D, lig);
+        if (lig == 0) T.user_lin[id.u] = r.ul + (-a.lr) * (gp + gn);
+      }
+      if (lig == 0) {
+        a.gz[t] = gp;
+        a.gz[B + t] = gn;
+      }
+    }
+  };
+
+  // the software pipeline of fwd_stage_kernel: ids two triples ahead, rows one ahead, two register sets by parity
+  int64_t t = wave * TPW + lane / G;
+  const int64_t t_first = wave * TPW;
+  const int64_t niter = t_first < B ? (B - t_first + stride - 1) / stride : 0;
+  const int64_t niter2 = (niter + 1) & ~(int64_t)1;
+  MetaIds<MT> wE = issue(t), wO = issue(t + stride), idE, idO;
+  MetaRows<VEC, K, MT> rE, rO;
+  idE = wE;
+  finalize(idE);
+  gather(rE, idE);
+  for (int64_t it = 0; it < niter2; it += 2) {
+    wE = issue(t + 2 * stride);
+    idO = wO;
+    finalize(idO);
+    gather(rO, idO);
+    reduce(rE, idE, t);
+
+    wO = issue(t + 3 * stride);
+    idE = wE;
+    finalize(idE);
+    gather(rE, idE);
+    reduce(rO, idO, t + stride);
+    t += 2 * stride;
+  }
+  __shared__ float s_loss[TRS_BLOCK / TRS_WAVE];
+  const float wl = trs_wave_sum(loss_acc);
+  if (lane == 0) s_loss[threadIdx.x >> 6] = wl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float L = 0.f;
+#pragma unroll
+    for (int w = 0; w < TRS_BLOCK / TRS_WAVE; ++w) L += s_loss[w];
+    if (L != 0.f && a.loss_sum) atomicAdd(a.loss_sum, L);
+  }
+}
+
+template <int NET, int MT>
+static int launch_meta_stage_mt(const ScoreArgs& a, hipStream_t s) {
+  RowCfg c;
+  if (!pick_row_cfg(a.T.D, c)) {
+    trs_set_error("unsupported n_factors D=%d", a.T.D);
+    return TRS_E_ARG;
+  }
+  const int tpw = TRS_WAVE / c.g;
+  int64_t iters = (a.Bt.B + 512 * 4 * (int64_t)tpw - 1) / (512 * 4 * (int64_t)tpw);  // as launch_fwd_stage
+  iters = iters < 2 ? 2 : (iters > 8 ? 8 : iters);
+  int64_t grid = ((a.Bt.B + tpw - 1) / tpw + 4 * iters - 1) / (4 * iters);
+  grid = grid < 1 ? 1 : (grid > 4096 ? 4096 : grid);
+  const dim3 gr((unsigned)grid), bl(TRS_BLOCK);
+#define TRS_CASE(V, GG, KK)                                                                                   \
+  if (c.vec == V && c.g == GG && c.k == KK) {                                                                 \
+    if (V * GG * KK == a.T.D) hipLaunchKernelGGL((meta_stage_kernel<NET, V, GG, KK, true, MT>), gr, bl, 0, s, a); \
+    else hipLaunchKernelGGL((meta_stage_kernel<NET, V, GG, KK, false, MT>), gr, bl, 0, s, a);                  \
+    TRS_CHECK_LAUNCH("meta_stage_kernel");                                                                    \
+    return TRS_OK;                                                                                            \
+  }
+  TRS_CASE(4, 8, 1)
+  TRS_CASE(4, 16, 1)
+  TRS_CASE(4, 32, 1)
+  TRS_CASE(4, 64, 1)
+#undef TRS_CASE
+  return 1;  // shape not instantiated: the caller falls back to the generic scorer's staging mode
+}
+
+// > 0: not handled here (caller uses score_kernel<MODE 2>)
+template <int NET>
+static int launch_meta_stage(const ScoreArgs& a, hipStream_t s) {
+  if (!a.Bt.pos_meta || !a.Bt.neg_meta || a.grad_rows) return 1;
+  switch (a.T.M) {
+    case 1: return launch_meta_stage_mt<NET, 1>(a, s);
+    case 2: return launch_meta_stage_mt<NET, 2>(a, s);
+    case 3: return launch_meta_stage_mt<NET, 3>(a, s);
+    default: return 1;
+  }
+}
+
 template <int NET>
 static int launch_fwd_stage(const FastArgs& a, hipStream_t s) {
   RowCfg c;
@@ -924,7 +1170,9 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
       sa.udup_pos = a.udup_pos;
       sa.lr = a.lr;
       sa.meta_ids_out = meta->meta_ids;
-      rc = net == TRS_NET_FM ? launch_score<TRS_NET_FM, 2>(sa, s) : launch_score<TRS_NET_LINEAR, 2>(sa, s);
+      rc = net == TRS_NET_FM ? launch_meta_stage<TRS_NET_FM>(sa, s) : launch_meta_stage<TRS_NET_LINEAR>(sa, s);
+      if (rc > 0)  // more than 3 columns / odd D / no id arrays: the generic scorer's staging mode
+        rc = net == TRS_NET_FM ? launch_score<TRS_NET_FM, 2>(sa, s) : launch_score<TRS_NET_LINEAR, 2>(sa, s);
     } else {
       rc = net == TRS_NET_FM ? launch_fwd_stage<TRS_NET_FM>(a, s) : launch_fwd_stage<TRS_NET_LINEAR>(a, s);
     }
