@@ -630,6 +630,111 @@ __global__ __launch_bounds__(TRS_BLOCK) void user_update_kernel(const FastArgs a
 // score_kernel<MODE 2> (score_kernels.h) with every gather of a triple — user, two items, 2*MT metadata rows and their
 // 1-wide terms — issued before anything is consumed (the generic scorer walks the columns in a loop and the two passes
 // one after the other: three dependent rounds of latency per triple).
+// The north-star pass by itself — fused positive + negative embedding gather and Linear / FM pairwise score, no metadata,
+// int32 ids — in the software pipeline of fwd_stage_kernel (ids two triples ahead, the three row gathers of the next
+// triple in flight while the current one is reduced).  Same arithmetic as score_kernel<MODE 0>; used by
+// trs_score_forward (evaluate(), forward_pair) when the shape allows.
+template <int NET, int VEC, int G, int K, bool FULL>
+__global__ __launch_bounds__(TRS_BLOCK) void pair_scores_kernel(const ScoreArgs a) {
+  constexpr int N = K * VEC;
+  constexpr int TPW = TRS_WAVE / G;
+  const trs_tables& T = a.T;
+  const int D = T.D;
+  const int64_t B = a.Bt.B;
+  const int lane = threadIdx.x & 63;
+  const int lig = lane % G;
+  const int64_t wave = ((int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x) >> 6;
+  const int64_t nwave = ((int64_t)gridDim.x * TRS_BLOCK) >> 6;
+  const int64_t stride = nwave * TPW;
+  const int32_t* user = (const int32_t*)a.Bt.user;
+  const int32_t* pos = (const int32_t*)a.Bt.pos;
+  const int32_t* neg = (const int32_t*)a.Bt.neg;
+  struct Ids {
+    int32_t u, p, n;
+    bool valid, ok;
+  };
+  struct Rows {
+    RowReg<VEC, K> u, pi, ni;
+    float ul, pl, nl;
+  };
+  auto issue = [&](int64_t t) {
+    Ids r;
+    r.valid = t < B;
+    const int64_t tc = r.valid ? t : B - 1;
+    r.u = user[tc]; r.p = pos[tc]; r.n = neg[tc];
+    r.ok = true;
+    return r;
+  };
+  auto finalize = [&](Ids& r) {
+    if ((uint32_t)r.u >= (uint64_t)T.n_users) { r.ok = false; r.u = 0; }
+    if ((uint32_t)r.p >= (uint64_t)T.n_items) { r.ok = false; r.p = 0; }
+    if ((uint32_t)r.n >= (uint64_t)T.n_items) { r.ok = false; r.n = 0; }
+  };
+  auto gather = [&](Rows& r, const Ids& id) {
+    row_load<VEC, G, K, FULL>(r.u, T.user, id.u, D, lig);
+    row_load<VEC, G, K, FULL>(r.pi, T.item, id.p, D, lig);
+    row_load<VEC, G, K, FULL>(r.ni, T.item, id.n, D, lig);
+    r.ul = T.user_lin[id.u]; r.pl = T.item_lin[id.p]; r.nl = T.item_lin[id.n];
+  };
+  auto reduce = [&](const Rows& r, const Ids& id, int64_t t) {
+    if (id.valid && !id.ok && lig == 0 && a.Bt.err_flag_dev) atomicOr(a.Bt.err_flag_dev, 1);
+    float pp = 0.f, pn = 0.f;
+    if (NET == TRS_NET_FM) {  // (u+i)^2 - (u^2 + i^2) per element: the reference's power_of_sum - sum_of_power
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        const float sp_ = r.u.v[n] + r.pi.v[n], sn_ = r.u.v[n] + r.ni.v[n];
+        const float uu = r.u.v[n] * r.u.v[n];
+        pp += sp_ * sp_ - (uu + r.pi.v[n] * r.pi.v[n]);
+        pn += sn_ * sn_ - (uu + r.ni.v[n] * r.ni.v[n]);
+      }
+    } else {
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        pp += r.u.v[n] * r.pi.v[n];
+        pn += r.u.v[n] * r.ni.v[n];
+      }
+    }
+    pp = trs_group_sum<G>(pp);
+    pn = trs_group_sum<G>(pn);
+    float sp, sn;
+    if (NET == TRS_NET_FM) {
+      sp = sigmoidf_((r.ul + r.pl) + 0.5f * pp);
+      sn = sigmoidf_((r.ul + r.nl) + 0.5f * pn);
+    } else {
+      sp = (pp + r.ul) + r.pl;
+      sn = (pn + r.ul) + r.nl;
+    }
+    if (id.valid && lig == 0) {
+      const bool live = id.ok;
+      a.pos_score[t] = live ? sp : 0.f;
+      a.neg_score[t] = live ? sn : 0.f;
+    }
+  };
+  int64_t t = wave * TPW + lane / G;
+  const int64_t t_first = wave * TPW;
+  const int64_t niter = t_first < B ? (B - t_first + stride - 1) / stride : 0;
+  const int64_t niter2 = (niter + 1) & ~(int64_t)1;
+  Ids wE = issue(t), wO = issue(t + stride), idE, idO;
+  Rows rE, rO;
+  idE = wE;
+  finalize(idE);
+  gather(rE, idE);
+  for (int64_t it = 0; it < niter2; it += 2) {
+    wE = issue(t + 2 * stride);
+    idO = wO;
+    finalize(idO);
+    gather(rO, idO);
+    reduce(rE, idE, t);
+
+    wO = issue(t + 3 * stride);
+    idE = wE;
+    finalize(idE);
+    gather(rE, idE);
+    reduce(rO, idO, t + stride);
+    t += 2 * stride;
+  }
+}
+
 template <int MT>
 struct MetaIds {  // loads issued (raw) or clamped (final)
   int32_t u, p, n, mp[MT], mn[MT];
@@ -1024,6 +1129,40 @@ int trs_launch_sgd_fields(int net, const trs_tables* tables, const trs_batch* ba
 int trs_launch_sorted_user_dup_update(const trs_tables* tables, const void* ukeys_step, const void* uvals_step,
                                       int key_bytes, int64_t batch, int64_t q0, const float* du, const float* gz,
                                       float lr, hipStream_t s);
+
+// > 0: shape not handled (caller uses score_kernel<MODE 0>)
+int trs_launch_pair_scores(int net, const ScoreArgs* ap, hipStream_t s) {
+  const ScoreArgs& a = *ap;
+  if (a.T.M != 0 || a.Bt.idx_bytes != 4 || !a.Bt.neg || !a.neg_score || a.iota_user >= 0 || !a.T.user_lin ||
+      !a.T.item_lin || a.Bt.B < 1)
+    return 1;
+  RowCfg c;
+  if (!pick_row_cfg(a.T.D, c) || c.vec != 4 || c.k != 1 || c.g < 8) return 1;
+  const int tpw = TRS_WAVE / c.g;
+  int64_t iters = (a.Bt.B + 512 * 4 * (int64_t)tpw - 1) / (512 * 4 * (int64_t)tpw);
+  iters = iters < 2 ? 2 : (iters > 8 ? 8 : iters);
+  int64_t grid = ((a.Bt.B + tpw - 1) / tpw + 4 * iters - 1) / (4 * iters);
+  grid = grid < 1 ? 1 : (grid > 4096 ? 4096 : grid);
+  const dim3 gr((unsigned)grid), bl(TRS_BLOCK);
+#define TRS_PS(NETV, V, GG)                                                                                    \
+  {                                                                                                            \
+    if (V * GG == a.T.D) hipLaunchKernelGGL((pair_scores_kernel<NETV, V, GG, 1, true>), gr, bl, 0, s, a);      \
+    else hipLaunchKernelGGL((pair_scores_kernel<NETV, V, GG, 1, false>), gr, bl, 0, s, a);                     \
+  }
+#define TRS_CASE(GG)                                                          \
+  if (c.g == GG) {                                                            \
+    if (net == TRS_NET_FM) TRS_PS(TRS_NET_FM, 4, GG) else TRS_PS(TRS_NET_LINEAR, 4, GG) \
+    TRS_CHECK_LAUNCH("pair_scores_kernel");                                   \
+    return TRS_OK;                                                            \
+  }
+  TRS_CASE(8)
+  TRS_CASE(16)
+  TRS_CASE(32)
+  TRS_CASE(64)
+#undef TRS_CASE
+#undef TRS_PS
+  return 1;
+}
 
 extern "C" int64_t trs_train_scratch_bytes(int64_t n_users, int64_t n_items, int64_t batch, int32_t D) {
   if (n_users <= 0 || n_items <= 0 || batch <= 0 || D <= 0) return 0;

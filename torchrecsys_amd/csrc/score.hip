@@ -37,6 +37,8 @@ static int launch_net(int net, const ScoreArgs& a, hipStream_t s) {
   return launch_score<TRS_NET_LINEAR, MODE>(a, s);
 }
 
+int trs_launch_pair_scores(int net, const trs::ScoreArgs* a, hipStream_t s);  // fast_step.hip
+
 extern "C" int trs_score_forward(int net, const trs_tables* tables, const trs_batch* batch, float* pos_score_dev,
                                  float* neg_score_dev, void* stream) {
   int rc = check_tables(net, tables, "trs_score_forward");
@@ -52,6 +54,10 @@ extern "C" int trs_score_forward(int net, const trs_tables* tables, const trs_ba
   a.pos_score = pos_score_dev;
   a.neg_score = neg_score_dev;
   a.iota_user = -1;
+  if (batch->B > 0) {  // no metadata, int32 ids, both passes: the software-pipelined form (fast_step.hip)
+    rc = trs_launch_pair_scores(net, &a, (hipStream_t)stream);
+    if (rc <= 0) return rc;
+  }
   return launch_net<0>(net, a, (hipStream_t)stream);
 }
 
