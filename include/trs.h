@@ -174,8 +174,15 @@ typedef struct trs_opt {
   int32_t* cut_rows;   /* (cut_capacity) rows with a cut run in the current step */
   int32_t* cut_count;  /* [2] zero-initialised once; the steps alternate between the two counters */
   int32_t cut_capacity; /* >= 2*batch/64 + the number of rows with more than 64 references (2*batch is always enough) */
+  /* Metadata scorers (tables->M > 0, trs_meta_stage with sorted columns): the same state per metadata column m < M.
+   * meta_lin_* / meta_gacc_lin belong to the 1-wide metadata tables of FM; a Linear scorer has none and passes scratch
+   * arrays of n_meta[m] floats.  meta_cut_rows[m]: cut_capacity entries; meta_cut_count[m]: [2], zeroed once. */
+  float *meta_s1[TRS_MAX_META], *meta_s2[TRS_MAX_META], *meta_lin_s1[TRS_MAX_META], *meta_lin_s2[TRS_MAX_META];
+  float *meta_gacc[TRS_MAX_META], *meta_gacc_lin[TRS_MAX_META];
+  int32_t *meta_cut_rows[TRS_MAX_META], *meta_cut_count[TRS_MAX_META];
 } trs_opt;
-/* Metadata scorers (tables->M > 0) on the presorted step, plain SGD: K1 is the generic scorer in a staging mode that
+/* Metadata scorers (tables->M > 0) on the presorted step (plain SGD; the adaptive rules of trs_opt with sorted columns,
+ * M <= 3 and D in {32, 64, 128, 256}): K1 is the generic scorer in a staging mode that
  * looks the metadata ids up in item_meta_tab, applies the user update in place, stages the rows the sorted item update
  * multiplies (FM: the per-pass field sums, Linear: the user row) and the metadata fields' gradients; user and item rows
  * then go through the sorted runs as without metadata, the (small, heavily shared) metadata tables through an atomic

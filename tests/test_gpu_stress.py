@@ -171,3 +171,58 @@ def test_fit_with_metadata_presorted_path_equals_generic_path(net_type, n_meta_c
     assert out["presorted"][1] == out["generic"][1]
     for k, v in out["generic"][0].items():
         assert rel_err(out["presorted"][0][k], v) < 1e-5, k
+
+
+@pytest.mark.parametrize("net_type,n_meta_cols", [("fm", 1), ("linear", 2), ("fm", 3)])
+@pytest.mark.parametrize("oname", ["adam", "adagrad"])
+def test_fit_with_metadata_and_adaptive_rule_equals_generic_path(net_type, n_meta_cols, oname, monkeypatch):
+    """fit() of a metadata scorer with Adam (lazy / SparseAdam semantics on the tables) or Adagrad: the presorted step
+    with the rule fused in trains the same model as the generic staged path (TRS_META_FAST=0): printed losses, weights,
+    optimiser state under torch's key names."""
+    import contextlib
+    import io
+    import re
+    import pandas as pd
+    from torchrecsys_amd.model import TorchRecSys
+    rs = np.random.RandomState(12)
+    n, n_u, n_i = 4000, 120, 37
+    items = np.concatenate([np.arange(n_i), rs.randint(0, n_i, n - n_i)])
+    df = pd.DataFrame({"user": np.concatenate([np.arange(n_u), rs.randint(0, n_u, n - n_u)]), "item": items})
+    cols = []
+    for c in range(n_meta_cols):
+        cat_of_item = rs.randint(0, 5 + c, n_i)
+        cat_of_item[:5 + c] = np.arange(5 + c)
+        df[f"cat{c}"] = cat_of_item[items]
+        cols.append(f"cat{c}")
+    out = {}
+    from torchrecsys_amd.engine import SparseScorerTrainer
+    calls, inner = [0], SparseScorerTrainer.fast_sorted_steps
+
+    def counted(self, *a, **k):
+        calls[0] += 1
+        return inner(self, *a, **k)
+
+    monkeypatch.setattr(SparseScorerTrainer, "fast_sorted_steps", counted)
+    for path in ("presorted", "generic"):
+        monkeypatch.setenv("TRS_META_FAST", "1" if path == "presorted" else "0")
+        torch.manual_seed(3)
+        np.random.seed(3)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            model = TorchRecSys(dataset=df, user_id_col="user", item_id_col="item", metadata_id_col=cols, n_factors=32,
+                                net_type=net_type, dynamic_neg_sampling=True)
+            opt = (torch.optim.Adam(model.parameters(), lr=0.01) if oname == "adam"
+                   else torch.optim.Adagrad(model.parameters(), lr=0.05))
+            model.fit(optimizer=opt, epochs=2, batch_size=128)
+        assert (calls[0] > 0) == (path == "presorted")  # the C step loop ran / did not run
+        calls[0] = 0
+        st = opt.state[model.net.metadata[0].weight]
+        losses = [float(x) for x in re.findall(r"Training Loss: ([0-9.]+)", buf.getvalue())]
+        out[path] = ({k: v.cpu().numpy() for k, v in model.state_dict().items()}, losses,
+                     (st["exp_avg_sq"] if oname == "adam" else st["sum"]).cpu().numpy(), int(st["step"]))
+    assert out["presorted"][1] == pytest.approx(out["generic"][1], abs=2.01e-4) and len(out["generic"][1]) == 2
+    assert out["presorted"][3] == out["generic"][3] == 2 * -(-int(n * 0.8) // 128)
+    for k, v in out["generic"][0].items():
+        d = np.abs(out["presorted"][0][k] - v).max(axis=1)
+        assert (d <= 1e-3 * np.abs(v).max()).mean() >= 0.95, k  # bulk (see test_presorted_adaptive_rules_match_the_oracle)
+    assert rel_err(out["presorted"][2], out["generic"][2]) < 1e-2

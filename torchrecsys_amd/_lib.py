@@ -62,6 +62,10 @@ class TrsOpt(C.Structure):
         ("item_lin_s2", C.c_void_p),
         ("gacc", C.c_void_p), ("gacc_lin", C.c_void_p), ("cut_rows", C.c_void_p), ("cut_count", C.c_void_p),
         ("cut_capacity", C.c_int32),
+        ("meta_s1", C.c_void_p * TRS_MAX_META), ("meta_s2", C.c_void_p * TRS_MAX_META),
+        ("meta_lin_s1", C.c_void_p * TRS_MAX_META), ("meta_lin_s2", C.c_void_p * TRS_MAX_META),
+        ("meta_gacc", C.c_void_p * TRS_MAX_META), ("meta_gacc_lin", C.c_void_p * TRS_MAX_META),
+        ("meta_cut_rows", C.c_void_p * TRS_MAX_META), ("meta_cut_count", C.c_void_p * TRS_MAX_META),
     ]
 
 

@@ -745,9 +745,11 @@ template <int VEC, int K, int MT>
 struct MetaRows {
   RowReg<VEC, K> u, pi, ni, rp[MT], rn[MT];
   float ul, pl, nl, lp[MT], ln[MT];
+  RowReg<VEC, K> us1, us2;  // adaptive rules: the user row's optimiser state, as in fwd_stage_kernel
+  float uls1, uls2;
 };
 
-template <int NET, int VEC, int G, int K, bool FULL, int MT>
+template <int NET, int VEC, int G, int K, bool FULL, int MT, int OPT = OPT_SGD>
 __global__ __launch_bounds__(TRS_BLOCK) void meta_stage_kernel(const ScoreArgs a) {
   constexpr int N = K * VEC;
   constexpr int TPW = TRS_WAVE / G;
@@ -805,8 +807,16 @@ __global__ __launch_bounds__(TRS_BLOCK) void meta_stage_kernel(const ScoreArgs a
       r.lp[m] = NET == TRS_NET_FM ? T.meta_lin[m][id.mp[m]] : 0.f;
       r.ln[m] = NET == TRS_NET_FM ? T.meta_lin[m][id.mn[m]] : 0.f;
     }
+    if (OPT != OPT_SGD) {
+      row_load<VEC, G, K, FULL>(r.us1, a.o.user_s1, id.u, D, lig);
+      r.uls1 = a.o.user_lin_s1[id.u];
+      if (OPT == OPT_ADAM) {
+        row_load<VEC, G, K, FULL>(r.us2, a.o.user_s2, id.u, D, lig);
+        r.uls2 = a.o.user_lin_s2[id.u];
+      }
+    }
   };
-  auto reduce = [&](const MetaRows<VEC, K, MT>& r, const MetaIds<MT>& id, int64_t t) {
+  auto reduce = [&](MetaRows<VEC, K, MT>& r, const MetaIds<MT>& id, int64_t t) {
     if (id.valid && !id.ok && lig == 0 && a.Bt.err_flag_dev) atomicOr(a.Bt.err_flag_dev, 1);
     const bool live = id.valid && id.ok;
     // the two passes, operation by operation as pass_forward (score_kernels.h) does them
@@ -889,10 +899,23 @@ __global__ __launch_bounds__(TRS_BLOCK) void meta_stage_kernel(const ScoreArgs a
         row_store<VEC, G, K>(g, a.du + t * (int64_t)D, D, lig);
       } else {
         RowReg<VEC, K> un;
+        if (OPT == OPT_SGD) {
 #pragma unroll
-        for (int n = 0; n < N; ++n) un.v[n] = r.u.v[n] + (-a.lr) * g.v[n];
-        row_store<VEC, G, K>(un, T.user + id.u * (int64_t)D, D, lig);
-        if (lig == 0) T.user_lin[id.u] = r.ul + (-a.lr) * (gp + gn);
+          for (int n = 0; n < N; ++n) un.v[n] = r.u.v[n] + (-a.lr) * g.v[n];
+          row_store<VEC, G, K>(un, T.user + id.u * (int64_t)D, D, lig);
+          if (lig == 0) T.user_lin[id.u] = r.ul + (-a.lr) * (gp + gn);
+        } else {
+#pragma unroll
+          for (int n = 0; n < N; ++n) un.v[n] = opt_apply<OPT>(r.u.v[n], g.v[n], r.us1.v[n], r.us2.v[n], a.o);
+          row_store<VEC, G, K>(un, T.user + id.u * (int64_t)D, D, lig);
+          row_store<VEC, G, K>(r.us1, a.o.user_s1 + id.u * (int64_t)D, D, lig);
+          if (OPT == OPT_ADAM) row_store<VEC, G, K>(r.us2, a.o.user_s2 + id.u * (int64_t)D, D, lig);
+          if (lig == 0) {
+            T.user_lin[id.u] = opt_apply<OPT>(r.ul, gp + gn, r.uls1, r.uls2, a.o);
+            a.o.user_lin_s1[id.u] = r.uls1;
+            if (OPT == OPT_ADAM) a.o.user_lin_s2[id.u] = r.uls2;
+          }
+        }
       }
       if (lig == 0) {
         a.gz[t] = gp;
@@ -952,8 +975,16 @@ static int launch_meta_stage_mt(const ScoreArgs& a, hipStream_t s) {
   const dim3 gr((unsigned)grid), bl(TRS_BLOCK);
 #define TRS_CASE(V, GG, KK)                                                                                   \
   if (c.vec == V && c.g == GG && c.k == KK) {                                                                 \
-    if (V * GG * KK == a.T.D) hipLaunchKernelGGL((meta_stage_kernel<NET, V, GG, KK, true, MT>), gr, bl, 0, s, a); \
-    else hipLaunchKernelGGL((meta_stage_kernel<NET, V, GG, KK, false, MT>), gr, bl, 0, s, a);                  \
+    if (a.o.kind != OPT_SGD) { /* adaptive rules: whole-row shapes only */                                    \
+      if (V * GG * KK != a.T.D) return 1;                                                                     \
+      if (a.o.kind == OPT_ADAM)                                                                               \
+        hipLaunchKernelGGL((meta_stage_kernel<NET, V, GG, KK, true, MT, OPT_ADAM>), gr, bl, 0, s, a);          \
+      else                                                                                                    \
+        hipLaunchKernelGGL((meta_stage_kernel<NET, V, GG, KK, true, MT, OPT_ADAGRAD>), gr, bl, 0, s, a);       \
+    } else if (V * GG * KK == a.T.D)                                                                          \
+      hipLaunchKernelGGL((meta_stage_kernel<NET, V, GG, KK, true, MT>), gr, bl, 0, s, a);                      \
+    else                                                                                                      \
+      hipLaunchKernelGGL((meta_stage_kernel<NET, V, GG, KK, false, MT>), gr, bl, 0, s, a);                     \
     TRS_CHECK_LAUNCH("meta_stage_kernel");                                                                    \
     return TRS_OK;                                                                                            \
   }
@@ -1122,7 +1153,7 @@ int trs_launch_sorted_updates_fused(const trs_tables* tables, const void* keys_s
                                     const OptArgs* opt, int parity, int64_t xpass, int fmsub, hipStream_t s);
 int trs_launch_sorted_meta_update(const trs_tables* tables, int m, float* lin_or_scratch, const void* keys_step,
                                   const void* vals_step, int64_t batch, const float* gz, float lr, const float* xstage,
-                                  int64_t xpass, int fmsub, hipStream_t s);
+                                  int64_t xpass, int fmsub, const OptArgs* opt, int parity, hipStream_t s);
 // rows.hip
 int trs_launch_sgd_fields(int net, const trs_tables* tables, const trs_batch* batch, const float* grad_rows_dev,
                           const float* grad_lin_dev, float lr, int f_begin, void* stream);
@@ -1200,9 +1231,21 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
   }
   const bool adaptive = opt && opt->kind != TRS_OPT_SGD;
   if (meta) {
-    TRS_REQUIRE(sorted_keys_dev && user_dup_flags_dev && key_bytes == 4 && ukey_bytes == 4 && !adaptive,
-                "trs_train_steps_sgd: metadata scorers run on the presorted step with plain SGD only");
+    TRS_REQUIRE(sorted_keys_dev && user_dup_flags_dev && key_bytes == 4 && ukey_bytes == 4,
+                "trs_train_steps_sgd: metadata scorers run on the presorted step");
     const bool meta_sorted = meta->sorted_keys[0] != nullptr;
+    if (adaptive) {
+      const int D = tables->D;
+      TRS_REQUIRE(meta_sorted && meta->pos_meta_ids && meta->neg_meta_ids && tables->M <= 3 &&
+                      (D == 32 || D == 64 || D == 128 || D == 256),
+                  "trs_train_steps_sgd: adaptive rules on metadata scorers need sorted columns with their id arrays, "
+                  "M <= 3 and D in {32, 64, 128, 256}");
+      for (int m = 0; m < tables->M; ++m)
+        TRS_REQUIRE(opt->meta_s1[m] && opt->meta_lin_s1[m] && opt->meta_gacc[m] && opt->meta_gacc_lin[m] &&
+                        opt->meta_cut_rows[m] && opt->meta_cut_count[m] &&
+                        (opt->kind != TRS_OPT_SPARSE_ADAM || (opt->meta_s2[m] && opt->meta_lin_s2[m])),
+                    "trs_train_steps_sgd: optimiser state of metadata column %d is NULL", m);
+    }
     TRS_REQUIRE(meta->item_meta_tab && meta->xstage, "trs_train_steps_sgd: metadata staging buffer is NULL");
     TRS_REQUIRE(meta_sorted || (meta->grad_rows && meta->grad_lin && meta->meta_ids),
                 "trs_train_steps_sgd: metadata gradient staging is NULL");
@@ -1309,7 +1352,12 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
       sa.udup_pos = a.udup_pos;
       sa.lr = a.lr;
       sa.meta_ids_out = meta->meta_ids;
+      if (adaptive) sa.o = a.o;
       rc = net == TRS_NET_FM ? launch_meta_stage<TRS_NET_FM>(sa, s) : launch_meta_stage<TRS_NET_LINEAR>(sa, s);
+      if (rc > 0 && adaptive) {
+        trs_set_error("trs_train_steps_sgd: no adaptive metadata kernel for this shape");
+        return TRS_E_ARG;
+      }
       if (rc > 0)  // more than 3 columns / odd D / no id arrays: the generic scorer's staging mode
         rc = net == TRS_NET_FM ? launch_score<TRS_NET_FM, 2>(sa, s) : launch_score<TRS_NET_LINEAR, 2>(sa, s);
     } else {
@@ -1333,9 +1381,16 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
           for (int m = 0; m < tables->M; ++m) {
             const char* mk = (const char*)meta->sorted_keys[m] + (int64_t)st * 2 * batch * 4;
             const char* mv = (const char*)meta->sorted_vals[m] + (int64_t)st * 2 * batch * 4;
+            OptArgs mo = a.o;  // this column's state, accumulators and cut-run list in the item slots
+            if (adaptive) {
+              mo.item_s1 = opt->meta_s1[m]; mo.item_s2 = opt->meta_s2[m];
+              mo.item_lin_s1 = opt->meta_lin_s1[m]; mo.item_lin_s2 = opt->meta_lin_s2[m];
+              mo.gacc = opt->meta_gacc[m]; mo.gacc_lin = opt->meta_gacc_lin[m];
+              mo.cut_rows = opt->meta_cut_rows[m]; mo.cut_count = opt->meta_cut_count[m];
+            }
             rc = trs_launch_sorted_meta_update(tables, m, net == TRS_NET_FM ? tables->meta_lin[m] : meta->lin_scratch, mk,
                                                mv, batch, a.gz, a.lr, meta->xstage, fm_meta ? batch : 0, fm_meta ? 1 : 0,
-                                               s);
+                                               adaptive ? &mo : nullptr, (int)(a.stamp & 1u), s);
             if (rc) return rc;
           }
         } else if (meta) {  // the metadata fields staged by K1: atomic scatter into their (small) tables

@@ -333,8 +333,11 @@ __device__ __forceinline__ void sorted_item_update_staged_body(const SortedArgs&
             row_store<VEC, G, K>(w[s], irow, D, lig);
             if (lig == 0) tab_lin[row[s]] = wl[s] + lin;
           } else {  // the run is the row's whole gradient: apply the rule once, state rows beside the weights
+            const float sub = a.fmsub ? lin : 0.f;  // FM with metadata: G = sum(c*S) - sum(c)*w
 #pragma unroll
-            for (int q = 0; q < N; ++q) w[s].v[q] = opt_apply<OPT>(w[s].v[q], acc.v[q], s1[s].v[q], s2[s].v[q], a.o);
+            for (int q = 0; q < N; ++q)
+              w[s].v[q] = opt_apply<OPT>(w[s].v[q], a.fmsub ? acc.v[q] - sub * w[s].v[q] : acc.v[q], s1[s].v[q], s2[s].v[q],
+                                         a.o);
             row_store<VEC, G, K>(w[s], irow, D, lig);
             row_store<VEC, G, K>(s1[s], a.o.item_s1 + row[s] * (int64_t)D, D, lig);
             if (OPT == OPT_ADAM) row_store<VEC, G, K>(s2[s], a.o.item_s2 + row[s] * (int64_t)D, D, lig);
@@ -346,14 +349,16 @@ __device__ __forceinline__ void sorted_item_update_staged_body(const SortedArgs&
           }
         } else if (OPT != OPT_SGD) {
           // a piece of a run cut at a chunk boundary: the rule is not linear, so the pieces first meet in the (zeroed)
-          // gradient accumulator; the head piece lists the row for cut_rows_apply_kernel
+          // gradient accumulator; the head piece lists the row for cut_rows_apply_kernel.  (fmsub: w is the pre-update
+          // row in every piece — the rule is applied after all of them — so the pieces' -sum(c)*w add up exactly)
           float* grow = a.o.gacc + row[s] * (int64_t)D;
 #pragma unroll
           for (int kk = 0; kk < K; ++kk) {
             const int e = (kk * G + lig) * VEC;
 #pragma unroll
             for (int q = 0; q < VEC; ++q)
-              if (e + q < D) atomicAdd(grow + e + q, acc.v[kk * VEC + q]);
+              if (e + q < D)
+                atomicAdd(grow + e + q, a.fmsub ? acc.v[kk * VEC + q] - lin * w[s].v[kk * VEC + q] : acc.v[kk * VEC + q]);
           }
           if (lig == 0) {
             atomicAdd(a.o.gacc_lin + row[s], lin);
@@ -533,10 +538,15 @@ __device__ __forceinline__ void sorted_user_dup_update_body(const UserDupArgs& a
 // Item rows whose run was cut at a chunk boundary (adaptive rules): the pieces' sums are in gacc; apply the rule once
 // per listed row, clear the accumulator row, and reset the OTHER step parity's counter for the next step.
 template <int VEC, int G, int K, bool FULL, int OPT>
-__global__ __launch_bounds__(TRS_BLOCK) void cut_rows_apply_kernel(const trs_tables T, const OptArgs o, int parity) {
+__global__ __launch_bounds__(TRS_BLOCK) void cut_rows_apply_kernel(const trs_tables T, const OptArgs o, int parity,
+                                                                  float* tab, float* tab_lin) {
   constexpr int N = K * VEC;
   constexpr int TPW = TRS_WAVE / G;
   const int D = T.D;
+  if (!tab) {  // the item table, or one metadata column's tables (o.item_* are then that column's state)
+    tab = T.item;
+    tab_lin = T.item_lin;
+  }
   const int lane = threadIdx.x & 63, lig = lane % G;
   int count = o.cut_count[parity];
   if (count > o.cut_capacity) count = o.cut_capacity;
@@ -546,7 +556,7 @@ __global__ __launch_bounds__(TRS_BLOCK) void cut_rows_apply_kernel(const trs_tab
   for (int64_t i = wave * TPW + lane / G; i < count; i += nwave * TPW) {
     const int64_t row = o.cut_rows[i];
     RowReg<VEC, K> w, g, s1, s2, z;
-    row_load<VEC, G, K, FULL>(w, T.item, row, D, lig);
+    row_load<VEC, G, K, FULL>(w, tab, row, D, lig);
     row_load<VEC, G, K, FULL>(g, o.gacc, row, D, lig);
     row_load<VEC, G, K, FULL>(s1, o.item_s1, row, D, lig);
     if (OPT == OPT_ADAM) row_load<VEC, G, K, FULL>(s2, o.item_s2, row, D, lig);
@@ -555,13 +565,13 @@ __global__ __launch_bounds__(TRS_BLOCK) void cut_rows_apply_kernel(const trs_tab
       w.v[q] = opt_apply<OPT>(w.v[q], g.v[q], s1.v[q], s2.v[q], o);
       z.v[q] = 0.f;
     }
-    row_store<VEC, G, K>(w, T.item + row * (int64_t)D, D, lig);
+    row_store<VEC, G, K>(w, tab + row * (int64_t)D, D, lig);
     row_store<VEC, G, K>(s1, o.item_s1 + row * (int64_t)D, D, lig);
     if (OPT == OPT_ADAM) row_store<VEC, G, K>(s2, o.item_s2 + row * (int64_t)D, D, lig);
     row_store<VEC, G, K>(z, o.gacc + row * (int64_t)D, D, lig);
     if (lig == 0) {
       float ls1 = o.item_lin_s1[row], ls2 = OPT == OPT_ADAM ? o.item_lin_s2[row] : 0.f;
-      T.item_lin[row] = opt_apply<OPT>(T.item_lin[row], o.gacc_lin[row], ls1, ls2, o);
+      tab_lin[row] = opt_apply<OPT>(tab_lin[row], o.gacc_lin[row], ls1, ls2, o);
       o.item_lin_s1[row] = ls1;
       if (OPT == OPT_ADAM) o.item_lin_s2[row] = ls2;
       o.gacc_lin[row] = 0.f;
@@ -569,9 +579,9 @@ __global__ __launch_bounds__(TRS_BLOCK) void cut_rows_apply_kernel(const trs_tab
   }
 }
 
-template <typename KeyT, int VEC, int G, int K, bool FULL>
+template <typename KeyT, int VEC, int G, int K, bool FULL, int OPT = OPT_SGD>
 __global__ __launch_bounds__(TRS_BLOCK) void sorted_item_update_staged_kernel(const SortedArgs a) {
-  sorted_item_update_staged_body<KeyT, VEC, G, K, FULL>(a, blockIdx.x, gridDim.x);
+  sorted_item_update_staged_body<KeyT, VEC, G, K, FULL, OPT>(a, blockIdx.x, gridDim.x);
 }
 
 template <typename KeyT, int VEC, int G, int K, bool FULL>
@@ -863,10 +873,12 @@ int trs_launch_sorted_item_update(const trs_tables* tables, const void* keys_ste
 
 int trs_item_bits_for(int64_t n_items) { return bits_for(n_items); }
 
-// Sorted-run update of one metadata column (SGD): the staged item kernel pointed at that column's tables.
+// Sorted-run update of one metadata column: the staged item kernel pointed at that column's tables.  opt (adaptive
+// rules): item_* / gacc* / cut_* are the COLUMN's state, accumulators and cut-run list; adaptive kernels exist for the
+// shapes meta_stage_kernel handles (D = 4*G, G in {8,16,32,64}).
 int trs_launch_sorted_meta_update(const trs_tables* tables, int m, float* lin_or_scratch, const void* keys_step,
                                   const void* vals_step, int64_t batch, const float* gz, float lr, const float* xstage,
-                                  int64_t xpass, int fmsub, hipStream_t s) {
+                                  int64_t xpass, int fmsub, const OptArgs* opt, int parity, hipStream_t s) {
   SortedArgs a = {};
   a.T = *tables;
   a.keys = keys_step;
@@ -880,12 +892,39 @@ int trs_launch_sorted_meta_update(const trs_tables* tables, int m, float* lin_or
   a.fmsub = fmsub;
   a.tab = tables->meta[m];
   a.tab_lin = lin_or_scratch;
+  a.parity = parity & 1;
+  const int kind = opt ? opt->kind : OPT_SGD;
+  if (opt) a.o = *opt;
   RowCfg c;
   if (!pick_row_cfg(tables->D, c)) {
     trs_set_error("unsupported n_factors D=%d", tables->D);
     return TRS_E_ARG;
   }
-  const dim3 gs(trs_grid((2 * batch + RUN_CHUNK - 1) / RUN_CHUNK, 1)), bl(TRS_BLOCK);
+  const dim3 gs(trs_grid((2 * batch + RUN_CHUNK - 1) / RUN_CHUNK, 1)), bl(TRS_BLOCK), gc(16);
+  if (kind != OPT_SGD) {
+    const trs_tables T = *tables;
+#define TRS_CASE(GG)                                                                                                  \
+  if (c.vec == 4 && c.g == GG && c.k == 1 && 4 * GG == tables->D) {                                                   \
+    if (kind == OPT_ADAM) {                                                                                           \
+      hipLaunchKernelGGL((sorted_item_update_staged_kernel<uint32_t, 4, GG, 1, true, OPT_ADAM>), gs, bl, 0, s, a);     \
+      hipLaunchKernelGGL((cut_rows_apply_kernel<4, GG, 1, true, OPT_ADAM>), gc, bl, 0, s, T, a.o, a.parity, a.tab,     \
+                         a.tab_lin);                                                                                  \
+    } else {                                                                                                          \
+      hipLaunchKernelGGL((sorted_item_update_staged_kernel<uint32_t, 4, GG, 1, true, OPT_ADAGRAD>), gs, bl, 0, s, a);  \
+      hipLaunchKernelGGL((cut_rows_apply_kernel<4, GG, 1, true, OPT_ADAGRAD>), gc, bl, 0, s, T, a.o, a.parity, a.tab,  \
+                         a.tab_lin);                                                                                  \
+    }                                                                                                                 \
+    TRS_CHECK_LAUNCH("sorted_item_update_staged_kernel");                                                             \
+    return TRS_OK;                                                                                                    \
+  }
+    TRS_CASE(8)
+    TRS_CASE(16)
+    TRS_CASE(32)
+    TRS_CASE(64)
+#undef TRS_CASE
+    trs_set_error("adaptive rules on metadata columns need D in {32, 64, 128, 256} (got %d)", tables->D);
+    return TRS_E_ARG;
+  }
 #define TRS_CASE(V, GG, KK)                                                                                          \
   if (c.vec == V && c.g == GG && c.k == KK) {                                                                        \
     if (V * GG * KK == tables->D)                                                                                    \
@@ -957,10 +996,10 @@ int trs_launch_sorted_updates_fused(const trs_tables* tables, const void* keys_s
   {                                                                                                              \
     if (kind == OPT_ADAM) {                                                                                      \
       hipLaunchKernelGGL((sorted_updates_fused_kernel<V, GG, KK, FULL, OPT_ADAM>), gr, bl, 0, s, ia, ua, nu);     \
-      hipLaunchKernelGGL((cut_rows_apply_kernel<V, GG, KK, FULL, OPT_ADAM>), gc, bl, 0, s, T, ia.o, ia.parity);   \
+      hipLaunchKernelGGL((cut_rows_apply_kernel<V, GG, KK, FULL, OPT_ADAM>), gc, bl, 0, s, T, ia.o, ia.parity, (float*)nullptr, (float*)nullptr); \
     } else if (kind == OPT_ADAGRAD) {                                                                            \
       hipLaunchKernelGGL((sorted_updates_fused_kernel<V, GG, KK, FULL, OPT_ADAGRAD>), gr, bl, 0, s, ia, ua, nu);  \
-      hipLaunchKernelGGL((cut_rows_apply_kernel<V, GG, KK, FULL, OPT_ADAGRAD>), gc, bl, 0, s, T, ia.o, ia.parity); \
+      hipLaunchKernelGGL((cut_rows_apply_kernel<V, GG, KK, FULL, OPT_ADAGRAD>), gc, bl, 0, s, T, ia.o, ia.parity, (float*)nullptr, (float*)nullptr); \
     } else {                                                                                                     \
       hipLaunchKernelGGL((sorted_updates_fused_kernel<V, GG, KK, FULL>), gr, bl, 0, s, ia, ua, nu);               \
     }                                                                                                            \

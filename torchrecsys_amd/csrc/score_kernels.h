@@ -10,6 +10,7 @@
 // the group.  All rows are read from the pre-update tables; nothing here writes a table.
 #pragma once
 #include "trs_common.h"
+#include "opt_rows.h"
 
 namespace trs {
 
@@ -105,6 +106,7 @@ struct ScoreArgs {
   const uint8_t* udup_pos;
   float lr;
   int32_t* meta_ids_out;
+  OptArgs o;  // meta_stage_kernel (fast_step.hip): update rule of the in-place user update (kind OPT_SGD: lr above)
 };
 
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }

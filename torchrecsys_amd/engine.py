@@ -113,8 +113,10 @@ class SparseScorerTrainer:
         self.fast_kind = None  # "sgd": C step loop on every path; "sparse_adam" / "adagrad": on the presorted path only
         hyper = {"sgd": ("lr",), "sparse_adam": ("lr", "betas", "eps"),
                  "adagrad": ("lr", "lr_decay", "eps", "initial_accumulator_value")}.get(self.kind)
-        # metadata scorers: plain SGD only (their small tables take an atomic scatter of staged gradients)
-        if hyper is not None and (self.M == 0 or self.kind == "sgd"):
+        # metadata scorers: plain SGD on any shape; the adaptive rules where the staging kernel with the rule exists
+        # (csrc/fast_step.hip meta_stage_kernel: up to 3 sorted columns, whole-row D)
+        meta_adaptive_ok = (self.M <= 3 and self.D in (32, 64, 128, 256) and os.environ.get("TRS_META_SORTED", "1") != "0")
+        if hyper is not None and (self.M == 0 or self.kind == "sgd" or meta_adaptive_ok):
             lrs = {tuple(_group_of(optimizer, p).get(k) for k in hyper) for p in self.params}
             if len(lrs) == 1:  # one rule for all tables
                 self.fast_kind = self.kind
@@ -129,8 +131,10 @@ class SparseScorerTrainer:
             self.row_state = {id(p): RowState(p) for p in self.params}
         if self.fast_kind in ("sparse_adam", "adagrad"):
             # item runs cut at a chunk boundary: at most one per 64-reference chunk (+ slack)
-            self.cut_rows = torch.empty(2 * batch_capacity // 64 + 64, dtype=torch.int32, device=dev)
-            self.cut_count = torch.zeros(2, dtype=torch.int32, device=dev)
+            # (one list + counter pair for the item table and one per metadata column)
+            self.cut_rows = torch.empty((1 + self.M, 2 * batch_capacity // 64 + 64), dtype=torch.int32, device=dev)
+            self.cut_count = torch.zeros((1 + self.M, 2), dtype=torch.int32, device=dev)
+            self.meta_lin_state = None  # Linear scorer: scratch in place of the 1-wide metadata tables' state
         # presorted epoch slices (csrc/presort.hip): two buffer sets, the one being built on the side stream and the one
         # the step kernels read
         self.ustage = None            # (capacity, D) pre-update user rows staged by K1 for the item update
@@ -339,12 +343,27 @@ class SparseScorerTrainer:
             s1, s2 = [st["exp_avg"] for st in sts], [st["exp_avg_sq"] for st in sts]
         else:
             o.kind, o.eps, o.lr_decay = 2, float(g["eps"]), float(g["lr_decay"])
-            s1, s2 = [st["sum"] for st in sts], [None] * 4
-        o.user_s1, o.item_s1, o.user_lin_s1, o.item_lin_s1 = (ops.ptr(t) for t in s1)
-        o.user_s2, o.item_s2, o.user_lin_s2, o.item_lin_s2 = (ops.ptr(t) for t in s2)
+            s1, s2 = [st["sum"] for st in sts], [None] * len(sts)
+        o.user_s1, o.item_s1, o.user_lin_s1, o.item_lin_s1 = (ops.ptr(t) for t in s1[:4])
+        o.user_s2, o.item_s2, o.user_lin_s2, o.item_lin_s2 = (ops.ptr(t) for t in s2[:4])
         # the generic path's (all-zero between steps) gradient accumulators double as the meeting point of cut runs
         o.gacc, o.gacc_lin = ops.ptr(self.row_state[id(self.params[1])].acc), ops.ptr(self.row_state[id(self.params[3])].acc)
-        o.cut_rows, o.cut_count, o.cut_capacity = ops.ptr(self.cut_rows), ops.ptr(self.cut_count), self.cut_rows.numel()
+        o.cut_rows, o.cut_count, o.cut_capacity = ops.ptr(self.cut_rows[0]), ops.ptr(self.cut_count[0]), self.cut_rows.shape[1]
+        M = self.M
+        has_lin = len(self.params) == 4 + 2 * M  # FM: 1-wide metadata tables follow the metadata tables
+        if M > 0 and not has_lin and self.meta_lin_state is None:
+            self.meta_lin_state = [torch.zeros((3, self.params[4 + m].shape[0]), dtype=torch.float32, device=self.dev)
+                                   for m in range(M)]
+        for m in range(M):
+            o.meta_s1[m], o.meta_s2[m] = ops.ptr(s1[4 + m]), ops.ptr(s2[4 + m])
+            o.meta_gacc[m] = ops.ptr(self.row_state[id(self.params[4 + m])].acc)
+            if has_lin:
+                o.meta_lin_s1[m], o.meta_lin_s2[m] = ops.ptr(s1[4 + M + m]), ops.ptr(s2[4 + M + m])
+                o.meta_gacc_lin[m] = ops.ptr(self.row_state[id(self.params[4 + M + m])].acc)
+            else:
+                sc = self.meta_lin_state[m]
+                o.meta_lin_s1[m], o.meta_lin_s2[m], o.meta_gacc_lin[m] = ops.ptr(sc[0]), ops.ptr(sc[1]), ops.ptr(sc[2])
+            o.meta_cut_rows[m], o.meta_cut_count[m] = ops.ptr(self.cut_rows[1 + m]), ops.ptr(self.cut_count[1 + m])
         for st in sts:
             st["step"] += n_steps
         return o
