@@ -311,18 +311,32 @@ __device__ __forceinline__ void sorted_item_update_staged_body(const SortedArgs&
           for (int q = 0; q < N; ++q) acc.v[q] += cm[s][j] * __uint_as_float(__float_as_uint(u[s][j].v[q]) & on);
           lin += cm[s][j];
         }
-        if (!has[s]) continue;
-        for (int j = SI_MEMB; j < len[s]; ++j) {  // longer runs (hot rows): one more row per turn
-          const RefPayload pl = a.vals[base + l[s] + j];
-          const int tj = (int)(pl.tw >> 1);
-          const float gj = a.gz[(int64_t)(pl.tw & 1u) * a.B + tj];
-          const float cj = OPT == OPT_SGD ? -a.lr * gj : gj;
-          RowReg<VEC, K> uj;
-          row_load<VEC, G, K, FULL>(uj, a.ustage, (int64_t)tj + (int64_t)(pl.tw & 1u) * a.xpass, D, lig);
+        // longer runs (hot rows, metadata columns): TU more members per turn.  The run lies inside this wave's 64
+        // references, so staging rows and coefficients come from the detection lanes by shuffle — the loop is
+        // wave-uniform (all lanes shuffle; groups whose run has ended add masked zeros) and its row loads are independent.
+        constexpr int TU = N <= 4 ? 4 : 2;
+        for (int j0 = SI_MEMB; __ballot(has[s] && j0 < len[s]) != 0ull; j0 += TU) {
+          RowReg<VEC, K> uj[TU];
+          float cj[TU];
+          uint32_t onj[TU];
 #pragma unroll
-          for (int q = 0; q < N; ++q) acc.v[q] += cj * uj.v[q];
-          lin += cj;
+          for (int tu = 0; tu < TU; ++tu) {
+            const bool on = has[s] && j0 + tu < len[s];
+            const int src = on ? l[s] + j0 + tu : l[s];
+            const int tj = __shfl(xrow, src, 64);
+            const float cv = __shfl(c, src, 64);
+            cj[tu] = on ? cv : 0.f;
+            onj[tu] = on ? 0xffffffffu : 0u;
+            row_load<VEC, G, K, FULL>(uj[tu], a.ustage, (int64_t)tj, D, lig);
+          }
+#pragma unroll
+          for (int tu = 0; tu < TU; ++tu) {
+#pragma unroll
+            for (int q = 0; q < N; ++q) acc.v[q] += cj[tu] * __uint_as_float(__float_as_uint(uj[tu].v[q]) & onj[tu]);
+            lin += cj[tu];
+          }
         }
+        if (!has[s]) continue;
         const bool cut_tail = (l[s] + len[s] == RUN_CHUNK) && (base + RUN_CHUNK < n) && knext == keyv[s];
         float* irow = tab + row[s] * (int64_t)D;
         if (hd[s] != 0 && !cut_tail) {
@@ -900,7 +914,7 @@ int trs_launch_sorted_meta_update(const trs_tables* tables, int m, float* lin_or
     trs_set_error("unsupported n_factors D=%d", tables->D);
     return TRS_E_ARG;
   }
-  const dim3 gs(trs_grid((2 * batch + RUN_CHUNK - 1) / RUN_CHUNK, 1)), bl(TRS_BLOCK), gc(16);
+  const dim3 gs(trs_grid((2 * batch + RUN_CHUNK - 1) / RUN_CHUNK, 1)), bl(TRS_BLOCK), gc(128);
   if (kind != OPT_SGD) {
     const trs_tables T = *tables;
 #define TRS_CASE(GG)                                                                                                  \
