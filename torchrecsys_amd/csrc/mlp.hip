@@ -116,6 +116,7 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_stats_partial_kernel(const float
 // update (momentum 0.1, unbiased variance) applied once per pass, positive pass first.
 // Block = 64 columns x 4 segments of the chunk list; the 4 partial (n, mean, M2) triples are merged in LDS.
 constexpr int FIN_COLS = 16, FIN_SEGS = TRS_BLOCK / FIN_COLS;  // narrow column slabs: H/16 workgroups, 16 segments each
+constexpr int FIN_U = 8;  // chunk partials a thread has in flight
 
 __global__ __launch_bounds__(TRS_BLOCK) void bn_stats_final_kernel(const float* __restrict__ part,
                                                                   int64_t rows_per_pass, int chunk_rows, int H,
@@ -130,12 +131,25 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_stats_final_kernel(const float* 
   const int pass = blockIdx.y;
   const float* base = part + (int64_t)pass * n_chunks * 2 * H;
   double s1 = 0.0, cnt = 0.0;
+  // FIN_U partials in flight per turn (the loads are issued before the first add; summation order unchanged)
   if (col < H) {
-    for (int c = seg; c < n_chunks; c += FIN_SEGS) {
-      const int64_t r0 = (int64_t)c * chunk_rows;
-      const double nb = (double)((r0 + chunk_rows < rows_per_pass ? r0 + chunk_rows : rows_per_pass) - r0);
-      s1 += nb * (double)base[(int64_t)c * 2 * H + col];
-      cnt += nb;
+    for (int c0 = seg; c0 < n_chunks; c0 += FIN_U * FIN_SEGS) {
+      float v[FIN_U];
+#pragma unroll
+      for (int k = 0; k < FIN_U; ++k) {
+        const int c = c0 + k * FIN_SEGS;
+        v[k] = base[(int64_t)(c < n_chunks ? c : n_chunks - 1) * 2 * H + col];
+      }
+#pragma unroll
+      for (int k = 0; k < FIN_U; ++k) {
+        const int c = c0 + k * FIN_SEGS;
+        const int64_t r0 = (int64_t)c * chunk_rows;
+        const double nb = (double)((r0 + chunk_rows < rows_per_pass ? r0 + chunk_rows : rows_per_pass) - r0);
+        if (c < n_chunks) {
+          s1 += nb * (double)v[k];
+          cnt += nb;
+        }
+      }
     }
   }
   s_a[seg][cl] = s1; s_b[seg][cl] = cnt;
@@ -149,12 +163,23 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_stats_final_kernel(const float* 
   const double n = (double)rows_per_pass;
   double m2 = 0.0;
   if (col < H) {
-    for (int c = seg; c < n_chunks; c += FIN_SEGS) {
-      const int64_t r0 = (int64_t)c * chunk_rows;
-      const double nb = (double)((r0 + chunk_rows < rows_per_pass ? r0 + chunk_rows : rows_per_pass) - r0);
-      const float* o = base + (int64_t)c * 2 * H;
-      const double d = (double)o[col] - mean;
-      m2 += (double)o[H + col] + nb * d * d;
+    for (int c0 = seg; c0 < n_chunks; c0 += FIN_U * FIN_SEGS) {
+      float v[FIN_U], w[FIN_U];
+#pragma unroll
+      for (int k = 0; k < FIN_U; ++k) {
+        const int c = c0 + k * FIN_SEGS;
+        const float* o = base + (int64_t)(c < n_chunks ? c : n_chunks - 1) * 2 * H;
+        v[k] = o[col];
+        w[k] = o[H + col];
+      }
+#pragma unroll
+      for (int k = 0; k < FIN_U; ++k) {
+        const int c = c0 + k * FIN_SEGS;
+        const int64_t r0 = (int64_t)c * chunk_rows;
+        const double nb = (double)((r0 + chunk_rows < rows_per_pass ? r0 + chunk_rows : rows_per_pass) - r0);
+        const double d = (double)v[k] - mean;
+        if (c < n_chunks) m2 += (double)w[k] + nb * d * d;
+      }
     }
   }
   __syncthreads();
@@ -300,10 +325,21 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_final_kernel(const float* __
   for (int pass = 0; pass < passes; ++pass) {
     double s1 = 0.0, s2 = 0.0;
     if (col < H) {
-      for (int c = seg; c < n_chunks; c += FIN_SEGS) {
-        const float* o = part + (((int64_t)pass * n_chunks + c) * 2) * H;
-        s1 += o[col];
-        s2 += o[H + col];
+      for (int c0 = seg; c0 < n_chunks; c0 += FIN_U * FIN_SEGS) {
+        float v[FIN_U], w[FIN_U];
+#pragma unroll
+        for (int k = 0; k < FIN_U; ++k) {
+          const int c = c0 + k * FIN_SEGS;
+          const float* o = part + (((int64_t)pass * n_chunks + (c < n_chunks ? c : n_chunks - 1)) * 2) * H;
+          v[k] = o[col];
+          w[k] = o[H + col];
+        }
+#pragma unroll
+        for (int k = 0; k < FIN_U; ++k)
+          if (c0 + k * FIN_SEGS < n_chunks) {
+            s1 += v[k];
+            s2 += w[k];
+          }
       }
     }
     s_1[seg][cl] = s1; s_2[seg][cl] = s2;
@@ -383,7 +419,17 @@ __global__ __launch_bounds__(TRS_BLOCK) void colsum_final_kernel(const float* __
   for (int p = 0; p < passes; ++p) {  // per pass first: identical summation structure in both passes (exact cancellation)
     double s = 0.0;
     if (col < H)
-      for (int c = seg; c < n_chunks; c += FIN_SEGS) s += part[((int64_t)p * n_chunks + c) * H + col];
+      for (int c0 = seg; c0 < n_chunks; c0 += FIN_U * FIN_SEGS) {
+        float v[FIN_U];
+#pragma unroll
+        for (int k = 0; k < FIN_U; ++k) {
+          const int c = c0 + k * FIN_SEGS;
+          v[k] = part[((int64_t)p * n_chunks + (c < n_chunks ? c : n_chunks - 1)) * H + col];
+        }
+#pragma unroll
+        for (int k = 0; k < FIN_U; ++k)
+          if (c0 + k * FIN_SEGS < n_chunks) s += v[k];
+      }
     s_s[seg][cl] = s;
     __syncthreads();
     if (seg == 0) {
