@@ -5,7 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from torchrecsys_amd import ops
 dev = "cuda:0"
-for (nu, ni, D, B) in ((1_000_000, 100_000, 64, 65_536), (10_000_000, 1_000_000, 128, 32_768), (10_000_000, 1_000_000, 128, 262_144)):
+SHAPES = ((1_000_000, 100_000, 64, 65_536), (10_000_000, 1_000_000, 128, 32_768), (10_000_000, 1_000_000, 128, 262_144))
+if len(sys.argv) > 1:  # one shape only (PMC passes: one kernel shape per run)
+    SHAPES = (SHAPES[int(sys.argv[1])],)
+for (nu, ni, D, B) in SHAPES:
     g = torch.Generator(device=dev); g.manual_seed(0)
     t = [torch.randn(nu, D, device=dev) * 0.1, torch.randn(ni, D, device=dev) * 0.1, torch.randn(nu, 1, device=dev), torch.randn(ni, 1, device=dev)]
     T, keep = ops.make_tables(*t)
