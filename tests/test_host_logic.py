@@ -3,6 +3,7 @@
 without a device."""
 import contextlib
 import io
+import os
 
 import numpy as np
 import pandas as pd
@@ -197,3 +198,28 @@ def test_seeded_construction_reproduces_reference_initial_weights():
             assert sorted(sd) == sorted(ref)
             for k, v in ref.items():
                 assert np.array_equal(sd[k].cpu().numpy(), v), k
+
+
+def test_host_thread_budget_caps_and_restores(monkeypatch):
+    """helper.cuda.host_threads(): torch's intra-op pool is capped at min(CPU budget, 8) inside the block (a container's
+    CPU quota is far below the host's core count torch sizes its pool from) and restored afterwards; TRS_HOST_THREADS
+    overrides; entry points keep the reference's signatures through the wrapper."""
+    import inspect
+    import torch
+    from torchrecsys_amd.helper.cuda import cpu_budget, host_threads
+    from torchrecsys_amd.model import TorchRecSys
+    assert 1 <= cpu_budget() <= (os.cpu_count() or 1)
+    before = torch.get_num_threads()
+    try:
+        torch.set_num_threads(max(before, 2))
+        monkeypatch.setenv("TRS_HOST_THREADS", "1")
+        with host_threads():
+            assert torch.get_num_threads() == 1
+        assert torch.get_num_threads() == max(before, 2)
+        monkeypatch.setenv("TRS_HOST_THREADS", "4096")  # never raises the count
+        with host_threads():
+            assert torch.get_num_threads() == max(before, 2)
+    finally:
+        torch.set_num_threads(before)
+    assert list(inspect.signature(TorchRecSys.fit).parameters)[:4] == ["self", "optimizer", "epochs", "batch_size"]
+    assert list(inspect.signature(TorchRecSys.__init__).parameters)[:4] == ["self", "dataset", "user_id_col", "item_id_col"]

@@ -10,6 +10,7 @@ Same constructor keywords, same methods, same printed strings, same state_dict k
         benchmark runs in
   seed : seed of the device-side generators (rng='device')
 """
+import functools
 import math
 import os
 from typing import List
@@ -27,8 +28,17 @@ from .collaborative.linear import Linear
 from .dataset.dataset import FastDataLoader, ProcessData, sample_negatives_reference_stream
 from .engine import SparseScorerTrainer
 from .evaluate.metrics import Metrics
-from .helper.cuda import gpu
+from .helper.cuda import gpu, host_threads
 from .helper.loss import hinge_loss  # noqa: F401  (part of the reference's module surface)
+
+
+def _host_side(fn):
+    """Run a public entry point under helper.cuda.host_threads() (torch's CPU thread pool capped at the CPU budget)."""
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        with host_threads():
+            return fn(*args, **kwargs)
+    return wrapped
 
 _NO_GPU_MSG = ("torchrecsys_amd needs an AMD Instinct MI355X (gfx950) visible to PyTorch-ROCm; "
                "it has no CPU fallback (use_cuda=False only means: hand results back as CPU tensors)")
@@ -53,6 +63,7 @@ def _mix64(a, b):
 
 class TorchRecSys(torch.nn.Module):
 
+    @_host_side
     def __init__(self,
                  dataset: pd.DataFrame,
                  user_id_col: str,
@@ -245,6 +256,7 @@ class TorchRecSys(torch.nn.Module):
         """The step-level driver fit() is built on (bench.py times exactly this object)."""
         return FitRunner(self, optimizer, batch_size)
 
+    @_host_side
     def fit(self, optimizer, epochs=10, batch_size=512, profile_epochs: int = 0, sync_tables_every: int = 1):
         """Fits the model (reference model.py:203-288).  Under torch.distributed (one process per GPU) every rank trains
         its contiguous shard of the training split with `batch_size` per rank; dense MLP gradients are all-reduced every
@@ -279,6 +291,7 @@ class TorchRecSys(torch.nn.Module):
             print(f'|--- Epoch {epoch+1}/{epochs} --- Training Loss: {avg_loss:.4f}')
 
     # ------------------------------------------------------------------------------------------------ evaluate
+    @_host_side
     def evaluate(self, batch_size=512, eval_metrics=['loss', 'auc']):
         """reference model.py:292-338: eval-mode scores of the test split, hinge loss and pairwise AUC per batch,
         unweighted means over batches, printed; returns None."""
@@ -329,6 +342,7 @@ class TorchRecSys(torch.nn.Module):
             print(f'|--- Testing {metric}: {value:.4f}')
 
     # ------------------------------------------------------------------------------------------------ predict
+    @_host_side
     def predict(self, user_id: int, top_k: int = 10, prediction_batch_size: int = 4096):
         """Top-K item ids for one user (reference model.py:341-452): score every item, sort descending, first top_k.
         Ties are ordered by ascending item id (unspecified in the reference).  Returns an int64 CPU tensor.
