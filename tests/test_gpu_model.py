@@ -419,3 +419,25 @@ def test_mlp_bf16_resident_path_tracks_fp32(use_bn):
         a, c = a.reshape(-1).astype(np.float64), c.reshape(-1).astype(np.float64)
         cos = a @ c / (np.linalg.norm(a) * np.linalg.norm(c))
         assert cos > 0.97, cos  # y_l, dx_l, x_l and dy_l all live in bf16 between the GEMMs
+
+
+@pytest.mark.parametrize("net_type", ["linear", "mlp"])
+def test_amp_training_run_and_profiling_run(net_type):
+    """The reference's smoke tests (tests/test_model_and_features.py:136-143, 219-227): fit() with use_amp=True and
+    with profile_epochs=1 runs to the end with torch.optim.Adam at batch_size 32 (here use_amp is bf16 GEMM inputs on the
+    MLP and a no-op on the scorers without GEMMs; the profiler prints its table after the first epoch)."""
+    from torchrecsys_amd.model import TorchRecSys
+    rs = np.random.RandomState(1)
+    n_u, n_i, n = 60, 40, 1000
+    df = pd.DataFrame({"user_id": np.concatenate([np.arange(n_u), rs.randint(0, n_u, n - n_u)]),
+                       "item_id": np.concatenate([np.arange(n_i), rs.randint(0, n_i, n - n_i)])})
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        model = TorchRecSys(dataset=df, user_id_col="user_id", item_id_col="item_id", n_factors=16, net_type=net_type,
+                            use_amp=True, use_cuda=True)
+        model.fit(torch.optim.Adam(model.parameters(), lr=1e-3), epochs=1, batch_size=32)
+        model = TorchRecSys(dataset=df, user_id_col="user_id", item_id_col="item_id", n_factors=16, net_type=net_type)
+        model.fit(torch.optim.Adam(model.parameters(), lr=1e-3), epochs=1, batch_size=32, profile_epochs=1)
+    out = buf.getvalue()
+    assert out.count("Training Loss") == 2 and "Profiler Results" in out
+    assert all(np.isfinite(v.cpu().numpy()).all() for v in model.state_dict().values())

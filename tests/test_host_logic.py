@@ -223,3 +223,24 @@ def test_host_thread_budget_caps_and_restores(monkeypatch):
         torch.set_num_threads(before)
     assert list(inspect.signature(TorchRecSys.fit).parameters)[:4] == ["self", "optimizer", "epochs", "batch_size"]
     assert list(inspect.signature(TorchRecSys.__init__).parameters)[:4] == ["self", "dataset", "user_id_col", "item_id_col"]
+
+
+def test_mlp_custom_hidden_layers_and_batch_norm_toggle():  # reference tests/test_model_and_features.py:145-185
+    from torchrecsys_amd.collaborative.mlp import MLP
+    from torchrecsys_amd.dataset.dataset import ProcessData
+    rs = np.random.RandomState(0)
+    df = pd.DataFrame({"user_id": np.concatenate([np.arange(100), rs.randint(0, 100, 900)]),
+                       "item_id": np.concatenate([np.arange(50), rs.randint(0, 50, 950)])})
+    counts = ProcessData(df, "user_id", "item_id")
+    custom = [64, 32]
+    mlp = MLP(n_users=counts.num_users, n_items=counts.num_items, n_metadata={}, n_factors=16, use_metadata=False,
+              hidden_layers=custom)
+    assert len(mlp.fcs) == len(custom)
+    assert mlp.fcs[0].out_features == custom[0] and mlp.fcs[1].out_features == custom[1]
+    assert mlp.fcs[0].in_features == 2 * 16 and mlp.output_layer.in_features == custom[-1]
+    with_bn = MLP(n_users=counts.num_users, n_items=counts.num_items, n_metadata={}, n_factors=16, use_metadata=False,
+                  use_batch_norm=True)
+    assert hasattr(with_bn, "bns") and len(with_bn.bns) == len(with_bn.hidden_layers)
+    without = MLP(n_users=counts.num_users, n_items=counts.num_items, n_metadata={}, n_factors=16, use_metadata=False,
+                  use_batch_norm=False)
+    assert not hasattr(without, "bns") or len(without.bns) == 0
