@@ -166,7 +166,11 @@ class SparseScorerTrainer:
         self.stamp += n
         return first
 
-    EVENT_EVERY = 8  # bench timing samples one step in 8
+    # bench timing samples one step in 29: a sampled step carries four event records and runs ~20 us longer (rocprofv3
+    # trace: 9 us between K1 and K2, 4-6 us before / after the step, against back-to-back launches otherwise).  A prime
+    # stride: a power of two would pin the samples to the same positions of the 512-batch presort slices (the first
+    # steps of a slice overlap the next slice's sort) and of the 64-step C calls
+    EVENT_EVERY = 29
 
     def _make_events(self, n_steps):
         """Raw hipEvent_t handles, 4 per sampled step (None for the others), owned by an ops.TimingEvents."""
