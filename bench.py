@@ -166,6 +166,7 @@ def main():
     if not args.no_kernel_events:
         if is_mlp:
             model.net.compute.gemm_events = []
+            model.net.compute.gemm_steps_seen = model.net.compute.gemm_steps_timed = 0
         else:
             runner.trainer.kernel_events = {}
     t0 = time.perf_counter()
@@ -209,14 +210,17 @@ def main():
     if gemm_events:
         dims = [(2 + M) * D] + list(cfg["hidden"])
         P = sum(a_ * b_ for a_, b_ in zip(dims[:-1], dims[1:])) + dims[-1]  # MACs per sample
+        timed_steps = max(model.net.compute.gemm_steps_timed, 1)  # the GEMMs of one step in 5 carry events
         ms = sum(e0.elapsed_time(e1) for e0, e1, _ in gemm_events)
         fl = sum(f for _, _, f in gemm_events)
         ach = fl / (ms * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[dtype]
         out["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16in_kernel" if cfg["amp"] else "gemm_f32_kernel",
                            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-                           "gemm_launches_per_step": len(gemm_events) / args.steps,
-                           "gemm_ms_per_step": ms / args.steps, "gemm_share_of_step": ms / (1e3 * elapsed),
+                           "gemm_launches_per_step": len(gemm_events) / timed_steps,
+                           "gemm_ms_per_step": ms / timed_steps,
+                           "gemm_share_of_step": (ms / timed_steps) / (1e3 * elapsed / args.steps),
+                           "timed_steps": timed_steps,
                            "algorithmic_flops_per_triple": 12 * P,
                            "whole_step_TFLOPs": 12.0 * P * B * args.steps / elapsed / 1e12,
                            "note": "event intervals around the GEMM launches (HIP events on the launch stream); they "
