@@ -23,6 +23,12 @@
 #include "score_kernels.h"
 #include "opt_rows.h"
 
+// The plain-SGD run kernels with one float4 per lane and whole rows (D = 4*G) are compiled for 4 waves per SIMD (128 VGPRs, no spill; the
+// compiler's own choice is 130 = 3 waves): random-row latency is hidden by waves in flight (c2: K2 22.0 -> 21.1 us
+// between its events).  5 waves spill; the adaptive rules need 174-210 VGPRs and keep the default.
+#ifndef K2_WAVES
+#define K2_WAVES 4
+#endif
 namespace trs {
 
 struct RefPayload {
@@ -594,7 +600,9 @@ __global__ __launch_bounds__(TRS_BLOCK) void cut_rows_apply_kernel(const trs_tab
 }
 
 template <typename KeyT, int VEC, int G, int K, bool FULL, int OPT = OPT_SGD>
-__global__ __launch_bounds__(TRS_BLOCK) void sorted_item_update_staged_kernel(const SortedArgs a) {
+__global__ __launch_bounds__(TRS_BLOCK)
+__attribute__((amdgpu_waves_per_eu(OPT == OPT_SGD && VEC == 4 && K == 1 && FULL && sizeof(KeyT) == 4 ? K2_WAVES : 1)))
+void sorted_item_update_staged_kernel(const SortedArgs a) {
   sorted_item_update_staged_body<KeyT, VEC, G, K, FULL, OPT>(a, blockIdx.x, gridDim.x);
 }
 
@@ -607,7 +615,9 @@ __global__ __launch_bounds__(TRS_BLOCK) void sorted_user_dup_update_kernel(const
 // n_user_blocks workgroups walk the duplicated-user runs, the rest the item chunks.  Saves a kernel boundary and hides
 // the short, latency-bound user pass under the item pass.  32-bit keys on both sides (the common case).
 template <int VEC, int G, int K, bool FULL, int OPT = OPT_SGD>
-__global__ __launch_bounds__(TRS_BLOCK) void sorted_updates_fused_kernel(const SortedArgs ia, const UserDupArgs ua,
+__global__ __launch_bounds__(TRS_BLOCK)
+__attribute__((amdgpu_waves_per_eu(OPT == OPT_SGD && VEC == 4 && K == 1 && FULL ? K2_WAVES : 1)))
+void sorted_updates_fused_kernel(const SortedArgs ia, const UserDupArgs ua,
                                                                         int n_user_blocks) {
   if ((int)blockIdx.x < n_user_blocks)
     sorted_user_dup_update_body<uint32_t, VEC, G, K, FULL, OPT>(ua, blockIdx.x, n_user_blocks);
