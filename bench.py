@@ -286,4 +286,6 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    from torchrecsys_amd.helper.cuda import host_threads
+    with host_threads():  # torch's CPU pool capped at the container's CPU budget (N ranks share one host)
+        main()
