@@ -410,16 +410,6 @@ __device__ __forceinline__ void sorted_item_update_staged_body(const SortedArgs&
 // flags[q] = 1 iff the user of position q is referenced by another triple of the same batch (static for the epoch):
 // segmented sort of (user, q) with one segment per batch, then compare neighbours inside the segment.
 template <typename KeyT>
-__global__ __launch_bounds__(TRS_BLOCK) void user_keys_kernel(const int32_t* __restrict__ user, int64_t n_pos,
-                                                             KeyT* __restrict__ keys, uint32_t* __restrict__ vals) {
-  const int64_t stride = (int64_t)gridDim.x * TRS_BLOCK;
-  for (int64_t q = (int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x; q < n_pos; q += stride) {
-    keys[q] = (KeyT)(uint32_t)user[q];
-    vals[q] = (uint32_t)q;
-  }
-}
-
-template <typename KeyT>
 __global__ __launch_bounds__(TRS_BLOCK) void user_flags_kernel(const KeyT* __restrict__ keys,
                                                               const uint32_t* __restrict__ vals, int64_t n_pos,
                                                               int64_t batch, uint8_t* __restrict__ flags) {
@@ -733,8 +723,9 @@ extern "C" int trs_epoch_user_dups_sizes(int64_t n_batches, int64_t batch, int64
   const size_t n = (size_t)(n_batches * batch);
   size_t temp = 0;
   hipError_t e = rocprim::segmented_radix_sort_pairs<UserSortCfg>(
-      nullptr, temp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n,
-      (unsigned)n_batches, seg_it(0, (uint32_t)batch), seg_it(1, (uint32_t)batch), 0u, (unsigned)bits, (hipStream_t)0);
+      nullptr, temp, (const uint32_t*)nullptr, (uint32_t*)nullptr, rocprim::counting_iterator<uint32_t>(0),
+      (uint32_t*)nullptr, n, (unsigned)n_batches, seg_it(0, (uint32_t)batch), seg_it(1, (uint32_t)batch), 0u,
+      (unsigned)bits, (hipStream_t)0);
   TRS_REQUIRE(e == hipSuccess, "trs_epoch_user_dups_sizes: rocprim size query failed");
   *ukeys_bytes_out = 2 * (int64_t)n * kb;
   *uvals_bytes_out = 2 * (int64_t)n * 4;
@@ -757,11 +748,13 @@ extern "C" int trs_epoch_user_dups(const int32_t* user_dev, int64_t n_batches, i
   size_t temp = (size_t)temp_bytes;
   uint32_t* vin = (uint32_t*)uvals_dev;
   uint32_t* kin = (uint32_t*)ukeys_dev;
-  hipLaunchKernelGGL((user_keys_kernel<uint32_t>), gr, bl, 0, s, user_dev, n_pos, kin, vin);
-  // one segment per batch, keys = user id: two 10-bit passes for up to 2^20 users
+  // one segment per batch; the sort reads the user ids where they lie (non-negative int32 = uint32 keys) and numbers
+  // the positions q with a counting iterator — no key / payload arrays are built first: two 10-bit passes for up to
+  // 2^20 users
   hipError_t e = rocprim::segmented_radix_sort_pairs<UserSortCfg>(
-      temp_dev, temp, kin, kin + n_pos, vin, vin + n_pos, (size_t)n_pos, (unsigned)n_batches,
-      seg_it(0, (uint32_t)batch), seg_it(1, (uint32_t)batch), 0u, (unsigned)user_bits, s);
+      temp_dev, temp, (const uint32_t*)user_dev, kin + n_pos, rocprim::counting_iterator<uint32_t>(0), vin + n_pos,
+      (size_t)n_pos, (unsigned)n_batches, seg_it(0, (uint32_t)batch), seg_it(1, (uint32_t)batch), 0u,
+      (unsigned)user_bits, s);
   if (e == hipSuccess)
     hipLaunchKernelGGL((user_flags_kernel<uint32_t>), gr, bl, 0, s, kin + n_pos, vin + n_pos, n_pos, batch,
                        flags_out_dev);
