@@ -441,3 +441,31 @@ def test_amp_training_run_and_profiling_run(net_type):
     out = buf.getvalue()
     assert out.count("Training Loss") == 2 and "Profiler Results" in out
     assert all(np.isfinite(v.cpu().numpy()).all() for v in model.state_dict().values())
+
+
+def test_bench_line_contract():
+    """`python bench.py` prints ONE JSON line with the contract's keys, a roofline object (bound / achieved / peak / unit /
+    frac / traffic) and a cpu_baseline object (value / unit / cores / kind / sample).  Run on the small c1 workload."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "c1", "--steps", "64", "--warmup", "8"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 64 and d["warmup"] == 8 and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["scaling"] == "weak" and d["data"] == "synthetic" and d["dtype"] == "f32"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] == pytest.approx(2 * 1024 * 64 / (d["ms_per_step"] * 64 * 1e-3), rel=1e-6)
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and "traffic" in r
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0.0 < r["frac"] < 1.0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == d["unit"] and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
