@@ -277,6 +277,8 @@ class TorchRecSys(torch.nn.Module):
             runner.more_epochs = epoch < epochs - 1  # lets the last slice's steps hide the next epoch's first presort
             runner.begin_epoch()
             runner.run_steps(runner.num_batches)
+            if runner.more_epochs:
+                runner.prepare_next_epoch()  # host work of epoch e+1 while the GPU runs epoch e
             avg_loss = runner.end_epoch()
             world = tdist.world_info()[1]
             if world > 1:
@@ -377,6 +379,7 @@ class FitRunner:
         self.loss_sums = torch.zeros(max(self.num_batches, 1), dtype=torch.float32, device=self.dev)
         self.next_batch = 0
         self.ep = None
+        self._next_ep = None
         self.prep_out = None
 
     def begin_epoch(self):
@@ -388,11 +391,23 @@ class FitRunner:
         if self.num_batches == 0:
             return
         if m.rng == 'reference':
-            iter(self.loader)  # reshuffle: one torch.randperm per epoch (dataset.py:369-373)
-            self.ep = m._host_epoch(self.data, self.loader)
+            if self._next_ep is not None:  # drawn by prepare_next_epoch() while the previous epoch's steps ran
+                self.ep, self._next_ep = self._next_ep, None
+            else:
+                iter(self.loader)  # reshuffle: one torch.randperm per epoch (dataset.py:369-373)
+                self.ep = m._host_epoch(self.data, self.loader)
         else:
             self.st = m._device_stream('train')
             self.shuffle_key, self.sample_seed = self._epoch_keys(m._fit_epochs_done)
+
+    def prepare_next_epoch(self):
+        """Reference-RNG mode: draw the NEXT epoch's batches (shuffle + sampler, in the reference's RNG order — nothing
+        else consumes the generators in between) right after the current epoch's steps were enqueued, so the host work
+        overlaps the GPU instead of following the epoch's loss read-back.  Only fit() calls this, and only when another
+        epoch follows: the generators are left exactly where the reference leaves them."""
+        if self.m.rng == 'reference' and self.num_batches > 0 and self._next_ep is None:
+            iter(self.loader)
+            self._next_ep = self.m._host_epoch(self.data, self.loader)
 
     def _epoch_keys(self, epochs_done):
         """(shuffle key, sampler seed) of the device-RNG epoch that follows `epochs_done` finished ones."""
