@@ -418,7 +418,7 @@ __global__ __launch_bounds__(TRS_BLOCK) void user_flags_kernel(const KeyT* __res
     const KeyT k = keys[s];
     const int64_t in_seg = s % batch;
     const bool dup = (in_seg > 0 && keys[s - 1] == k) || (in_seg + 1 < batch && keys[s + 1] == k);
-    flags[vals[s]] = dup ? 1 : 0;
+    if (dup) flags[vals[s]] = 1;  // the array was zeroed: only the (few) duplicated positions take a scattered byte store
   }
 }
 
@@ -755,9 +755,11 @@ extern "C" int trs_epoch_user_dups(const int32_t* user_dev, int64_t n_batches, i
       temp_dev, temp, (const uint32_t*)user_dev, kin + n_pos, rocprim::counting_iterator<uint32_t>(0), vin + n_pos,
       (size_t)n_pos, (unsigned)n_batches, seg_it(0, (uint32_t)batch), seg_it(1, (uint32_t)batch), 0u,
       (unsigned)user_bits, s);
-  if (e == hipSuccess)
+  if (e == hipSuccess) {
+    (void)hipMemsetAsync(flags_out_dev, 0, (size_t)n_pos, s);
     hipLaunchKernelGGL((user_flags_kernel<uint32_t>), gr, bl, 0, s, kin + n_pos, vin + n_pos, n_pos, batch,
                        flags_out_dev);
+  }
   if (sorted_ukeys_out) *sorted_ukeys_out = (void*)(kin + n_pos);
   if (ukey_bytes_out) *ukey_bytes_out = 4;
   if (sorted_uvals_out) *sorted_uvals_out = (void*)(vin + n_pos);
