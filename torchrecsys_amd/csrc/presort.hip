@@ -44,6 +44,18 @@ using SegIt = rocprim::transform_iterator<rocprim::counting_iterator<uint32_t>, 
 static inline SegIt seg_it(uint32_t first, uint32_t len) {
   return rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(first), SegBegin{len});
 }
+// The payload of reference 2q + w, (t << 1) | w = (2q + w) mod 2*batch, is not materialised: the item sort reads it
+// through an iterator (8 bytes per triple less to write and to read back).
+struct RefVal {
+  uint32_t per_batch;  // 2 * batch
+  uint32_t mask;       // per_batch - 1 when it is a power of two (no division), else 0
+  __host__ __device__ RefPayload operator()(uint32_t i) const { return RefPayload{mask ? (i & mask) : (i % per_batch)}; }
+};
+using RefValIt = rocprim::transform_iterator<rocprim::counting_iterator<uint32_t>, RefVal>;
+static inline RefValIt ref_val_it(int64_t batch) {
+  const uint32_t pb = (uint32_t)(2 * batch);
+  return rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), RefVal{pb, (pb & (pb - 1)) ? 0u : pb - 1});
+}
 // 9-bit (item rows) / 10-bit (users) digits need >= 512 / 1024 threads; 1024 x 8 measured best for both
 using ItemSortCfg = rocprim::segmented_radix_sort_config<9, rocprim::kernel_config<1024, 8>>;
 using UserSortCfg = rocprim::segmented_radix_sort_config<10, rocprim::kernel_config<1024, 8>>;
@@ -96,13 +108,8 @@ __global__ __launch_bounds__(TRS_BLOCK) void epoch_refs_kernel(const EpochArgs a
       a.pos[q] = (int32_t)i;
       a.neg[q] = (int32_t)j;
     }
-    const int64_t b = q / a.batch;
-    const uint32_t t = (uint32_t)(q - b * a.batch);
     keys[2 * q] = (KeyT)i;
     keys[2 * q + 1] = (KeyT)j;
-    RefPayload v0 = {(t << 1)}, v1 = {(t << 1) | 1u};
-    a.vals[2 * q] = v0;
-    a.vals[2 * q + 1] = v1;
   }
 }
 
@@ -640,9 +647,9 @@ extern "C" int trs_epoch_presort_sizes(int64_t n_batches, int64_t batch, int64_t
   const size_t n = (size_t)(2 * n_batches * batch);
   size_t temp = 0;
   hipError_t e = rocprim::segmented_radix_sort_pairs<ItemSortCfg>(
-      nullptr, temp, (uint32_t*)nullptr, (uint32_t*)nullptr, (RefPayload*)nullptr, (RefPayload*)nullptr, n,
-      (unsigned)n_batches, seg_it(0, (uint32_t)(2 * batch)), seg_it(1, (uint32_t)(2 * batch)), 0u, (unsigned)bits,
-      (hipStream_t)0);
+      nullptr, temp, (uint32_t*)nullptr, (uint32_t*)nullptr,
+      ref_val_it(batch), (RefPayload*)nullptr, n, (unsigned)n_batches, seg_it(0, (uint32_t)(2 * batch)), seg_it(1, (uint32_t)(2 * batch)),
+      0u, (unsigned)bits, (hipStream_t)0);
   TRS_REQUIRE(e == hipSuccess, "trs_epoch_presort_sizes: rocprim size query failed");
   *key_bytes_out = kb;
   *keys_total_bytes_out = 2 * (int64_t)n * kb;
@@ -699,8 +706,9 @@ extern "C" int trs_epoch_presort(const int32_t* stream_ui_dev, const int32_t* ne
   RefPayload* vout = vin + n;
   uint32_t* kin = (uint32_t*)keys_dev;
   hipError_t e = rocprim::segmented_radix_sort_pairs<ItemSortCfg>(
-      temp_dev, temp, kin, kin + n, vin, vout, n, (unsigned)n_batches, seg_it(0, (uint32_t)(2 * batch)),
-      seg_it(1, (uint32_t)(2 * batch)), 0u, (unsigned)bits, s);
+      temp_dev, temp, kin, kin + n,
+      ref_val_it(batch), vout, n,
+      (unsigned)n_batches, seg_it(0, (uint32_t)(2 * batch)), seg_it(1, (uint32_t)(2 * batch)), 0u, (unsigned)bits, s);
   *sorted_keys_out = (void*)(kin + n);
   *sorted_vals_out = (void*)vout;
   if (e != hipSuccess) {
@@ -781,7 +789,6 @@ __global__ __launch_bounds__(TRS_BLOCK) void meta_refs_kernel(const int32_t* __r
                                                              int32_t* __restrict__ neg_meta_out) {
   const int64_t stride = (int64_t)gridDim.x * TRS_BLOCK;
   for (int64_t q = (int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x; q < n_pos; q += stride) {
-    const uint32_t t = (uint32_t)(q % batch);
     int64_t kp = item_meta[(int64_t)pos[q] * M + m], kn = item_meta[(int64_t)neg[q] * M + m];
     if ((uint64_t)kp >= (uint64_t)n_cat || (uint64_t)kn >= (uint64_t)n_cat) {
       if (err) atomicOr(err, 1);
@@ -790,9 +797,6 @@ __global__ __launch_bounds__(TRS_BLOCK) void meta_refs_kernel(const int32_t* __r
     }
     keys[2 * q] = (uint32_t)kp;
     keys[2 * q + 1] = (uint32_t)kn;
-    RefPayload v0 = {(t << 1)}, v1 = {(t << 1) | 1u};
-    vals[2 * q] = v0;
-    vals[2 * q + 1] = v1;
     if (pos_meta_out) {  // (n_pos, M) id arrays for K1: contiguous reads instead of a lookup behind the item id
       pos_meta_out[q * M + m] = (int32_t)kp;
       neg_meta_out[q * M + m] = (int32_t)kn;
@@ -822,8 +826,8 @@ extern "C" int trs_epoch_presort_meta(const int32_t* pos_dev, const int32_t* neg
   TRS_CHECK_LAUNCH("meta_refs_kernel");
   size_t temp = (size_t)temp_bytes;
   hipError_t e = rocprim::segmented_radix_sort_pairs<ItemSortCfg>(
-      temp_dev, temp, kin, kin + n, vin, vin + n, n, (unsigned)n_batches, seg_it(0, (uint32_t)(2 * batch)),
-      seg_it(1, (uint32_t)(2 * batch)), 0u, (unsigned)bits_for(n_cat), s);
+      temp_dev, temp, kin, kin + n, ref_val_it(batch), vin + n, n, (unsigned)n_batches,
+      seg_it(0, (uint32_t)(2 * batch)), seg_it(1, (uint32_t)(2 * batch)), 0u, (unsigned)bits_for(n_cat), s);
   *sorted_keys_out = (void*)(kin + n);
   *sorted_vals_out = (void*)(vin + n);
   if (e != hipSuccess) {
