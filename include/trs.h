@@ -284,6 +284,11 @@ int trs_rows_apply_adagrad(float* table_dev, float* acc_dev, float* state_sum_de
 /* loss_sum += sum_t max(neg-pos+1, 0); auc_count += #(pos > neg).  (helper/loss.py:5-9, evaluate/metrics.py:23-31) */
 int trs_hinge_auc(const float* pos_dev, const float* neg_dev, int64_t B, float* loss_sum_dev,
                   int32_t* auc_count_dev, void* stream);
+/* The same for consecutive batches of `batch` rows of (n_total,) score arrays in one launch: loss_sums_dev[b] /
+ * auc_counts_dev[b] (b < ceil(n_total / batch) <= 65535) accumulate batch b's sums — evaluate()'s per-batch metrics
+ * (model.py:300-330) without one launch and one host round trip per batch. */
+int trs_hinge_auc_batches(const float* pos_dev, const float* neg_dev, int64_t n_total, int64_t batch,
+                          float* loss_sums_dev, int32_t* auc_counts_dev, void* stream);
 /* d(mean hinge)/d(pos), d(.)/d(neg): -a/B, +a/B with a = [neg-pos+1 >= 0] (torch clamp subgradient). */
 int trs_hinge_backward(const float* pos_dev, const float* neg_dev, int64_t B, float inv_B, float* gpos_dev,
                        float* gneg_dev, void* stream);

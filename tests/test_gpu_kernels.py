@@ -239,6 +239,26 @@ def test_hinge_auc():
         assert ac.item() == int((pos > neg).sum())
 
 
+@pytest.mark.parametrize("n,batch", [(1, 1), (1000, 7), (70_001, 512), (300, 1000), (65_536, 1024)])
+def test_hinge_auc_batches(n, batch):
+    """Per-batch hinge sums / AUC counts of consecutive batches in one launch (evaluate()): each slot equals the oracle's
+    batch value; the AUC counts are exact integers."""
+    ops = _ops()
+    rs = np.random.RandomState(n)
+    pos, neg = rs.normal(0, 1, n).astype(np.float32), rs.normal(0, 1, n).astype(np.float32)
+    neg[::5] = pos[::5]  # ties: pos > neg is false
+    nb = -(-n // batch)
+    ls = torch.zeros(nb, dtype=torch.float32, device=DEV)
+    ac = torch.zeros(nb, dtype=torch.int32, device=DEV)
+    ops.hinge_auc_batches(torch.from_numpy(pos).to(DEV), torch.from_numpy(neg).to(DEV), batch, ls, ac)
+    ls, ac = ls.cpu().numpy(), ac.cpu().numpy()
+    for b in range(nb):
+        p, q = pos[b * batch:(b + 1) * batch], neg[b * batch:(b + 1) * batch]
+        want = float(onets.hinge_loss(p, q))
+        assert abs(ls[b] / p.size - want) < 1e-5 * max(1.0, want), b
+        assert ac[b] == int((p > q).sum()), b
+
+
 @pytest.mark.parametrize("n,k", [(1, 1), (37, 10), (4096, 10), (4097, 5), (100_000, 10), (100_000, 2048),
                                  (1_000_003, 100)])
 def test_topk_bit_exact(n, k):

@@ -112,6 +112,7 @@ PROTOTYPES = {
     "trs_epoch_presort": (C.c_int, [_vp, _vp, _i64, _u64, _u64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _i64, _vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp]),
     "trs_hinge_auc": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "trs_hinge_auc_batches": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "trs_hinge_backward": (C.c_int, [_vp, _vp, _i64, _f, _vp, _vp, _vp]),
     "trs_score_all_items": (C.c_int, [C.c_int, _T, _i64, _i64, _i64, _vp, _vp, _vp]),
     "trs_topk_workspace_bytes": (C.c_int64, [_i64, _i32]),

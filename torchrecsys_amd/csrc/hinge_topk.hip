@@ -36,6 +36,42 @@ __global__ __launch_bounds__(TRS_BLOCK) void hinge_auc_kernel(const float* __res
   }
 }
 
+// The same reductions for consecutive batches of `batch` rows in one launch (evaluate(): blockIdx.y = batch).
+__global__ __launch_bounds__(TRS_BLOCK) void hinge_auc_batches_kernel(const float* __restrict__ pos,
+                                                                     const float* __restrict__ neg, int64_t n_total,
+                                                                     int64_t batch, float* loss_sums,
+                                                                     int32_t* auc_counts) {
+  const int64_t b = blockIdx.y;
+  const int64_t t0 = b * batch, t1 = t0 + batch < n_total ? t0 + batch : n_total;
+  float L = 0.f;
+  int A = 0;
+  const int64_t stride = (int64_t)gridDim.x * TRS_BLOCK;
+  for (int64_t t = t0 + (int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x; t < t1; t += stride) {
+    const float p = pos[t], n = neg[t];
+    L += fmaxf(n - p + 1.0f, 0.f);
+    A += (p > n) ? 1 : 0;
+  }
+  __shared__ float s_l[TRS_BLOCK / TRS_WAVE];
+  __shared__ int s_a[TRS_BLOCK / TRS_WAVE];
+  L = trs_wave_sum(L);
+  A = trs_wave_sum_i(A);
+  if ((threadIdx.x & 63) == 0) {
+    s_l[threadIdx.x >> 6] = L;
+    s_a[threadIdx.x >> 6] = A;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float l = 0.f;
+    int a = 0;
+    for (int w = 0; w < TRS_BLOCK / TRS_WAVE; ++w) {
+      l += s_l[w];
+      a += s_a[w];
+    }
+    if (loss_sums && l != 0.f) atomicAdd(loss_sums + b, l);
+    if (auc_counts && a != 0) atomicAdd(auc_counts + b, a);
+  }
+}
+
 __global__ __launch_bounds__(TRS_BLOCK) void hinge_backward_kernel(const float* __restrict__ pos,
                                                                   const float* __restrict__ neg, int64_t B,
                                                                   float inv_B, float* __restrict__ gpos,
@@ -115,6 +151,19 @@ extern "C" int trs_hinge_auc(const float* pos_dev, const float* neg_dev, int64_t
   hipLaunchKernelGGL(hinge_auc_kernel, dim3(trs_grid(B, TRS_BLOCK * 4)), dim3(TRS_BLOCK), 0, (hipStream_t)stream,
                      pos_dev, neg_dev, B, loss_sum_dev, auc_count_dev);
   TRS_CHECK_LAUNCH("hinge_auc_kernel");
+  return TRS_OK;
+}
+
+extern "C" int trs_hinge_auc_batches(const float* pos_dev, const float* neg_dev, int64_t n_total, int64_t batch,
+                                     float* loss_sums_dev, int32_t* auc_counts_dev, void* stream) {
+  TRS_REQUIRE(n_total >= 0 && batch > 0, "trs_hinge_auc_batches: bad sizes");
+  if (n_total == 0) return TRS_OK;
+  TRS_REQUIRE(pos_dev && neg_dev, "trs_hinge_auc_batches: scores are NULL");
+  const int64_t nb = (n_total + batch - 1) / batch;
+  TRS_REQUIRE(nb <= 65535, "trs_hinge_auc_batches: more than 65535 batches in one call");
+  hipLaunchKernelGGL(hinge_auc_batches_kernel, dim3(trs_grid(batch, TRS_BLOCK * 4), (unsigned)nb), dim3(TRS_BLOCK), 0,
+                     (hipStream_t)stream, pos_dev, neg_dev, n_total, batch, loss_sums_dev, auc_counts_dev);
+  TRS_CHECK_LAUNCH("hinge_auc_batches_kernel");
   return TRS_OK;
 }
 

@@ -317,15 +317,20 @@ class TorchRecSys(torch.nn.Module):
         else:
             st = self._device_stream('test')
             sample_seed = _mix64(self.seed, 0xE7A1)
-        for b in range(nb):
-            s, e = b * batch_size, min((b + 1) * batch_size, n_test)
+        # Linear / FM score triples independently of their batch: several batches per launch (ids, scores, per-batch
+        # reductions, one id-range check per group); the MLP's activations are per batch
+        group = 64 if hasattr(self.net, 'table_params') else 1
+        group = max(1, min(group, (1 << 22) // max(batch_size, 1)))
+        for b0 in range(0, nb, group):
+            b1 = min(b0 + group, nb)
+            s, e = b0 * batch_size, min(b1 * batch_size, n_test)
             if self.rng == 'reference':
                 ids = {k: v[s:e] for k, v in ep.items()}
             else:
                 ids = ops.batch_prepare(st['user'], st['pos'], st['neg'], 0, s, e - s, self.n_items, sample_seed, s,
                                         st['item_meta'])
             pos, neg = self.net.score_ids(ids)
-            ops.hinge_auc(pos, neg, loss_sums[b:b + 1], auc_counts[b:b + 1])
+            ops.hinge_auc_batches(pos, neg, batch_size, loss_sums[b0:b1], auc_counts[b0:b1])
         ls, ac = loss_sums.cpu().numpy(), auc_counts.cpu().numpy()
         sizes = [min((b + 1) * batch_size, n_test) - b * batch_size for b in range(nb)]
         results = {}

@@ -301,6 +301,12 @@ def hinge_auc(pos, neg, loss_sum, auc_count):
           "trs_hinge_auc")
 
 
+def hinge_auc_batches(pos, neg, batch, loss_sums, auc_counts):
+    """Per-batch hinge sums / AUC counts of consecutive `batch`-row pieces of pos / neg into loss_sums[b], auc_counts[b]."""
+    check(_lib.load().trs_hinge_auc_batches(ptr(pos), ptr(neg), pos.numel(), batch, ptr(loss_sums), ptr(auc_counts),
+                                            _stream()), "trs_hinge_auc_batches")
+
+
 def hinge_backward(pos, neg):
     B = pos.numel()
     gp, gn = torch.empty_like(pos), torch.empty_like(neg)
