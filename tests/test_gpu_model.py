@@ -469,3 +469,24 @@ def test_bench_line_contract():
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0.0 < r["frac"] < 1.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == d["unit"] and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+
+
+@pytest.mark.parametrize("net_type", ["linear", "fm", "mlp"])
+def test_predict_many_equals_predict(net_type):
+    """predict_many (extension): every row is predict() of that user, bit for bit."""
+    from torchrecsys_amd.model import TorchRecSys
+    rs = np.random.RandomState(2)
+    n_u, n_i, n = 50, 333, 2000
+    df = pd.DataFrame({"user_id": np.concatenate([np.arange(n_u), rs.randint(0, n_u, n - n_u)]),
+                       "item_id": np.concatenate([np.arange(n_i), rs.randint(0, n_i, n - n_i)])})
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = TorchRecSys(df, "user_id", "item_id", n_factors=16, net_type=net_type)
+        users = [0, 7, 49, 7]
+        many = model.predict_many(users, top_k=12)
+        single = [model.predict(u, top_k=12) for u in users]
+    assert many.shape == (4, 12) and many.dtype == torch.int64 and not many.is_cuda
+    for r in range(4):
+        assert torch.equal(many[r], single[r])
+    assert model.predict_many([], top_k=5).shape == (0, 5)
+    with pytest.raises(IndexError):
+        model.predict_many([0, n_u], top_k=3)

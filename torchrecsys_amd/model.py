@@ -363,6 +363,22 @@ class TorchRecSys(torch.nn.Module):
         return ops.topk(scores, k).cpu()
 
 
+    @_host_side
+    def predict_many(self, user_ids, top_k: int = 10):
+        """Extension: predict() for several users — row r of the (len(user_ids), top_k) int64 CPU tensor
+        equals `predict(user_ids[r], top_k)`; the per-user kernels are queued back to back and read back once."""
+        self.net = self.net.eval()
+        k = min(int(top_k), self.n_items)
+        users = [int(u) for u in (user_ids.tolist() if hasattr(user_ids, "tolist") else user_ids)]
+        if k <= 0 or not users:
+            return torch.empty((len(users), max(k, 0)), dtype=torch.int64)
+        meta = self._item_meta_dev()
+        out = torch.empty((len(users), k), dtype=torch.int64, device=_device())
+        for r, u in enumerate(users):
+            out[r] = ops.topk(self.net.score_all_items(u, meta), k)
+        return out.cpu()
+
+
 class FitRunner:
     """One training run at a fixed batch size: owns the optimiser plan, the staging buffers and the per-epoch batch
     feed.  begin_epoch() -> run_steps(k) (any number of calls) -> end_epoch()."""
