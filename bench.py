@@ -7,8 +7,10 @@
 
 A "step" is one pass of the training hot path over one batch of synthetic interactions already resident in HBM:
 epoch-shuffle slice + dynamic negative sampling -> fused embedding gather + FM pairwise scoring + hinge + backward ->
-sparse embedding-row SGD update.  The item references of every 256 batches are grouped by row once
-(trs_epoch_presort); that work runs INSIDE the timed region at its true rate (default 1024 timed steps = 4 slices).  Workload (BASELINE.json configs[1], SURVEY §8d "c2"): net_type='fm',
+sparse embedding-row SGD update.  The item references and user ids of every 512 batches are grouped by row once
+(trs_epoch_presort / trs_epoch_user_dups, on a side stream); that work runs INSIDE the timed region at its true rate
+(default 1024 timed steps = 2 slices).  Per-kernel HIP events are recorded on one step in 29 (a sampled step runs about
+20 us longer); --no-kernel-events drops them and the roofline object.  Workload (BASELINE.json configs[1], SURVEY §8d "c2"): net_type='fm',
 1M users x 100K items x 100M interactions (80M train triples after the 0.8 split), dim=64, dynamic_neg_sampling=True,
 batch 65 536, torch.optim.SGD(lr=1e-2), fp32.  metric = training interactions/s (pos+neg) = 2 x triples/s.
 
