@@ -7,16 +7,22 @@
 
 A "step" is one pass of the training hot path over one batch of synthetic interactions already resident in HBM:
 epoch-shuffle slice + dynamic negative sampling -> fused embedding gather + FM pairwise scoring + hinge + backward ->
-sparse embedding-row SGD update.  The item references and user ids of every 512 batches are grouped by row once
-(trs_epoch_presort / trs_epoch_user_dups, on a side stream); that work runs INSIDE the timed region at its true rate
-(default 1024 timed steps = 2 slices).  Per-kernel HIP events are recorded on one step in 29 (a sampled step runs about
-20 us longer); --no-kernel-events drops them and the roofline object.  Workload (BASELINE.json configs[1], SURVEY §8d "c2"): net_type='fm',
-1M users x 100K items x 100M interactions (80M train triples after the 0.8 split), dim=64, dynamic_neg_sampling=True,
-batch 65 536, torch.optim.SGD(lr=1e-2), fp32.  metric = training interactions/s (pos+neg) = 2 x triples/s.
+sparse embedding-row SGD update.  Default workload at EVERY N (BASELINE.json's metric is quoted on it: configs[3],
+SURVEY 8d "c4"): net_type='fm', 10M users x 1M items, dim=128, dynamic_neg_sampling=True, per-GPU batch 32 768 (global
+batch 262 144 at 8 GPUs), every rank an independent 125M-interaction shard of the 1B stream (weak scaling),
+torch.optim.SGD(lr=1e-2), fp32.  --config c2 | c1 | c3 | c5 select BASELINE.json's other configurations.
+metric = training interactions/s (pos+neg) = 2 x triples/s.
 
-Multi-GPU: one process per GPU; the interaction stream is sharded across ranks (each rank owns an
-independent 100M-interaction shard, weak scaling: per-GPU batch fixed); embedding tables are replicated and the FM has
-no dense parameters, so the step has no data-path collective.  Rank 0 prints ONE JSON line.
+What the timed region contains: exactly K steps through FitRunner.run_steps — the object fit() is built on — incl. the
+per-slice grouping of item references / user ids (trs_epoch_presort / trs_epoch_user_dups, prefetched on a side stream;
+slices are sized to the run so a short run carries its proportional share).  NO kernel events are recorded in it.
+After it, untimed: (1) an instrumented window of the same steps with HIP events around K1 / K2 on the launch stream
+(>= 8 samples whatever --steps is) -> `roofline` of the dominant kernel; (2) the north-star pass alone
+(trs_score_forward = fused pos+neg gather + FM pairwise score) at the per-GPU batch and at the global batch 262 144
+-> `roofline_pass`; (3) rank 0, N=1: the CPU port of the reference's loop on a bounded sample -> `cpu_baseline`.
+
+Multi-GPU: one process per GPU; tables replicated; FM/Linear have no dense parameters, so a step has no
+data-path collective.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -74,17 +80,103 @@ def synth_stream(n_users, n_items, n, device, seed):
     return users[perm].contiguous(), items[perm].contiguous()
 
 
+def slice_fractions(runner):
+    """Shares of the row references of the presort slice in use that are alone on their row inside their batch (K1
+    updates them in place) — what the exact per-kernel byte counts below depend on.  None off the presorted path."""
+    tr = runner.trainer
+    ps = tr._ps_sets[tr._ps_cur] if getattr(tr, "_ps_sets", None) else None
+    if ps is None:
+        return None
+    n = ps.n_batches * ps.batch
+    return {"users_alone": 1.0 - float(ps.user_dup[:n].float().mean()),
+            "item_refs_alone": 1.0 - float(ps.item_dup[:n].float().mean()),
+            "triples_staging_user_row": float((ps.item_dup[:n].amax(dim=1) > 0).float().mean())}
+
+
+def kernel_algorithmic_bytes(R, row, state_rows, seen, frac):
+    """Algorithmic bytes per triple of each step kernel (DESIGN.md "Kernels"): every row a kernel must read counted
+    once, every row it must write counted once, ids and per-triple scalars; no staging traffic is credited."""
+    inline_user = "sorted_updates_fused_kernel" in seen or "sorted_item_update_kernel" in seen
+    ua = frac["users_alone"] if frac else 1.0       # K1 writes these user rows itself
+    ia = frac["item_refs_alone"] if (frac and state_rows == 0 and R == 3) else 0.0  # ... and these item rows
+    k1 = 16 + R * row + 8 + ((ua + 2 * ia) * (1 + 2 * state_rows) * row if inline_user else 0)
+    # K2 (sorted runs): reads ids/coefficients, reads + writes the item rows K1 left (at most one row per reference:
+    # an upper bound of the distinct rows) and the user rows of duplicated users
+    k2 = 12 + ((2 * (1 - ia)) * 2 + (1 - ua) * 2) * (1 + state_rows) * row
+    return {"score_kernel<fwd_bwd>": 16 + R * row + 8, "score_sgd_update_kernel": 12 + R * row,
+            "fwd_stage_kernel": k1, "item_update_kernel": 12 + 3 * row, "sorted_item_update_kernel": 12 + 3 * row,
+            "sorted_updates_fused_kernel": k2, "user_update_kernel": 4 + row, "sorted_user_dup_update_kernel": 4 + row}
+
+
+def time_pass(model, runner, B, D, R, dev):
+    """The north-star pass by itself at this config's tables: trs_score_forward (pair_scores_kernel: fused positive +
+    negative embedding gather + FM / Linear pairwise score, read-only).  Every launch scores DIFFERENT triples (fresh
+    rows: nothing is served from a previous launch's cache footprint); 8 groups of 10 back-to-back launches, one HIP
+    event pair per group on the launch stream, at the per-GPU batch and at BASELINE's global batch 262 144."""
+    st = runner.st
+    n_items = model.n_items
+    per = 16 + R * (4 * D + 4) + 8  # SURVEY 8d: ids, R rows + 1-wide terms, two scores out
+    res = {"kernel": "pair_scores_kernel", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "algorithmic_bytes_per_triple": per, "shapes": {}}
+    groups, per_group = 8, 10
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    for Bp in sorted({B, 262_144}):
+        need = (groups * per_group + 3) * Bp
+        if need > st["user"].shape[0]:
+            continue
+        neg = torch.randint(0, n_items, (need,), device=dev, dtype=torch.int32, generator=g)
+        import ctypes as C
+        from torchrecsys_amd import _lib, ops
+        lib, T = _lib.load(), model.net.tables()
+        err = torch.zeros(1, dtype=torch.int32, device=dev)
+        pos_s, neg_s = torch.empty(Bp, device=dev), torch.empty(Bp, device=dev)
+        bts = [ops.make_batch(st["user"][k * Bp:(k + 1) * Bp], st["pos"][k * Bp:(k + 1) * Bp],
+                              neg[k * Bp:(k + 1) * Bp], None, None, err) for k in range(groups * per_group + 3)]
+        net_id = ops.NET_ID[model.net.NET]
+
+        def launch(k):  # one C-ABI call = one kernel launch on torch's current stream; no allocation, no sync
+            _lib.check(lib.trs_score_forward(net_id, C.byref(T), C.byref(bts[k][0]), ops.ptr(pos_s), ops.ptr(neg_s),
+                                             ops._stream()), "trs_score_forward")
+        for k in range(3):
+            launch(k)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(groups)]
+        k = 3
+        for e0, e1 in evs:
+            e0.record()
+            for _ in range(per_group):
+                launch(k)
+                k += 1
+            e1.record()
+        torch.cuda.synchronize()
+        us = [1e3 * e0.elapsed_time(e1) / per_group for e0, e1 in evs]
+        mean_us = sum(us) / len(us)
+        ach = per * Bp / (mean_us * 1e-6) / 1e9
+        res["shapes"][f"B={Bp}"] = {"mean_launch_us": mean_us, "min_group_us": min(us), "max_group_us": max(us),
+                                    "achieved": ach, "frac": ach / HBM_PEAK_GBS, "samples": groups,
+                                    "launches": groups * per_group}
+        assert int(err.item()) == 0, "an id outside its table in the pass measurement"
+        del neg, bts
+    if f"B={B}" in res["shapes"]:
+        res["achieved"] = res["shapes"][f"B={B}"]["achieved"]
+        res["frac"] = res["shapes"][f"B={B}"]["frac"]
+    res["note"] = "launch-to-launch intervals of back-to-back C-ABI calls (launch gaps and 1/10 event record included)"
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1024)
     ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="c4", choices=sorted(CONFIGS),
+                    help="c4 (default at every N): the workload BASELINE.json's metric and scaling target are quoted on")
     ap.add_argument("--optimizer", default="sgd", choices=["sgd", "sparse_adam", "adagrad", "adam"],
                     help="sgd = BASELINE.json's primary optimiser; sparse_adam (lazy Adam) / adagrad = secondary; adam = "
                          "torch.optim.Adam as in the reference's README (lazy rows on the tables, dense Adam on the MLP)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-events", action="store_true", help="skip per-kernel HIP event timing")
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip the instrumented window (no roofline)")
+    ap.add_argument("--no-pass", action="store_true", help="skip the north-star pass measurement (no roofline_pass)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -139,6 +231,16 @@ def main():
     if args.optimizer != "sgd":
         desc = desc.replace("SGD(lr=1e-2)", {"sparse_adam": "SparseAdam(lr=1e-3)", "adagrad": "Adagrad(lr=1e-2)",
                                              "adam": "Adam(lr=1e-3)"}[args.optimizer])
+    # Presort slices sized to the run: a slice's grouping work is prefetched on a side stream while the previous slice's
+    # steps run, so a run much shorter than the production slice (512 batches) would otherwise be charged a whole
+    # slice's sort; with slices no longer than the run the timed steps carry their proportional share.
+    is_mlp = net == "mlp"
+    if not is_mlp and "TRS_SLICE_BATCHES" not in os.environ:
+        from torchrecsys_amd.engine import SparseScorerTrainer
+        sl = 8
+        while sl * 2 <= min(512, max(args.steps, 8)):
+            sl *= 2
+        SparseScorerTrainer.SLICE_BATCHES = sl
     runner = model.make_runner(opt, B)
     model.net.train()
 
@@ -164,36 +266,44 @@ def main():
 
     run(args.warmup)
     barrier()
-    is_mlp = net == "mlp"
+    t0 = time.perf_counter()
+    run(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- instrumented window (untimed): the same steps with HIP events around the kernels, on the launch stream ----
+    events, gemm_events = {}, None
     if not args.no_kernel_events:
+        n_inst = 64 if is_mlp else 256
         if is_mlp:
             model.net.compute.gemm_events = []
             model.net.compute.gemm_steps_seen = model.net.compute.gemm_steps_timed = 0
         else:
             runner.trainer.kernel_events = {}
-    t0 = time.perf_counter()
-    run(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    events = (getattr(runner.trainer, "kernel_events", None) or {}) if not is_mlp else {}
-    gemm_events = model.net.compute.gemm_events if is_mlp else None
-    if is_mlp:
-        model.net.compute.gemm_events = None
-    else:
-        runner.trainer.kernel_events = None
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+            runner.trainer.EVENT_EVERY = 7  # 36 sampled steps of 256 (a prime stride: never in phase with the C calls)
+        run(n_inst)
+        torch.cuda.synchronize()
+        if is_mlp:
+            gemm_events = model.net.compute.gemm_events
+            model.net.compute.gemm_events = None
+        else:
+            events = runner.trainer.kernel_events or {}
+            runner.trainer.kernel_events = None
+    frac = slice_fractions(runner) if not is_mlp else None
     runner.end_epoch()  # also raises if any id was out of range
 
     triples = args.steps * B * world
     value = 2.0 * triples / elapsed
     M = len(cfg["meta"])
     R = 3 + 2 * M
-    step_bytes = 16 + 2 * R * (4 * D + 4)  # FM/Linear fused SGD step, rows read once + written once
+    row = 4 * D + 4  # one embedding row + its 1-wide term
+    step_bytes = 16 + 2 * R * row  # FM/Linear fused SGD step, rows read once + written once
     state_rows = {"sgd": 0, "sparse_adam": 2, "adagrad": 1, "adam": 2}[args.optimizer]  # state tables read + written per row
-    step_bytes += 2 * state_rows * R * (4 * D + 4)
+    step_bytes += 2 * state_rows * R * row
     dtype = "bf16" if cfg["amp"] else "f32"
     out = {
         "metric": "training interactions/sec (pos+neg)", "value": value, "unit": "interactions/s",
@@ -208,6 +318,8 @@ def main():
     }
     if not is_mlp:
         out["step_algorithmic_GBps_per_gpu"] = step_bytes * B * args.steps / elapsed / 1e9
+        out["step_frac_of_hbm_peak"] = out["step_algorithmic_GBps_per_gpu"] / HBM_PEAK_GBS
+        out["step_algorithmic_bytes_per_triple"] = step_bytes
     # ---- MLP: the GEMMs are the dominant kernels, bound by the matrix cores ----
     if gemm_events:
         dims = [(2 + M) * D] + list(cfg["hidden"])
@@ -225,49 +337,50 @@ def main():
                            "timed_steps": timed_steps,
                            "algorithmic_flops_per_triple": 12 * P,
                            "whole_step_TFLOPs": 12.0 * P * B * args.steps / elapsed / 1e12,
-                           "note": "event intervals around the GEMM launches (HIP events on the launch stream); they "
-                                   "include one event record each"}
+                           "note": "event intervals around the GEMM launches (HIP events on the launch stream) in an "
+                                   "instrumented window right after the timed region; they include one event record each"}
     # ---- roofline of the dominant kernel: algorithmic bytes per launch / mean launch duration (HIP events) ----
     if events:
         def _ms(rec):  # (TimingEvents, i, j) from the C step loop, or (torch start, torch end) from the generic path
             return rec[0].elapsed_ms(rec[1], rec[2]) if len(rec) == 3 else rec[0].elapsed_time(rec[1])
+        n_samples = {k: len(v) for k, v in events.items()}
         raw_ms = {k: sum(_ms(r) for r in v) / len(v) for k, v in events.items()}
         # An interval between two hipEventRecords contains the second record's own cost (a barrier packet + timestamp
         # write).  On the presorted path the last two events of a step are recorded back to back, so an upper bound of
-        # that cost is measured live (two barrier packets in a row are slower than one behind a kernel).  `achieved` is
-        # computed from the RAW intervals (conservative: rocprofv3's kernel durations in profiles/ are a little shorter);
-        # the intervals minus the measured record cost are reported beside them as the lower bound.
+        # that cost is measured live.  `achieved` is computed from the RAW intervals (conservative: rocprofv3's kernel
+        # durations in profiles/ are shorter); the intervals minus the measured record cost are reported beside them.
         ev_ms = raw_ms.pop("event_overhead", 0.0)
+        n_samples.pop("event_overhead", None)
         mean_ms = dict(raw_ms)
         dom = max(mean_ms, key=mean_ms.get)
-        row = 4 * D + 4  # one embedding row + its 1-wide term
-        inline_user = "sorted_updates_fused_kernel" in mean_ms or "sorted_item_update_kernel" in mean_ms
-        # algorithmic bytes per triple of each kernel (DESIGN.md "Kernels"): the forward+backward pass reads the ids and
-        # the R rows once and writes the two loss-gradient scalars; the update passes write the R rows once
-        per_triple = {"score_kernel<fwd_bwd>": 16 + R * row + 8, "score_sgd_update_kernel": 12 + R * row,
-                      # fast path (csrc/fast_step.hip): K1 reads the ids + R rows; on the presorted path it also writes
-                      # the user row (users referenced once per batch are updated in place by K1)
-                      "fwd_stage_kernel": 16 + R * row + 8 + ((1 + 2 * state_rows) * row if inline_user else 0),
-                      # item updates: write the 2 item rows (+ read and write their state rows), need the user row
-                      "item_update_kernel": 12 + 3 * row, "sorted_item_update_kernel": 12 + 3 * row,
-                      "sorted_updates_fused_kernel": 12 + 3 * row + 2 * 2 * state_rows * row,
-                      "user_update_kernel": 4 + row, "sorted_user_dup_update_kernel": 4 + row}
+        per_triple = kernel_algorithmic_bytes(R, row, state_rows, mean_ms, frac)
         ach = per_triple[dom] * B / (mean_ms[dom] * 1e-3) / 1e9
-        # measured HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
-        # corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py); valid for the c2 workload on one GPU only
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if args.config == "c2" and os.path.exists(pmc_path):
+        # measured HBM bytes per launch of that kernel: rocprofv3 PMC passes of THIS command committed under profiles/
+        # (FETCH_SIZE / WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py).
+        # A constant read from that file, not a live measurement: named in traffic_source; null when no profile of the
+        # running config exists.
+        traffic, traffic_source = None, None
+        pmc_path = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_{args.config}.json")
+        if world == 1 and args.optimizer == "sgd" and os.path.exists(pmc_path):
             pk = json.load(open(pmc_path))["kernels"]
             parts = {"item_update_kernel": ("item_owner_update_kernel", "item_update_kernel")}.get(dom, (dom,))
             if all(q in pk for q in parts):
                 traffic = sum(pk[q]["traffic_bytes_per_launch"] for q in parts)
+                traffic_source = f"profiles/r02_pmc_traffic_{args.config}.json (rocprofv3 --pmc, not measured in this run)"
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                           "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                           "samples": n_samples[dom],
                            "mean_launch_us": {k: 1e3 * v for k, v in mean_ms.items()},
                            "mean_launch_us_minus_event_record": {k: 1e3 * max(v - ev_ms, 0.0) for k, v in mean_ms.items()},
                            "event_record_overhead_us": 1e3 * ev_ms,
-                           "algorithmic_bytes_per_triple": per_triple[dom]}
+                           "algorithmic_bytes_per_triple": per_triple[dom],
+                           "algorithmic_bytes_per_triple_all": {k: per_triple[k] for k in mean_ms if k in per_triple},
+                           "row_reference_fractions": frac,
+                           "note": "HIP events on the launch stream, one step in 7 of a 256-step instrumented window "
+                                   "that follows the timed region (the timed region itself records no events)"}
+    # ---- the north-star pass alone: fused pos+neg gather + pairwise score (trs_score_forward), read-only ----
+    if not is_mlp and not args.no_pass and M == 0:
+        out["roofline_pass"] = time_pass(model, runner, B, D, R, dev)
     # ---- CPU baseline: the op-sequence port of the reference's fit() loop on this box's host cores ----
     # (torch.optim.Adam rejects the sparse gradients of the CPU port's nn.Embedding(sparse=True): no CPU leg for it)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.optimizer != "adam":

@@ -76,7 +76,10 @@ typedef struct trs_batch {
 
 /* ---------------------------------------------------------------------------------------------- misc */
 const char* trs_last_error(void);
-/* ABI version of this header; bump on any signature change. */
+/* ABI version of this header; bump on ANY signature or struct-layout change.  The ctypes binding refuses a library
+ * whose trs_abi_version() differs (torchrecsys_amd/_lib.py::load), tests/test_abi.py checks the three copies agree.
+ *   1: round 1.   2: trs_train_steps_sgd takes a trs_train_args struct; trs_epoch_presort writes item-duplicate flags. */
+#define TRS_ABI_VERSION 2
 int trs_abi_version(void);
 /* 0 if the current HIP device is gfx950, TRS_E_DEVICE otherwise. */
 int trs_check_device(void);
@@ -214,16 +217,51 @@ int trs_epoch_presort_meta(const int32_t* pos_dev, const int32_t* neg_dev, int64
                            void** sorted_keys_out, void** sorted_vals_out, int32_t* pos_meta_out_dev,
                            int32_t* neg_meta_out_dev, void* stream);
 int64_t trs_train_scratch_bytes(int64_t n_users, int64_t n_items, int64_t batch, int32_t D);
-int trs_train_steps_sgd(int net, const trs_tables* tables, const int32_t* stream_ui_dev,
-                        const int32_t* neg_static_dev, int64_t N,
-                        uint64_t shuffle_key, uint64_t sample_seed, int64_t first_pos, int64_t batch, int32_t n_steps,
-                        float lr, int32_t* user_buf_dev, int32_t* pos_buf_dev, int32_t* neg_buf_dev,
-                        float* gz_buf_dev, float* du_buf_dev, float* loss_sums_dev, int32_t* err_flag_dev,
-                        void* scratch_dev, uint32_t first_stamp, const void* sorted_keys_dev,
-                        const void* sorted_vals_dev, int32_t key_bytes, const uint8_t* user_dup_flags_dev,
-                        float* ustage_buf_dev, const void* sorted_ukeys_dev, const void* sorted_uvals_dev,
-                        int32_t ukey_bytes, int64_t slice_pos0, const trs_opt* opt, const trs_meta_stage* meta,
-                        void** events, void* stream);
+/* Arguments of trs_train_steps_sgd (one struct instead of a 33-long positional list: a caller built against another
+ * revision fails the trs_abi_version() check instead of shifting device pointers by one slot).  Zero-initialise, then
+ * fill the groups that apply. */
+typedef struct trs_train_args {
+  int32_t net;               /* TRS_NET_LINEAR | TRS_NET_FM */
+  int32_t n_steps;
+  const trs_tables* tables;
+  int64_t batch;
+  float lr;                  /* plain SGD (opt == NULL) */
+  uint32_t first_stamp;      /* with scratch: step counter of the first step, non-zero, strictly increasing */
+  /* ids: derived from the resident stream (stream_ui != NULL; {user,item} int32 pairs, (N,2)) or given in the buffers */
+  const int32_t* stream_ui_dev;
+  const int32_t* neg_static_dev;
+  int64_t N;
+  uint64_t shuffle_key;
+  uint64_t sample_seed;
+  int64_t first_pos;
+  int32_t* user_buf_dev;     /* (batch) outputs when derived; (n_steps*batch) inputs otherwise */
+  int32_t* pos_buf_dev;
+  int32_t* neg_buf_dev;
+  /* staging and results */
+  float* gz_buf_dev;         /* (2, batch) */
+  float* du_buf_dev;         /* (batch, D) */
+  float* loss_sums_dev;      /* (n_steps), accumulated */
+  int32_t* err_flag_dev;
+  void* scratch_dev;         /* NULL or trs_train_scratch_bytes(...) bytes, zeroed once */
+  /* presorted two-launch step (trs_epoch_presort / trs_epoch_user_dups outputs, offset to the call's first batch) */
+  const void* sorted_keys_dev;
+  const void* sorted_vals_dev;
+  int32_t key_bytes;
+  int32_t ukey_bytes;
+  const uint8_t* user_dup_flags_dev; /* (n_steps*batch) 1: the triple's user has another reference in its batch */
+  const uint8_t* item_dup_flags_dev; /* (n_steps*batch, 2) NULL, or per triple {pos, neg}: 1 = the item row has another
+                                        reference in the batch.  Given (plain SGD, no metadata): K1 also applies the
+                                        item update of every reference that is ALONE on its row in place, and the
+                                        sorted-run launch only walks rows referenced more than once */
+  float* ustage_buf_dev;     /* (batch, D) */
+  const void* sorted_ukeys_dev;
+  const void* sorted_uvals_dev;
+  int64_t slice_pos0;
+  const trs_opt* opt;        /* NULL: plain SGD */
+  const trs_meta_stage* meta;/* NULL iff tables->M == 0 */
+  void** events;             /* NULL, or 4*n_steps hipEvent_t handles (a step whose handles are NULL is not timed) */
+} trs_train_args;
+int trs_train_steps_sgd(const trs_train_args* args, void* stream);
 
 /* Epoch-level grouping of the item references by row.  trs_epoch_presort covers n_batches whole batches starting at
  * epoch position first_pos: it writes the triples' ids (generated from the resident stream exactly as
@@ -232,7 +270,10 @@ int trs_train_steps_sgd(int net, const trs_tables* tables, const int32_t* stream
  * (uint32), t = position inside the batch).  Passing the sorted arrays (offset to the first batch of the call) to
  * trs_train_steps_sgd together with the id arrays replaces K2a/K2b by one atomic-free launch: each run of equal keys is
  * summed by one lane group and applied with a plain whole-row read-modify-write (runs are cut every 64 references; cut
- * pieces of hot rows use float atomics).  Buffers: keys/vals two halves each (sizes from trs_epoch_presort_sizes). */
+ * pieces of hot rows use float atomics).  Buffers: keys/vals two halves each (sizes from trs_epoch_presort_sizes).
+ * item_dup_flags_out_dev (optional, 2*n_batches*batch bytes): byte 2q+w = 1 iff the item row of reference w (0 positive,
+ * 1 negative) of position q is referenced again inside q's batch — neighbour compare on the sorted keys, scattered back
+ * by payload (trs_train_args.item_dup_flags_dev). */
 /* Per-position flags of an epoch slice: 1 iff the triple's user is referenced by another triple of the same batch
  * (segmented sort of the user ids, one segment per batch).  Passing them (offset to the first batch) with a (batch,D) staging buffer to
  * trs_train_steps_sgd in presorted mode lets K1 apply the user update itself for users referenced once in the batch
@@ -251,7 +292,7 @@ int trs_epoch_presort(const int32_t* stream_ui_dev, const int32_t* neg_static_de
                       uint64_t sample_seed, int64_t first_pos, int64_t n_batches, int64_t batch, int64_t n_users,
                       int64_t n_items, int32_t* user_dev, int32_t* pos_dev, int32_t* neg_dev, void* keys_dev,
                       void* vals_dev, void* temp_dev, int64_t temp_bytes, int32_t* err_flag_dev,
-                      void** sorted_keys_out, void** sorted_vals_out, void* stream);
+                      void** sorted_keys_out, void** sorted_vals_out, uint8_t* item_dup_flags_out_dev, void* stream);
 
 /* ---------------------------------------------------------------- sparse row optimisers (a7, App. A.5) */
 /* table[idx[t]] += alpha * vals[t]  for t < n, rows of D floats, vals row t at vals + t*ld.  Float atomics, one
@@ -298,8 +339,10 @@ int trs_hinge_backward(const float* pos_dev, const float* neg_dev, int64_t B, fl
  * only).  item_meta (n_items,M) int32 gives each item's metadata ids (NULL when M == 0). */
 int trs_score_all_items(int net, const trs_tables* tables, int64_t user_id, int64_t item0, int64_t n,
                         const int32_t* item_meta_dev, float* score_out_dev, void* stream);
-/* Top-k of scores (n,) by (score descending, index ascending) -> idx_out (k,) int64.  workspace: at least
- * trs_topk_workspace_bytes(n, k) bytes.  (torch.sort(descending=True)[:top_k], model.py:447-450) */
+/* Top-k of scores (n,) by (score descending, index ascending) -> idx_out (k,) int64, any 1 <= k <= n.  workspace: at
+ * least trs_topk_workspace_bytes(n, k) bytes.  (torch.sort(descending=True)[:top_k], model.py:447-450)
+ * k <= 2048: per-chunk bitonic selection (4096 keys in LDS, iterated); larger k: a full bitonic sort of the padded keys
+ * in global memory (the reference sorts all scores for any top_k). */
 int64_t trs_topk_workspace_bytes(int64_t n, int32_t k);
 int trs_topk(const float* scores_dev, int64_t n, int32_t k, int64_t* idx_out_dev, void* workspace_dev,
              int64_t workspace_bytes, void* stream);

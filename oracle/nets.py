@@ -199,6 +199,111 @@ def mlp_backward(params, user, item, meta, g, cache, training=True):
     return grads
 
 
+# ----------------------------------------------------------------------------------------------- MLP, bf16-resident
+def bf16_round(a):
+    """Round-to-nearest-even to bfloat16, returned as float32 (what the kernels store in a bf16 image)."""
+    a = np.ascontiguousarray(a, F32)
+    u = a.view(np.uint32).astype(np.uint64)
+    r = ((u >> np.uint64(16)) & np.uint64(1)) + np.uint64(0x7FFF)
+    return ((u + r) & np.uint64(0xFFFF0000)).astype(np.uint32).view(F32).reshape(a.shape)
+
+
+def _mm(a, b):
+    """fp32-accumulated product of bf16-valued operands: products are exact in fp32, the sum is taken in float64 and
+    rounded once (the MFMA's fp32 accumulation order is not restated; it differs at the 1e-7 level)."""
+    return (a.astype(np.float64) @ b.astype(np.float64)).astype(F32)
+
+
+def mlp_train_step_bf16(params, batch, rnd=bf16_round, y_bf16=True):
+    """use_amp=True on tile-aligned nets (torchrecsys_amd/mlp_engine.py, the bf16-RESIDENT path): the arithmetic of
+    mlp_forward / mlp_backward with a rounding to bf16 at exactly the points where the product path keeps a bf16 image
+    in HBM — the gathered input x_0, every weight image W_l (forward and input gradient), the pre-BN outputs y_l (when
+    their statistics come from the fp32 accumulators of the same launch: y_bf16; statistics are taken BEFORE the
+    rounding), the layer inputs x_l (l < L; the last one feeds the fp32 H -> 1 dot), the BN-backward outputs dy_l and
+    the input gradients dx_l (l > 0; dx_0 = the embedding gradient stays fp32).  Bias / gamma / beta gradients and dW
+    are fp32 sums.  rnd=identity restates the fp32 path (tests/test_oracle_golden.py pins that against the fp32
+    functions above, which the reference's golden vectors pin).  The reference's own AMP is fp16 autocast + GradScaler
+    and CUDA-only (model.py:86-88,192-195): there is no reference output to pin the ROUNDED variant to — it is this
+    repository's statement of where it rounds.
+    Returns (pos, neg, loss, grads) like train_forward_backward; running statistics in `params` are updated."""
+    L, M, use_bn = _mlp_dims(params)
+    u, p, n = batch["user_id"], batch["pos_item_id"], batch["neg_item_id"]
+    pm, nm = batch.get("pos_metadata_id"), batch.get("neg_metadata_id")
+    W = [rnd(params[f"fcs.{l}.weight"]) for l in range(L)]
+
+    def forward(item, meta):
+        cols = [params["user.weight"][u], params["item.weight"][item]]
+        for m in range(M):
+            cols.append(params[f"metadata_embeddings.{m}.weight"][meta[:, m]])
+        x = rnd(np.concatenate(cols, axis=1))
+        c = {"x": [x], "y": [], "mu": [], "invstd": []}
+        B = x.shape[0]
+        for l in range(L):
+            y = (_mm(x, W[l].T) + params[f"fcs.{l}.bias"]).astype(F32)
+            mu = invstd = None
+            if use_bn:
+                y64 = y.astype(np.float64)
+                mu = y64.mean(axis=0).astype(F32)
+                var = y64.var(axis=0).astype(F32)
+                unb = (var * F32(B) / F32(max(B - 1, 1))).astype(F32)
+                rm, rv = params[f"bns.{l}.running_mean"], params[f"bns.{l}.running_var"]
+                rm[...] = (F32(1) - BN_MOMENTUM) * rm + BN_MOMENTUM * mu
+                rv[...] = (F32(1) - BN_MOMENTUM) * rv + BN_MOMENTUM * unb
+                params[f"bns.{l}.num_batches_tracked"] += 1
+                invstd = (F32(1) / np.sqrt(var + BN_EPS)).astype(F32)
+            if y_bf16 or not use_bn:
+                y = rnd(y)
+            c["y"].append(y)
+            c["mu"].append(mu)
+            c["invstd"].append(invstd)
+            h = ((y - mu) * invstd * params[f"bns.{l}.weight"] + params[f"bns.{l}.bias"]).astype(F32) if use_bn else y
+            x = np.maximum(h, F32(0))
+            if l < L - 1:
+                x = rnd(x)
+            c["x"].append(x)
+        out = (x.astype(np.float64) @ params["output_layer.weight"].astype(np.float64).T).astype(F32) \
+            + params["output_layer.bias"]
+        return out.astype(F32), c
+
+    def backward(item, meta, g, c):
+        g = np.asarray(g, F32).reshape(-1, 1)
+        grads = {k: np.zeros_like(v) for k, v in params.items() if v.dtype == np.float32 and "running" not in k}
+        xL = c["x"][L]
+        grads["output_layer.weight"] = (g.astype(np.float64).T @ xL.astype(np.float64)).astype(F32)
+        grads["output_layer.bias"] = g.sum(axis=0, dtype=np.float64).astype(F32)
+        dx = (g @ params["output_layer.weight"]).astype(F32)
+        B = g.shape[0]
+        for l in reversed(range(L)):
+            y = c["y"][l]
+            if use_bn:
+                mu, invstd, gamma = c["mu"][l], c["invstd"][l], params[f"bns.{l}.weight"]
+                xhat = ((y - mu) * invstd).astype(F32)
+                d = np.where(xhat * gamma + params[f"bns.{l}.bias"] > 0, dx, F32(0)).astype(F32)
+                s1 = d.sum(axis=0, dtype=np.float64).astype(F32)
+                s2 = (d.astype(np.float64) * xhat).sum(axis=0).astype(F32)
+                grads[f"bns.{l}.weight"], grads[f"bns.{l}.bias"] = s2, s1
+                dy = ((gamma * invstd) * (d - s1 / F32(B) - xhat * (s2 / F32(B)))).astype(F32)
+            else:
+                dy = np.where(y > 0, dx, F32(0)).astype(F32)
+            grads[f"fcs.{l}.bias"] = dy.sum(axis=0, dtype=np.float64).astype(F32)
+            dy16 = rnd(dy)
+            grads[f"fcs.{l}.weight"] = _mm(dy16.T, c["x"][l])
+            dx = _mm(dy16, W[l])
+            if l > 0 and (y_bf16 or not use_bn):  # the layer below keeps a bf16 y: its dx image is bf16 too
+                dx = rnd(dx)
+        D = params["user.weight"].shape[1]
+        np.add.at(grads["user.weight"], u, dx[:, 0:D])
+        np.add.at(grads["item.weight"], item, dx[:, D:2 * D])
+        for m in range(M):
+            np.add.at(grads[f"metadata_embeddings.{m}.weight"], meta[:, m], dx[:, (2 + m) * D:(3 + m) * D])
+        return grads
+
+    sp, cp = forward(p, pm)
+    sn, cn = forward(n, nm)
+    gp, gn = hinge_grad(sp, sn)
+    return sp, sn, hinge_loss(sp, sn), _add(backward(p, pm, gp, cp), backward(n, nm, gn, cn))
+
+
 # ----------------------------------------------------------------------------------------------- one step
 def _add(a, b):
     return {k: (a[k] + b[k]).astype(F32) for k in a}

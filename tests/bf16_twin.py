@@ -1,0 +1,100 @@
+# -*- coding: utf-8 -*-
+"""torch twin of oracle/nets.py::mlp_train_step_bf16 for sizes the numpy oracle cannot finish in seconds (c5: 65 536
+rows x [1280, 1024, 512, 256]): the same arithmetic and the same bf16 rounding points, products and sums in float64 on
+the GPU.  TEST INFRASTRUCTURE; tests/test_gpu_fullsize.py pins it to the numpy oracle at a small size before using it."""
+import torch
+
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+
+def rnd(a):
+    """fp32 -> bf16 (round-to-nearest-even) -> fp32."""
+    return a.float().bfloat16().float()
+
+
+def mm(a, b):
+    return (a.double() @ b.double()).float()
+
+
+def train_step_bf16(P, ids, y_bf16=True):
+    """P: dict name -> fp32 GPU tensor (state_dict layout; embedding tables may be compacted); ids: dict user/pos/neg
+    [/pos_meta/neg_meta] of int64 GPU tensors.  Returns (pos, neg, loss, grads, dx0 rows per pass) — running statistics
+    in P are updated in place."""
+    L = 0
+    while f"fcs.{L}.weight" in P:
+        L += 1
+    M = 0
+    while f"metadata_embeddings.{M}.weight" in P:
+        M += 1
+    use_bn = "bns.0.weight" in P
+    u = ids["user"]
+    W = [rnd(P[f"fcs.{l}.weight"]) for l in range(L)]
+
+    def forward(item, meta):
+        cols = [P["user.weight"][u], P["item.weight"][item]] + [P[f"metadata_embeddings.{m}.weight"][meta[:, m]]
+                                                                for m in range(M)]
+        x = rnd(torch.cat(cols, dim=1))
+        c = {"x": [x], "y": [], "mu": [], "invstd": []}
+        B = x.shape[0]
+        for l in range(L):
+            y = mm(x, W[l].T) + P[f"fcs.{l}.bias"]
+            mu = invstd = None
+            if use_bn:
+                y64 = y.double()
+                mu = y64.mean(0).float()
+                var = y64.var(0, unbiased=False).float()
+                unb = var * (B / max(B - 1, 1))
+                P[f"bns.{l}.running_mean"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * mu)
+                P[f"bns.{l}.running_var"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * unb)
+                invstd = 1.0 / torch.sqrt(var + BN_EPS)
+            if y_bf16 or not use_bn:
+                y = rnd(y)
+            c["y"].append(y)
+            c["mu"].append(mu)
+            c["invstd"].append(invstd)
+            h = ((y - mu) * invstd * P[f"bns.{l}.weight"] + P[f"bns.{l}.bias"]) if use_bn else y
+            x = torch.relu(h)
+            if l < L - 1:
+                x = rnd(x)
+            c["x"].append(x)
+        out = (x.double() @ P["output_layer.weight"].double().T).float() + P["output_layer.bias"]
+        return out.reshape(-1), c
+
+    def backward(g, c):
+        g = g.reshape(-1, 1)
+        gr = {}
+        xL = c["x"][L]
+        gr["output_layer.weight"] = (g.double().T @ xL.double()).float()
+        gr["output_layer.bias"] = g.double().sum(0).float()
+        dx = g @ P["output_layer.weight"]
+        B = g.shape[0]
+        for l in reversed(range(L)):
+            y = c["y"][l]
+            if use_bn:
+                mu, invstd, gamma = c["mu"][l], c["invstd"][l], P[f"bns.{l}.weight"]
+                xhat = (y - mu) * invstd
+                d = torch.where(xhat * gamma + P[f"bns.{l}.bias"] > 0, dx, torch.zeros_like(dx))
+                s1 = d.double().sum(0).float()
+                s2 = (d.double() * xhat.double()).sum(0).float()
+                gr[f"bns.{l}.weight"], gr[f"bns.{l}.bias"] = s2, s1
+                dy = (gamma * invstd) * (d - s1 / B - xhat * (s2 / B))
+            else:
+                dy = torch.where(y > 0, dx, torch.zeros_like(dx))
+            gr[f"fcs.{l}.bias"] = dy.double().sum(0).float()
+            dy16 = rnd(dy)
+            gr[f"fcs.{l}.weight"] = mm(dy16.T, c["x"][l])
+            dx = mm(dy16, W[l])
+            if l > 0 and (y_bf16 or not use_bn):
+                dx = rnd(dx)
+        return gr, dx
+
+    sp, cp = forward(ids["pos"], ids.get("pos_meta"))
+    sn, cn = forward(ids["neg"], ids.get("neg_meta"))
+    h = sn - sp + 1.0
+    B = h.shape[0]
+    act = (h >= 0).float() / B
+    loss = torch.clamp(h, min=0).mean()
+    gp, dxp = backward(-act, cp)
+    gn, dxn = backward(act, cn)
+    grads = {k: gp[k] + gn[k] for k in gp}
+    return sp, sn, loss, grads, (dxp, dxn)

@@ -260,7 +260,10 @@ def test_hinge_auc_batches(n, batch):
 
 
 @pytest.mark.parametrize("n,k", [(1, 1), (37, 10), (4096, 10), (4097, 5), (100_000, 10), (100_000, 2048),
-                                 (1_000_003, 100)])
+                                 (1_000_003, 100),
+                                 # k > 2048 (full-sort path; the reference sorts everything for any top_k, model.py:447)
+                                 (2049, 2049), (4096, 4096), (5000, 5000), (10_000, 3000), (100_000, 100_000),
+                                 (1_000_003, 5000)])
 def test_topk_bit_exact(n, k):
     ops = _ops()
     rs = np.random.RandomState(n % 1000)
@@ -599,10 +602,12 @@ def test_gemm_fused_bn_statistics(B, passes, K, H, bf16):
 
 @pytest.mark.parametrize("net,D,skew", [("fm", 64, False), ("fm", 64, True), ("fm", 16, True), ("linear", 32, True),
                                         ("fm", 80, False), ("fm", 10, True)])
-@pytest.mark.parametrize("inline_user", [False, True])
+@pytest.mark.parametrize("inline_user", [False, True, "items"])
 def test_presorted_item_update_matches_oracle(net, D, skew, inline_user):
     """trs_epoch_presort + the atomic-free per-run item update: 3 batches in one C call == oracle SGD steps.
-    `skew`: one hot item takes 40 % of the references (runs cut at 64, pieces added atomically)."""
+    `skew`: one hot item takes 40 % of the references (runs cut at 64, pieces added atomically).
+    inline_user "items": K1 also updates the item rows referenced once in the batch (item-duplicate flags) and the
+    sorted runs only walk rows with several references."""
     ops = _ops()
     rs = np.random.RandomState(D + skew)
     NU, NI, B, nb, lr = 300, 57, 512, 3, 0.05
@@ -620,7 +625,7 @@ def test_presorted_item_update_matches_oracle(net, D, skew, inline_user):
     ps = ops.EpochPresort(nb, B, NU, NI, DEV)
     given = [torch.from_numpy(a.astype(np.int32)).to(DEV) for a in (u, i, j)]
     ps.run(None, None, 0, 0, 0, err, given_ids=given)
-    ids, sk, sv, udup, usorted = ps.step_args(0)
+    ids, sk, sv, udup, usorted, idup = ps.step_args(0)
     gz, du = torch.empty((2, B), device=DEV), torch.empty((B, D), device=DEV)
     losses = torch.zeros(nb, device=DEV)
     # user-duplicate flags of the slice == "another triple of the same batch has this user"
@@ -628,10 +633,15 @@ def test_presorted_item_update_matches_oracle(net, D, skew, inline_user):
         ub = u[b * B:(b + 1) * B]
         cnt = np.bincount(ub, minlength=NU)
         assert np.array_equal(udup[b * B:(b + 1) * B].cpu().numpy(), (cnt[ub] > 1).astype(np.uint8))
+        # item-duplicate flags: {pos, neg} reference of a position shares its row with another reference of the batch
+        cnt = np.bincount(np.concatenate([i[b * B:(b + 1) * B], j[b * B:(b + 1) * B]]), minlength=NI)
+        want = np.stack([cnt[i[b * B:(b + 1) * B]] > 1, cnt[j[b * B:(b + 1) * B]] > 1], axis=1).astype(np.uint8)
+        assert np.array_equal(idup[b * B:(b + 1) * B].cpu().numpy(), want)
     if inline_user:
         ops.train_steps_sgd(net, T, None, None, 0, 0, 0, B, nb, lr, *ids, gz, du, losses, err,
                             ops.train_scratch(NU, NI, B, D, DEV), 1, None, sk, sv, ps.key_bytes, udup,
-                            torch.empty((B, D), device=DEV), usorted)
+                            torch.empty((B, D), device=DEV), usorted,
+                            item_dup=idup if inline_user == "items" else None)
     else:
         ops.train_steps_sgd(net, T, None, None, 0, 0, 0, B, nb, lr, *ids, gz, du, losses, err,
                             ops.train_scratch(NU, NI, B, D, DEV), 1, None, sk, sv, ps.key_bytes)
@@ -671,7 +681,7 @@ def test_presorted_adaptive_rules_match_the_oracle(net, D, skew, kind):
     err = torch.zeros(1, dtype=torch.int32, device=DEV)
     ps = ops.EpochPresort(nb, B, NU, NI, DEV)
     ps.run(None, None, 0, 0, 0, err, given_ids=[torch.from_numpy(a.astype(np.int32)).to(DEV) for a in (u, i, j)])
-    ids, sk, sv, udup, usorted = ps.step_args(0)
+    ids, sk, sv, udup, usorted, idup = ps.step_args(0)
     gz, du = torch.empty((2, B), device=DEV), torch.empty((B, D), device=DEV)
     losses = torch.zeros(nb, device=DEV)
     s1 = {k: torch.zeros_like(t[k]) for k in names}
@@ -750,7 +760,7 @@ def test_presorted_step_with_metadata_matches_oracle(net, D, M, skew, meta_sorte
     # meta_sorted: every metadata column's references grouped by row too (sorted runs instead of the atomic scatter)
     ps = ops.EpochPresort(nb, B, NU, NI, DEV, **(dict(item_meta=tab, n_meta=sizes) if meta_sorted else {}))
     ps.run(None, None, 0, 0, 0, err, given_ids=[torch.from_numpy(a.astype(np.int32)).to(DEV) for a in (u, i, j)])
-    ids, sk, sv, udup, usorted = ps.step_args(0)
+    ids, sk, sv, udup, usorted, idup = ps.step_args(0)
     R = 3 + 2 * M
     gz, du = torch.empty((2, B), device=DEV), torch.empty((B, D), device=DEV)
     xstage = torch.empty((2 if net == "fm" else 1, B, D), device=DEV)
@@ -815,7 +825,7 @@ def test_presorted_adaptive_rules_with_metadata_match_the_oracle(net, D, M, skew
     tab = torch.from_numpy(item_meta).to(DEV)
     ps = ops.EpochPresort(nb, B, NU, NI, DEV, item_meta=tab, n_meta=sizes)
     ps.run(None, None, 0, 0, 0, err, given_ids=[torch.from_numpy(a.astype(np.int32)).to(DEV) for a in (u, i, j)])
-    ids, sk, sv, udup, usorted = ps.step_args(0)
+    ids, sk, sv, udup, usorted, idup = ps.step_args(0)
     gz, du = torch.empty((2, B), device=DEV), torch.empty((B, D), device=DEV)
     xstage = torch.empty((2 if net == "fm" else 1, B, D), device=DEV)
     ms = _lib.TrsMetaStage()

@@ -11,6 +11,7 @@ import pytest
 import torch
 
 from conftest import load_golden, rel_err, sub
+from oracle import nets as onets
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -419,6 +420,76 @@ def test_mlp_bf16_resident_path_tracks_fp32(use_bn):
         a, c = a.reshape(-1).astype(np.float64), c.reshape(-1).astype(np.float64)
         cos = a @ c / (np.linalg.norm(a) * np.linalg.norm(c))
         assert cos > 0.97, cos  # y_l, dx_l, x_l and dy_l all live in bf16 between the GEMMs
+
+
+@pytest.mark.parametrize("use_bn,M,shape", [(True, 0, (64, [256, 128], 256)), (False, 0, (64, [256, 128], 256)),
+                                             (True, 2, (32, [128, 128, 128], 384)), (True, 1, (128, [512, 256], 1024))])
+def test_mlp_bf16_resident_step_matches_the_bf16_oracle(use_bn, M, shape):
+    """The bf16-RESIDENT training step (use_amp on tile-aligned nets) against oracle/nets.py::mlp_train_step_bf16, which
+    rounds to bf16 at the same points (x_0, W_l, y_l, x_l, dy_l, dx_l) and is pinned to the reference's golden vectors
+    with the rounding switched off: scores, loss, every dense gradient, the embedding gradient rows and the BatchNorm
+    running statistics within 2e-3 norm-wise (the fp32-accumulation order and the occasional element that rounds to the
+    neighbouring bf16 value are all that differs) — not "same direction as the fp32 path"."""
+    from torchrecsys_amd import ops
+    from torchrecsys_amd.model import TorchRecSys
+    D, hidden, B = shape
+    rs = np.random.RandomState(5)
+    n_u, n_i, n = 500, 300, 4096
+    users = torch.from_numpy(np.concatenate([np.arange(n_u), rs.randint(0, n_u, n - n_u)]).astype(np.int64))
+    items = torch.from_numpy(np.concatenate([np.arange(n_i), rs.randint(0, n_i, n - n_i)]).astype(np.int64))
+    cats = [17, 5, 9][:M]
+    meta = torch.from_numpy(np.stack([rs.randint(0, c, n_i) for c in cats], axis=1)) if M else None
+    seed(11)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = TorchRecSys.from_tensors(users, items, n_users=n_u, n_items=n_i, item_metadata=meta, n_factors=D,
+                                         net_type="mlp", hidden_layers=hidden, use_batch_norm=use_bn, use_amp=True,
+                                         dynamic_neg_sampling=True, rng="reference")
+    net = model.net
+    net.train()
+    dev = net.user.weight.device
+    params = {k: v.detach().cpu().numpy().copy() for k, v in net.state_dict().items()}
+    h = {"user": rs.randint(0, n_u, B), "pos": rs.randint(0, n_i, B), "neg": rs.randint(0, n_i, B)}
+    ids = {k: torch.from_numpy(v).to(dev) for k, v in h.items()}
+    batch = {"user_id": h["user"], "pos_item_id": h["pos"], "neg_item_id": h["neg"]}
+    if M:
+        mt = meta.numpy()
+        batch["pos_metadata_id"], batch["neg_metadata_id"] = mt[h["pos"]], mt[h["neg"]]
+        ids["pos_meta"] = torch.from_numpy(batch["pos_metadata_id"]).to(dev).contiguous()
+        ids["neg_meta"] = torch.from_numpy(batch["neg_metadata_id"]).to(dev).contiguous()
+    assert net.compute._resident(2 * B, True)
+    scores, ctx = net.compute.forward(ids, 2, True)
+    pos, neg = scores[:B], scores[B:]
+    gp, gn = ops.hinge_backward(pos, neg)
+    grads, dx0 = net.compute.backward(ctx, torch.cat([gp, gn]))
+    sp, sn, loss, og = onets.mlp_train_step_bf16(params, batch)
+    TOL16 = 2e-3
+    assert rel_err(pos.cpu().numpy(), sp.reshape(-1)) < TOL16 and rel_err(neg.cpu().numpy(), sn.reshape(-1)) < TOL16
+    named = dict(net.named_parameters())
+    for k, p_ in named.items():
+        if p_ in grads:
+            if use_bn and k.startswith("fcs") and k.endswith("bias"):
+                continue  # mathematically zero in front of train-mode BatchNorm: rounding noise on both sides
+            # BatchNorm's gamma / beta gradients are cancelling sums over the batch (sum d*xhat, sum d): an element of
+            # y_l that rounds to the neighbouring bf16 value moves them a little further than the GEMM outputs
+            assert rel_err(grads[p_].cpu().numpy(), og[k]) < (5e-3 if k.startswith("bns") else TOL16), k
+    dx = dx0.cpu().numpy().astype(np.float64)
+    gu = np.zeros((n_u, D))
+    np.add.at(gu, h["user"], dx[:B, :D] + dx[B:, :D])
+    gi = np.zeros((n_i, D))
+    np.add.at(gi, h["pos"], dx[:B, D:2 * D])
+    np.add.at(gi, h["neg"], dx[B:, D:2 * D])
+    assert rel_err(gu, og["user.weight"]) < TOL16 and rel_err(gi, og["item.weight"]) < TOL16
+    for m in range(M):
+        gm = np.zeros((cats[m], D))
+        np.add.at(gm, batch["pos_metadata_id"][:, m], dx[:B, (2 + m) * D:(3 + m) * D])
+        np.add.at(gm, batch["neg_metadata_id"][:, m], dx[B:, (2 + m) * D:(3 + m) * D])
+        assert rel_err(gm, og[f"metadata_embeddings.{m}.weight"]) < TOL16, m
+    if use_bn:
+        sd = net.state_dict()
+        for l in range(len(hidden)):
+            for stat in ("running_mean", "running_var"):
+                assert rel_err(sd[f"bns.{l}.{stat}"].cpu().numpy(), params[f"bns.{l}.{stat}"]) < 1e-4, (l, stat)
+            assert int(sd[f"bns.{l}.num_batches_tracked"]) == 2
 
 
 @pytest.mark.parametrize("net_type", ["linear", "mlp"])

@@ -48,7 +48,7 @@ def test_presorted_step_random_shapes(case):
     err = torch.zeros(1, dtype=torch.int32, device=DEV)
     ps = ops.EpochPresort(nb, B, NU, NI, DEV)
     ps.run(None, None, 0, 0, 0, err, given_ids=[torch.from_numpy(a.astype(np.int32)).to(DEV) for a in (u, i, j)])
-    ids, sk, sv, udup, usorted = ps.step_args(0)
+    ids, sk, sv, udup, usorted, idup = ps.step_args(0)
     gz, du = torch.empty((2, B), device=DEV), torch.empty((B, D), device=DEV)
     losses = torch.zeros(nb, device=DEV)
     lr, b1, b2, eps, lr_decay = {"sgd": (0.05, 0, 0, 0, 0), "sparse_adam": (0.01, 0.9, 0.999, 1e-8, 0.0),
@@ -69,7 +69,8 @@ def test_presorted_step_random_shapes(case):
         o.cut_capacity = cut_rows.numel()
     ops.train_steps_sgd(net, T, None, None, 0, 0, 0, B, nb, lr, *ids, gz, du, losses, err,
                         ops.train_scratch(NU, NI, B, D, DEV), 1, None, sk, sv, ps.key_bytes, udup,
-                        torch.empty((B, D), device=DEV), usorted, o)
+                        torch.empty((B, D), device=DEV), usorted, o,
+                        item_dup=idup if kind == "sgd" else None)  # plain SGD: K1 also takes item rows referenced once
     torch.cuda.synchronize()
     ref = {k: v.copy() for k, v in p.items()}
     r1 = {k: np.zeros_like(v) for k, v in p.items()}

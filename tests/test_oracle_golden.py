@@ -57,6 +57,36 @@ def test_g1_forward_backward(name, M):
         assert rel_err(pe, g["pos_eval"]) < TOL
 
 
+@pytest.mark.parametrize("name", ["mlp", "mlp_nobn"])
+@pytest.mark.parametrize("M", [0, 1, 3])
+def test_g1_bf16_oracle_without_rounding_is_the_reference(name, M):
+    """oracle/nets.py::mlp_train_step_bf16 restates the MLP step with a rounding hook at the points where the bf16-resident
+    product path stores bf16 images.  With the hook disabled it must reproduce the REFERENCE's golden vectors (so the
+    only thing the rounded variant adds is the rounding), and its hook is torch's own bf16 conversion."""
+    import torch
+    g = load_golden(f"g1_{name}_M{M}.npz")
+    params, batch = _params(g), _batch(g)
+    sp, sn, loss, grads = nets.mlp_train_step_bf16(params, batch, rnd=lambda a: np.asarray(a, np.float32))
+    assert rel_err(sp.reshape(-1), g["pos"].reshape(-1)) < TOL and rel_err(sn.reshape(-1), g["neg"].reshape(-1)) < TOL
+    assert abs(float(loss) - float(g["loss"])) <= TOL * abs(float(g["loss"]))
+    for k, v in sub(g, "grad").items():
+        if name == "mlp" and k.startswith("fcs") and k.endswith("bias"):
+            assert np.abs(grads[k]).max() < 1e-6
+            continue
+        assert rel_err(grads[k], v) < TOL, k
+    if name == "mlp":
+        for k, v in sub(g, "after_fwd").items():
+            if "running" in k:
+                assert rel_err(params[k], v) < TOL, k
+    x = np.concatenate([np.random.RandomState(0).normal(0, 1, 4096), [0.0, -0.0, 1.0, 3.0e38, 1e-40, 1.00390625,
+                                                                        1.01171875]]).astype(np.float32)
+    assert np.array_equal(nets.bf16_round(x), torch.from_numpy(x).bfloat16().float().numpy())
+    # and the rounded variant stays within bf16 distance of the fp32 step
+    params2 = _params(g)
+    rp, rn, rloss, _ = nets.mlp_train_step_bf16(params2, batch)
+    assert rel_err(rp.reshape(-1), g["pos"].reshape(-1)) < 3e-2 and abs(float(rloss) - float(g["loss"])) < 2e-2
+
+
 def _step(net_type, oname, params, batch, state, t):
     sp, sn, loss, grads = nets.train_forward_backward(net_type, params, batch)
     touched = nets.touched_rows(net_type, params, batch)

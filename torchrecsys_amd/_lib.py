@@ -10,7 +10,7 @@ import os
 TRS_MAX_META = 8
 TRS_NET_LINEAR = 0
 TRS_NET_FM = 1
-ABI_VERSION = 1
+ABI_VERSION = 2  # == TRS_ABI_VERSION of include/trs.h (tests/test_abi.py)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtrs_hip.so")
@@ -77,6 +77,22 @@ class TrsMetaStage(C.Structure):
                 ("pos_meta_ids", C.c_void_p), ("neg_meta_ids", C.c_void_p)]
 
 
+class TrsTrainArgs(C.Structure):
+    """struct trs_train_args (include/trs.h): arguments of trs_train_steps_sgd."""
+    _fields_ = [("net", C.c_int32), ("n_steps", C.c_int32), ("tables", C.POINTER(TrsTables)), ("batch", C.c_int64),
+                ("lr", C.c_float), ("first_stamp", C.c_uint32),
+                ("stream_ui_dev", C.c_void_p), ("neg_static_dev", C.c_void_p), ("N", C.c_int64),
+                ("shuffle_key", C.c_uint64), ("sample_seed", C.c_uint64), ("first_pos", C.c_int64),
+                ("user_buf_dev", C.c_void_p), ("pos_buf_dev", C.c_void_p), ("neg_buf_dev", C.c_void_p),
+                ("gz_buf_dev", C.c_void_p), ("du_buf_dev", C.c_void_p), ("loss_sums_dev", C.c_void_p),
+                ("err_flag_dev", C.c_void_p), ("scratch_dev", C.c_void_p),
+                ("sorted_keys_dev", C.c_void_p), ("sorted_vals_dev", C.c_void_p), ("key_bytes", C.c_int32),
+                ("ukey_bytes", C.c_int32), ("user_dup_flags_dev", C.c_void_p), ("item_dup_flags_dev", C.c_void_p),
+                ("ustage_buf_dev", C.c_void_p), ("sorted_ukeys_dev", C.c_void_p), ("sorted_uvals_dev", C.c_void_p),
+                ("slice_pos0", C.c_int64), ("opt", C.POINTER(TrsOpt)), ("meta", C.POINTER(TrsMetaStage)),
+                ("events", C.POINTER(C.c_void_p))]
+
+
 _vp, _i32, _i64, _u64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
 _T, _Bp = C.POINTER(TrsTables), C.POINTER(TrsBatch)
 
@@ -100,9 +116,7 @@ PROTOTYPES = {
                                              _f, _f, _f, _f, _i64, _vp]),
     "trs_rows_apply_adagrad": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _i64, _i32, _f, _f, _vp]),
     "trs_train_scratch_bytes": (C.c_int64, [_i64, _i64, _i64, _i32]),
-    "trs_train_steps_sgd": (C.c_int, [C.c_int, _T, _vp, _vp, _i64, _u64, _u64, _i64, _i64, _i32, _f, _vp, _vp, _vp,
-                                      _vp, _vp, _vp, _vp, _vp, C.c_uint32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32,
-                                      _i64, C.POINTER(TrsOpt), C.POINTER(TrsMetaStage), _vp, _vp]),
+    "trs_train_steps_sgd": (C.c_int, [C.POINTER(TrsTrainArgs), _vp]),
     "trs_epoch_presort_meta": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _i64, _vp,
                                          C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp, _vp, _vp]),
     "trs_epoch_user_dups_sizes": (C.c_int, [_i64, _i64, _i64, c_int64_p, c_int64_p, c_int64_p]),
@@ -110,7 +124,7 @@ PROTOTYPES = {
                                       C.POINTER(C.c_void_p), c_int32_p, _vp]),
     "trs_epoch_presort_sizes": (C.c_int, [_i64, _i64, _i64, c_int64_p, c_int64_p, c_int64_p, c_int64_p]),
     "trs_epoch_presort": (C.c_int, [_vp, _vp, _i64, _u64, _u64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp,
-                                    _vp, _i64, _vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp]),
+                                    _vp, _i64, _vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp, _vp]),
     "trs_hinge_auc": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "trs_hinge_auc_batches": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "trs_hinge_backward": (C.c_int, [_vp, _vp, _i64, _f, _vp, _vp, _vp]),

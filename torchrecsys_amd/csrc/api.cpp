@@ -14,7 +14,7 @@ void trs_set_error(const char* fmt, ...) {
 
 extern "C" const char* trs_last_error(void) { return g_err; }
 
-extern "C" int trs_abi_version(void) { return 1; }
+extern "C" int trs_abi_version(void) { return TRS_ABI_VERSION; }
 
 extern "C" int trs_check_device(void) {
   int dev = -1;

@@ -59,6 +59,10 @@ struct FastArgs {
   // presorted mode with precomputed per-position user-duplicate flags (trs_epoch_presort): K1 applies the user update
   // itself for users referenced once in the batch and stages the OLD user row for K2 instead of the gradient
   const uint8_t* udup_pos;  // (B) 1: this triple's user has another reference in the batch; NULL: mode off
+  // (B,2) {pos, neg}: 1 = that item row has another reference in the batch; NULL: every item reference goes through the
+  // sorted runs.  Given: K1 applies the item update of a reference that is alone on its row itself (the user row is in
+  // registers and nobody else reads or writes that item row this step) and K2 only walks rows with several references
+  const uint8_t* idup_pos;
   float* ustage;            // (B,D) pre-update user rows, read by the sorted item update
   OptArgs o;                // update rule of the presorted mode (kind OPT_SGD: lr above)
 };
@@ -66,13 +70,14 @@ struct FastArgs {
 struct RawIds {   // loads issued, nothing consumed yet
   int32_t u, p, n;
   uint8_t dup;
+  uint16_t idup;  // INL 2: {pos, neg} item-duplicate flags, one byte each
   int64_t v;      // SRC 1: uniform draw over n_items-1 values (the negative is v + (v >= pos))
   bool valid;
 };
 
 struct TripleIds {
   int32_t u, p, n;
-  bool valid, ok, dup;
+  bool valid, ok, dup, pdup, ndup;
 };
 
 // SRC: 0 = ids given in user/pos/neg; 1 = resident stream + dynamic sampler; 2 = resident stream + static negatives.
@@ -80,7 +85,7 @@ struct TripleIds {
 // which would also drain the row gathers in flight.  issue_ids only ISSUES the loads (and does the id-independent
 // Philox arithmetic); finalize_ids consumes them one iteration later, so the wait it implies covers loads that are
 // older than every row gather still in flight (vmcnt is in-order).
-template <int SRC, bool INL>
+template <int SRC, int INL>
 __device__ __forceinline__ RawIds issue_ids(const FastArgs& a, int64_t t) {
   RawIds r;
   r.valid = t < a.B;
@@ -105,7 +110,9 @@ __device__ __forceinline__ RawIds issue_ids(const FastArgs& a, int64_t t) {
     r.n = a.neg[tc];
   }
   r.dup = 1;
+  r.idup = 0x0101;
   if (INL) r.dup = a.udup_pos[tc];
+  if (INL == 2) r.idup = reinterpret_cast<const uint16_t*>(a.idup_pos)[tc];
   return r;
 }
 
@@ -123,6 +130,8 @@ __device__ __forceinline__ TripleIds finalize_ids(const FastArgs& a, const RawId
   r.p = (int32_t)pid;
   r.n = (int32_t)nid;
   r.dup = w.dup != 0;
+  r.pdup = (w.idup & 0x00ffu) != 0;
+  r.ndup = (w.idup & 0xff00u) != 0;
   return r;
 }
 
@@ -158,7 +167,11 @@ __device__ __forceinline__ void load_rows(TripleRows<VEC, K>& r, const trs_table
 // for K2 instead of the gradient; only duplicated users stage their gradient for the small atomic pass K3'.
 // OPT != OPT_SGD (INL only): the same in-place user update with the SparseAdam / Adagrad rule; its state rows travel with
 // the user row.
-template <int NET, int VEC, int G, int K, int SRC, bool FULL, bool INL, int OPT = OPT_SGD>
+// INL 2 (plain SGD, item-duplicate flags): an item reference that is alone on its row in the batch is updated right here
+// too — item[i] += (-lr*gz) * u with the same two roundings as the sorted run of length one it replaces — and the old
+// user row is staged only when one of the triple's item references still goes through the runs.  At c4 (65 536
+// references over 1M items per step) 94 % of the references are alone: the step becomes one read and one write per row.
+template <int NET, int VEC, int G, int K, int SRC, bool FULL, int INL, int OPT = OPT_SGD>
 __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) {
   constexpr int N = K * VEC;
   constexpr int TPW = TRS_WAVE / G;
@@ -221,7 +234,24 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
 #pragma unroll
       for (int n = 0; n < N; ++n) g.v[n] = gp * r.pi.v[n] + gn * r.ni.v[n];
       if (INL) {
-        row_store<VEC, G, K>(r.u, a.ustage + tt * (int64_t)D, D, lig);
+        if (INL != 2 || id.pdup || id.ndup) row_store<VEC, G, K>(r.u, a.ustage + tt * (int64_t)D, D, lig);
+        if (INL == 2 && live) {
+          const float cp = -a.lr * gp, cn = -a.lr * gn;  // the coefficient the sorted run forms from gz
+          if (!id.pdup) {
+            RowReg<VEC, K> o;
+#pragma unroll
+            for (int n = 0; n < N; ++n) o.v[n] = r.pi.v[n] + cp * r.u.v[n];
+            row_store<VEC, G, K>(o, T.item + id.p * (int64_t)D, D, lig);
+            if (lig == 0) T.item_lin[id.p] = r.pl + cp;
+          }
+          if (!id.ndup) {
+            RowReg<VEC, K> o;
+#pragma unroll
+            for (int n = 0; n < N; ++n) o.v[n] = r.ni.v[n] + cn * r.u.v[n];
+            row_store<VEC, G, K>(o, T.item + id.n * (int64_t)D, D, lig);
+            if (lig == 0) T.item_lin[id.n] = r.nl + cn;
+          }
+        }
         if (id.dup || !live) {
           row_store<VEC, G, K>(g, a.du + tt * (int64_t)D, D, lig);
         } else {
@@ -1032,13 +1062,15 @@ static int launch_fwd_stage(const FastArgs& a, hipStream_t s) {
   {                                                                                                             \
     const dim3 gr((unsigned)grid), bl(TRS_BLOCK);                                                               \
     if (src == 0 && a.udup_pos && a.o.kind == OPT_ADAM)                                                          \
-      hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL, true, OPT_ADAM>), gr, bl, 0, s, a);           \
+      hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL, 1, OPT_ADAM>), gr, bl, 0, s, a);              \
     else if (src == 0 && a.udup_pos && a.o.kind == OPT_ADAGRAD)                                                  \
-      hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL, true, OPT_ADAGRAD>), gr, bl, 0, s, a);        \
-    else if (src == 0 && a.udup_pos) hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL, true>), gr, bl, 0, s, a); \
-    else if (src == 0) hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL, false>), gr, bl, 0, s, a);  \
-    else if (src == 1) hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 1, FULL, false>), gr, bl, 0, s, a);  \
-    else hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 2, FULL, false>), gr, bl, 0, s, a);                \
+      hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL, 1, OPT_ADAGRAD>), gr, bl, 0, s, a);           \
+    else if (src == 0 && a.udup_pos && a.idup_pos)                                                               \
+      hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL, 2>), gr, bl, 0, s, a);                        \
+    else if (src == 0 && a.udup_pos) hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL, 1>), gr, bl, 0, s, a); \
+    else if (src == 0) hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL, 0>), gr, bl, 0, s, a);      \
+    else if (src == 1) hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 1, FULL, 0>), gr, bl, 0, s, a);      \
+    else hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 2, FULL, 0>), gr, bl, 0, s, a);                    \
   }
 #define TRS_CASE(V, GG, KK)                                                                                     \
   if (c.vec == V && c.g == GG && c.k == KK) {                                                                   \
@@ -1150,7 +1182,8 @@ int trs_item_bits_for(int64_t n_items);
 int trs_launch_sorted_updates_fused(const trs_tables* tables, const void* keys_step, const void* vals_step,
                                     int64_t batch, int64_t item_bits, const float* gz, float lr, const float* ustage,
                                     const void* ukeys_step, const void* uvals_step, int64_t q0, const float* du,
-                                    const OptArgs* opt, int parity, int64_t xpass, int fmsub, hipStream_t s);
+                                    const OptArgs* opt, int parity, int64_t xpass, int fmsub, int skip_single,
+                                    hipStream_t s);
 int trs_launch_sorted_meta_update(const trs_tables* tables, int m, float* lin_or_scratch, const void* keys_step,
                                   const void* vals_step, int64_t batch, const float* gz, float lr, const float* xstage,
                                   int64_t xpass, int fmsub, const OptArgs* opt, int parity, hipStream_t s);
@@ -1170,10 +1203,12 @@ int trs_launch_pair_scores(int net, const ScoreArgs* ap, hipStream_t s) {
   RowCfg c;
   if (!pick_row_cfg(a.T.D, c) || c.vec != 4 || c.k != 1 || c.g < 8) return 1;
   const int tpw = TRS_WAVE / c.g;
-  int64_t iters = (a.Bt.B + 512 * 4 * (int64_t)tpw - 1) / (512 * 4 * (int64_t)tpw);
-  iters = iters < 2 ? 2 : (iters > 8 ? 8 : iters);
+  static const int iters_env = getenv("TRS_PASS_ITERS") ? atoi(getenv("TRS_PASS_ITERS")) : 0;  // tuning knob
+  int64_t iters = iters_env > 0 ? iters_env : (a.Bt.B + 512 * 4 * (int64_t)tpw - 1) / (512 * 4 * (int64_t)tpw);
+  iters = iters < 2 ? 2 : (iters > 8 && iters_env <= 0 ? 8 : iters);
   int64_t grid = ((a.Bt.B + tpw - 1) / tpw + 4 * iters - 1) / (4 * iters);
-  grid = grid < 1 ? 1 : (grid > 4096 ? 4096 : grid);
+  static const int64_t grid_cap = getenv("TRS_PASS_GRID_CAP") ? atoll(getenv("TRS_PASS_GRID_CAP")) : 4096;
+  grid = grid < 1 ? 1 : (grid > grid_cap ? grid_cap : grid);
   const dim3 gr((unsigned)grid), bl(TRS_BLOCK);
 #define TRS_PS(NETV, V, GG)                                                                                    \
   {                                                                                                            \
@@ -1200,17 +1235,31 @@ extern "C" int64_t trs_train_scratch_bytes(int64_t n_users, int64_t n_items, int
   return 12 * (n_users + n_items);  // uown, iown (8 B per row) + udup, idup (4 B per row)
 }
 
-extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int32_t* stream_ui_dev,
-                                   const int32_t* neg_static_dev, int64_t N,
-                                   uint64_t shuffle_key, uint64_t sample_seed, int64_t first_pos, int64_t batch,
-                                   int32_t n_steps, float lr, int32_t* user_buf_dev, int32_t* pos_buf_dev,
-                                   int32_t* neg_buf_dev, float* gz_buf_dev, float* du_buf_dev, float* loss_sums_dev,
-                                   int32_t* err_flag_dev, void* scratch_dev, uint32_t first_stamp,
-                                   const void* sorted_keys_dev, const void* sorted_vals_dev, int32_t key_bytes,
-                                   const uint8_t* user_dup_flags_dev, float* ustage_buf_dev,
-                                   const void* sorted_ukeys_dev, const void* sorted_uvals_dev, int32_t ukey_bytes,
-                                   int64_t slice_pos0, const trs_opt* opt, const trs_meta_stage* meta, void** events,
-                                   void* stream) {
+extern "C" int trs_train_steps_sgd(const trs_train_args* args, void* stream) {
+  TRS_REQUIRE(args != nullptr, "trs_train_steps_sgd: NULL arguments");
+  const int net = args->net;
+  const trs_tables* tables = args->tables;
+  const int32_t* stream_ui_dev = args->stream_ui_dev;
+  const int32_t* neg_static_dev = args->neg_static_dev;
+  const int64_t N = args->N;
+  const uint64_t shuffle_key = args->shuffle_key, sample_seed = args->sample_seed;
+  const int64_t first_pos = args->first_pos, batch = args->batch;
+  const int32_t n_steps = args->n_steps;
+  const float lr = args->lr;
+  int32_t *user_buf_dev = args->user_buf_dev, *pos_buf_dev = args->pos_buf_dev, *neg_buf_dev = args->neg_buf_dev;
+  float *gz_buf_dev = args->gz_buf_dev, *du_buf_dev = args->du_buf_dev, *loss_sums_dev = args->loss_sums_dev;
+  int32_t* err_flag_dev = args->err_flag_dev;
+  void* scratch_dev = args->scratch_dev;
+  const uint32_t first_stamp = args->first_stamp;
+  const void *sorted_keys_dev = args->sorted_keys_dev, *sorted_vals_dev = args->sorted_vals_dev;
+  const int32_t key_bytes = args->key_bytes, ukey_bytes = args->ukey_bytes;
+  const uint8_t* user_dup_flags_dev = args->user_dup_flags_dev;
+  float* ustage_buf_dev = args->ustage_buf_dev;
+  const void *sorted_ukeys_dev = args->sorted_ukeys_dev, *sorted_uvals_dev = args->sorted_uvals_dev;
+  const int64_t slice_pos0 = args->slice_pos0;
+  const trs_opt* opt = args->opt;
+  const trs_meta_stage* meta = args->meta;
+  void** events = args->events;
   TRS_REQUIRE(net == TRS_NET_LINEAR || net == TRS_NET_FM, "trs_train_steps_sgd: bad net");
   TRS_REQUIRE(tables && tables->M >= 0 && tables->M <= TRS_MAX_META, "trs_train_steps_sgd: bad M");
   TRS_REQUIRE((tables->M > 0) == (meta != nullptr), "trs_train_steps_sgd: metadata tables need the metadata staging");
@@ -1230,6 +1279,10 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
                 "trs_train_steps_sgd: user-duplicate flags need the staging buffer and the slice's sorted (batch,user) pairs");
   }
   const bool adaptive = opt && opt->kind != TRS_OPT_SGD;
+  // K1 takes the item references that are alone on their row: plain SGD without metadata on the fused two-launch step
+  const bool item_inl = args->item_dup_flags_dev && inl && !adaptive && !meta && key_bytes == 4 && ukey_bytes == 4;
+  TRS_REQUIRE(!args->item_dup_flags_dev || item_inl,
+              "trs_train_steps_sgd: item-duplicate flags need the presorted plain-SGD step without metadata");
   if (meta) {
     TRS_REQUIRE(sorted_keys_dev && user_dup_flags_dev && key_bytes == 4 && ukey_bytes == 4,
                 "trs_train_steps_sgd: metadata scorers run on the presorted step");
@@ -1306,6 +1359,7 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
     if (inl) {
       a.udup_pos = user_dup_flags_dev + (int64_t)st * batch;
       a.ustage = ustage_buf_dev;
+      if (item_inl) a.idup_pos = args->item_dup_flags_dev + (int64_t)st * 2 * batch;
     }
     if (adaptive) {  // this step's effective learning rate, in double like the Python floats of torch.optim
       OptArgs& o = a.o;
@@ -1375,7 +1429,8 @@ extern "C" int trs_train_steps_sgd(int net, const trs_tables* tables, const int3
         rc = trs_launch_sorted_updates_fused(tables, ks, vs, batch, item_bits, a.gz, a.lr,
                                              meta ? meta->xstage : a.ustage, uk, uv,
                                              slice_pos0 + (int64_t)st * batch, a.du, adaptive ? &a.o : nullptr,
-                                             (int)(a.stamp & 1u), fm_meta ? batch : 0, fm_meta ? 1 : 0, s);
+                                             (int)(a.stamp & 1u), fm_meta ? batch : 0, fm_meta ? 1 : 0,
+                                             item_inl ? 1 : 0, s);
         if (rc) return rc;
         if (meta && meta->sorted_keys[0]) {  // one sorted-run launch per metadata column
           for (int m = 0; m < tables->M; ++m) {

@@ -141,6 +141,71 @@ __global__ __launch_bounds__(TRS_BLOCK) void topk_chunk_kernel(const float* __re
   }
 }
 
+// ---- k > TOPK_MAXK (predict(top_k) up to n_items, reference model.py:447-450 sorts everything): a full bitonic sort
+// of the P = 2^ceil(log2 n) padded keys in global memory, descending.  Strides >= TOPK_CHUNK are one pass over the
+// keys each (sort_global_step_kernel); all strides below TOPK_CHUNK of one merge size run in LDS (sort_local_kernel,
+// which also performs every merge size up to TOPK_CHUNK in its first call).  Off the hot path: ~45 launches at 1M items.
+__global__ __launch_bounds__(TRS_BLOCK) void sort_keys_kernel(const float* __restrict__ scores, int64_t n, int64_t P,
+                                                             uint64_t* __restrict__ keys) {
+  const int64_t stride = (int64_t)gridDim.x * TRS_BLOCK;
+  for (int64_t g = (int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x; g < P; g += stride)
+    keys[g] = g < n ? topk_key(scores[g], (uint32_t)g) : 0;  // padding sorts below every real key
+}
+
+__global__ __launch_bounds__(TRS_BLOCK) void sort_global_step_kernel(uint64_t* __restrict__ keys, int64_t P,
+                                                                    int64_t size, int64_t stride) {
+  const int64_t gs = (int64_t)gridDim.x * TRS_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x; i < P / 2; i += gs) {
+    const int64_t lo = 2 * i - (i & (stride - 1));
+    const int64_t hi = lo + stride;
+    const bool desc = (lo & size) == 0;
+    const uint64_t a = keys[lo], b = keys[hi];
+    if ((a < b) == desc) {
+      keys[lo] = b;
+      keys[hi] = a;
+    }
+  }
+}
+
+// One TOPK_CHUNK-aligned chunk per block: merge sizes first_size .. last_size (last_size > TOPK_CHUNK: only that size,
+// strides < TOPK_CHUNK — the wider strides were done by the global steps).
+__global__ __launch_bounds__(TRS_BLOCK) void sort_local_kernel(uint64_t* __restrict__ keys, int64_t first_size,
+                                                              int64_t last_size) {
+  __shared__ uint64_t s[TOPK_CHUNK];
+  const int64_t base = (int64_t)blockIdx.x * TOPK_CHUNK;
+  for (int i = threadIdx.x; i < TOPK_CHUNK; i += TRS_BLOCK) s[i] = keys[base + i];
+  __syncthreads();
+  for (int64_t size = first_size; size <= last_size; size <<= 1) {
+    for (int stride = (int)(size / 2 < TOPK_CHUNK / 2 ? size / 2 : TOPK_CHUNK / 2); stride > 0; stride >>= 1) {
+      for (int i = threadIdx.x; i < TOPK_CHUNK / 2; i += TRS_BLOCK) {
+        const int lo = 2 * i - (i & (stride - 1));
+        const int hi = lo + stride;
+        const bool desc = ((base + lo) & size) == 0;
+        const uint64_t a = s[lo], b = s[hi];
+        if ((a < b) == desc) {
+          s[lo] = b;
+          s[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < TOPK_CHUNK; i += TRS_BLOCK) keys[base + i] = s[i];
+}
+
+__global__ __launch_bounds__(TRS_BLOCK) void sort_emit_kernel(const uint64_t* __restrict__ keys, int64_t k,
+                                                             int64_t* __restrict__ idx_out) {
+  const int64_t stride = (int64_t)gridDim.x * TRS_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x; i < k; i += stride)
+    idx_out[i] = (int64_t)(0xFFFFFFFFu - (uint32_t)(keys[i] & 0xFFFFFFFFu));
+}
+
+static int64_t pow2_at_least(int64_t n, int64_t lo) {
+  int64_t p = lo;
+  while (p < n) p <<= 1;
+  return p;
+}
+
 }  // namespace
 
 extern "C" int trs_hinge_auc(const float* pos_dev, const float* neg_dev, int64_t B, float* loss_sum_dev,
@@ -180,6 +245,7 @@ extern "C" int trs_hinge_backward(const float* pos_dev, const float* neg_dev, in
 
 extern "C" int64_t trs_topk_workspace_bytes(int64_t n, int32_t k) {
   if (n <= 0 || k <= 0) return 0;
+  if (k > TOPK_MAXK) return 8 * pow2_at_least(n, TOPK_CHUNK);  // full sort of the padded keys
   const int64_t nb0 = (n + TOPK_CHUNK - 1) / TOPK_CHUNK;
   const int64_t nb1 = (nb0 * k + TOPK_CHUNK - 1) / TOPK_CHUNK;
   return 8 * (int64_t)k * (nb0 + nb1);
@@ -189,12 +255,26 @@ extern "C" int trs_topk(const float* scores_dev, int64_t n, int32_t k, int64_t* 
                         int64_t workspace_bytes, void* stream) {
   TRS_REQUIRE(n > 0 && n < ((int64_t)1 << 32), "trs_topk: n=%lld outside 1..2^32-1", (long long)n);
   TRS_REQUIRE(k >= 1 && k <= n, "trs_topk: need 1 <= k <= n (k=%d, n=%lld)", k, (long long)n);
-  TRS_REQUIRE(k <= TOPK_MAXK, "trs_topk: k=%d exceeds the supported maximum %d", k, TOPK_MAXK);
   TRS_REQUIRE(scores_dev && idx_out_dev, "trs_topk: scores/idx_out is NULL");
-  TRS_REQUIRE(workspace_bytes >= trs_topk_workspace_bytes(n, k) && (workspace_dev || n <= TOPK_CHUNK),
+  TRS_REQUIRE(workspace_bytes >= trs_topk_workspace_bytes(n, k) && (workspace_dev || (n <= TOPK_CHUNK && k <= TOPK_MAXK)),
               "trs_topk: workspace too small (%lld < %lld)", (long long)workspace_bytes,
               (long long)trs_topk_workspace_bytes(n, k));
   hipStream_t s = (hipStream_t)stream;
+  if (k > TOPK_MAXK) {  // more than a chunk can hand on: sort everything (the reference's torch.sort, model.py:447)
+    const int64_t P = pow2_at_least(n, TOPK_CHUNK);
+    uint64_t* keys = (uint64_t*)workspace_dev;
+    const dim3 bl(TRS_BLOCK), gp(trs_grid(P, TRS_BLOCK)), gh(trs_grid(P / 2, TRS_BLOCK)), gc((unsigned)(P / TOPK_CHUNK));
+    hipLaunchKernelGGL(sort_keys_kernel, gp, bl, 0, s, scores_dev, n, P, keys);
+    hipLaunchKernelGGL(sort_local_kernel, gc, bl, 0, s, keys, (int64_t)2, (int64_t)TOPK_CHUNK);
+    for (int64_t size = 2 * TOPK_CHUNK; size <= P; size <<= 1) {
+      for (int64_t stride = size / 2; stride >= TOPK_CHUNK; stride >>= 1)
+        hipLaunchKernelGGL(sort_global_step_kernel, gh, bl, 0, s, keys, P, size, stride);
+      hipLaunchKernelGGL(sort_local_kernel, gc, bl, 0, s, keys, size, size);
+    }
+    hipLaunchKernelGGL(sort_emit_kernel, dim3(trs_grid(k, TRS_BLOCK)), bl, 0, s, keys, (int64_t)k, idx_out_dev);
+    TRS_CHECK_LAUNCH("topk full sort");
+    return TRS_OK;
+  }
   if (n <= TOPK_CHUNK) {
     hipLaunchKernelGGL((topk_chunk_kernel<true, true>), dim3(1), dim3(TRS_BLOCK), 0, s, scores_dev, nullptr, n, k,
                        nullptr, idx_out_dev);

@@ -137,6 +137,9 @@ struct SortedArgs {
   // the table the runs update: the item table (NULL: T.item / T.item_lin) or one metadata column's tables
   float* tab;
   float* tab_lin;  // never NULL with tab (a Linear scorer's metadata columns pass a scratch array)
+  // 1: K1 has already applied the update of every reference that is alone on its row (item-duplicate flags,
+  // item_flags_kernel): runs of length one are not walked here
+  int skip_single;
 };
 
 constexpr int RUN_CHUNK = 64;  // runs are cut at multiples of this many references
@@ -261,7 +264,10 @@ __device__ __forceinline__ void sorted_item_update_staged_body(const SortedArgs&
     const float c = OPT == OPT_SGD ? -a.lr * gzv : gzv;
     const bool head = il == 0 || kp != k0;                // first reference of the row in this step
     const bool cont = valid && lane > 0 && !head;         // continues the run of the lane before it
-    const bool lead = valid && !cont;
+    // a reference alone on its row (same test as item_flags_kernel): K1 has updated that row already
+    const KeyT kn1 = keys[il + 1 < n ? il + 1 : il];
+    const bool single = head && !(il + 1 < n && kn1 == k0);
+    const bool lead = valid && !cont && !(a.skip_single != 0 && single);
     const uint64_t lmask = __ballot(lead), cmask = __ballot(cont);
     const int nlead = __popcll(lmask);
     const int rank = __popcll(lmask & (((uint64_t)1 << lane) - 1));
@@ -426,6 +432,20 @@ __global__ __launch_bounds__(TRS_BLOCK) void user_flags_kernel(const KeyT* __res
     const int64_t in_seg = s % batch;
     const bool dup = (in_seg > 0 && keys[s - 1] == k) || (in_seg + 1 < batch && keys[s + 1] == k);
     if (dup) flags[vals[s]] = 1;  // the array was zeroed: only the (few) duplicated positions take a scattered byte store
+  }
+}
+
+// iflags[2q + w] = 1 iff the item row of reference w of position q has another reference in q's batch: neighbour compare
+// on the batch's sorted keys, scattered back by payload (2t + w inside the batch).  The array was zeroed.
+__global__ __launch_bounds__(TRS_BLOCK) void item_flags_kernel(const uint32_t* __restrict__ keys,
+                                                              const RefPayload* __restrict__ vals, int64_t n_refs,
+                                                              int64_t per_batch, uint8_t* __restrict__ iflags) {
+  const int64_t stride = (int64_t)gridDim.x * TRS_BLOCK;
+  for (int64_t s = (int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x; s < n_refs; s += stride) {
+    const uint32_t k = keys[s];
+    const int64_t in_seg = s % per_batch;
+    const bool dup = (in_seg > 0 && keys[s - 1] == k) || (in_seg + 1 < per_batch && keys[s + 1] == k);
+    if (dup) iflags[(s - in_seg) + (int64_t)vals[s].tw] = 1;
   }
 }
 
@@ -665,7 +685,8 @@ extern "C" int trs_epoch_presort(const int32_t* stream_ui_dev, const int32_t* ne
                                  uint64_t shuffle_key, uint64_t sample_seed, int64_t first_pos, int64_t n_batches,
                                  int64_t batch, int64_t n_users, int64_t n_items, int32_t* user_dev, int32_t* pos_dev,
                                  int32_t* neg_dev, void* keys_dev, void* vals_dev, void* temp_dev, int64_t temp_bytes,
-                                 int32_t* err_flag_dev, void** sorted_keys_out, void** sorted_vals_out, void* stream) {
+                                 int32_t* err_flag_dev, void** sorted_keys_out, void** sorted_vals_out,
+                                 uint8_t* item_dup_flags_out_dev, void* stream) {
   TRS_REQUIRE(n_batches > 0 && batch > 0 && n_users > 0 && n_items > 0, "trs_epoch_presort: bad sizes");
   TRS_REQUIRE(user_dev && pos_dev && neg_dev && keys_dev && vals_dev && temp_dev, "trs_epoch_presort: NULL buffer");
   TRS_REQUIRE(sorted_keys_out && sorted_vals_out, "trs_epoch_presort: NULL output");
@@ -714,6 +735,12 @@ extern "C" int trs_epoch_presort(const int32_t* stream_ui_dev, const int32_t* ne
   if (e != hipSuccess) {
     trs_set_error("trs_epoch_presort: rocprim::segmented_radix_sort_pairs failed: %s", hipGetErrorString(e));
     return TRS_E_LAUNCH;
+  }
+  if (item_dup_flags_out_dev) {
+    (void)hipMemsetAsync(item_dup_flags_out_dev, 0, n, s);
+    hipLaunchKernelGGL(item_flags_kernel, dim3(trs_grid((int64_t)n, TRS_BLOCK)), bl, 0, s, kin + n, vout, (int64_t)n,
+                       2 * batch, item_dup_flags_out_dev);
+    TRS_CHECK_LAUNCH("item_flags_kernel");
   }
   return TRS_OK;
 }
@@ -978,8 +1005,10 @@ int trs_launch_sorted_meta_update(const trs_tables* tables, int m, float* lin_or
 int trs_launch_sorted_updates_fused(const trs_tables* tables, const void* keys_step, const void* vals_step,
                                     int64_t batch, int64_t item_bits, const float* gz, float lr, const float* ustage,
                                     const void* ukeys_step, const void* uvals_step, int64_t q0, const float* du,
-                                    const OptArgs* opt, int parity, int64_t xpass, int fmsub, hipStream_t s) {
+                                    const OptArgs* opt, int parity, int64_t xpass, int fmsub, int skip_single,
+                                    hipStream_t s) {
   SortedArgs ia = {};
+  ia.skip_single = skip_single;
   ia.T = *tables;
   ia.keys = keys_step;
   ia.vals = (const RefPayload*)vals_step;

@@ -221,6 +221,17 @@ class SparseScorerTrainer:
             memo[batch] = need < 0.3 * free
         return memo[batch]
 
+    def wants_item_inline(self, batch):
+        """K1 applies the item update of references that are ALONE on their row in the batch itself (item-duplicate
+        flags of the presort) when most references are: with uniform ids a reference is alone with probability
+        exp(-2B / n_items) — 0.94 at c4's per-GPU batch (65 536 references over 1M items: the step drops from 48.5 to
+        38.6 us, K2 shrinks to the 6 % duplicated references), 0.27 at c2 (131 072 over 100K: K1's extra flag loads and
+        conditional stores cost more than K2 saves, 45.7 -> 47.1 us).  TRS_ITEM_INLINE=0/1 forces it."""
+        env = os.environ.get("TRS_ITEM_INLINE")
+        if env is not None:
+            return env != "0"
+        return 2 * batch <= 0.7 * self.params[1].shape[0]  # expected share of lone references >= 1/2
+
     def _presort_run(self, i, n_batches, batch, st, shuffle_key, sample_seed, first_pos, given_ids):
         sets = self._ps_sets
         ps = sets[i]
@@ -306,7 +317,9 @@ class SparseScorerTrainer:
 
     def fast_sorted_steps(self, ps, b_in_slice, batch, n_steps, loss_sums, item_meta=None):
         te, evs, ns = self._make_events(n_steps) if self.kernel_events is not None else (None, None, 0)
-        ids, sk, sv, udup, usorted = ps.step_args(b_in_slice)
+        ids, sk, sv, udup, usorted, idup = ps.step_args(b_in_slice)
+        if self.fast_kind != "sgd" or self.M > 0 or not self.wants_item_inline(batch):
+            idup = None  # adaptive rules / metadata scorers / dense regime: every item reference goes through the runs
         if self.ustage is None:
             self.ustage = torch.empty_like(self.du)  # pre-update user rows staged by K1 for the item update
         opt = self._adaptive_rule(n_steps) if self.fast_kind != "sgd" else None
@@ -314,7 +327,7 @@ class SparseScorerTrainer:
                 if self.M > 0 else None)
         ops.train_steps_sgd(self.net.NET, self.net.tables(), None, None, 0, 0, 0, batch, n_steps, self.fast_lr, *ids,
                             self.gz, self.du, loss_sums, self.err, self.scratch, self._stamps(n_steps), evs, sk, sv,
-                            ps.key_bytes, udup, self.ustage, usorted, opt, meta)
+                            ps.key_bytes, udup, self.ustage, usorted, opt, meta, idup)
         if te is not None:
             # 32-bit keys: item and duplicated-user updates are ONE launch, and the last two events are recorded back to
             # back — that interval is the cost of an event record itself

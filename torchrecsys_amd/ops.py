@@ -179,6 +179,8 @@ class EpochPresort:
         self.temp_bytes = max(tmp.value, ut.value)
         self.temp = torch.empty(self.temp_bytes, dtype=torch.uint8, device=device)
         self.user_dup = torch.empty(n_pos, dtype=torch.uint8, device=device)  # 1: user has another reference in its batch
+        # {pos, neg} per position: 1 = the item row has another reference in the batch (K1 updates the others in place)
+        self.item_dup = torch.empty((n_pos, 2), dtype=torch.uint8, device=device)
         self.sorted_keys = self.sorted_vals = None
         self.item_meta, self.n_meta = item_meta, [int(c) for c in n_meta]
         self.meta_keys = [torch.empty(ktot.value, dtype=torch.uint8, device=device) for _ in self.n_meta]
@@ -195,7 +197,7 @@ class EpochPresort:
         check(lib.trs_epoch_presort_sizes(n_batches, batch, n_items, C.byref(kb), C.byref(ktot), C.byref(vtot),
                                           C.byref(tmp)), "trs_epoch_presort_sizes")
         return (12 * n_batches * batch + (1 + n_meta_cols) * (ktot.value + vtot.value) + tmp.value
-                + 17 * n_batches * batch)
+                + 19 * n_batches * batch)
 
     def run(self, stream_ui, neg_static, shuffle_key, sample_seed, first_pos, err_flag, given_ids=None):
         """Generate (stream_ui given) or adopt (given_ids = (user, pos, neg) int32 tensors) the ids and sort the refs."""
@@ -209,7 +211,8 @@ class EpochPresort:
                                             int(first_pos), self.n_batches, self.batch, self.n_users, self.n_items,
                                             ptr(self.ids[0]), ptr(self.ids[1]), ptr(self.ids[2]), ptr(self.keys),
                                             ptr(self.vals), ptr(self.temp), self.temp_bytes, ptr(err_flag),
-                                            C.byref(sk), C.byref(sv), _stream()), "trs_epoch_presort")
+                                            C.byref(sk), C.byref(sv), ptr(self.item_dup), _stream()),
+              "trs_epoch_presort")
         self.sorted_keys, self.sorted_vals = sk.value, sv.value
         uk, uv, ukb = C.c_void_p(), C.c_void_p(), C.c_int32()
         check(_lib.load().trs_epoch_user_dups(ptr(self.ids[0]), self.n_batches, self.batch, self.n_users,
@@ -241,34 +244,43 @@ class EpochPresort:
         return self.pos_meta[o:], self.neg_meta[o:]
 
     def step_args(self, b):
-        """(user, pos, neg id views, sorted keys address, sorted vals address, user-duplicate flags view) for the steps
-        starting at batch b."""
+        """(user, pos, neg id views, sorted keys address, sorted vals address, user-duplicate flags view, sorted user
+        runs, item-duplicate flags view) for the steps starting at batch b."""
         o = b * self.batch
         return ([t[o:] for t in self.ids], self.sorted_keys + 2 * o * self.key_bytes, self.sorted_vals + 2 * o * 4,
                 self.user_dup[o:], (self.sorted_ukeys + o * self.ukey_bytes, self.sorted_uvals + o * 4,
-                                    self.ukey_bytes, o))
+                                    self.ukey_bytes, o), self.item_dup[o:])
 
 
 def train_steps_sgd(net, T, stream_ui, neg_static, shuffle_key, sample_seed, first_pos, batch, n_steps,
                     lr, user_buf, pos_buf, neg_buf, gz_buf, du_buf, loss_sums, err_flag, scratch=None, first_stamp=1,
                     events=None, sorted_keys=None, sorted_vals=None, key_bytes=0, user_dup=None, ustage=None,
-                    user_sorted=None, opt=None, meta=None):
+                    user_sorted=None, opt=None, meta=None, item_dup=None):
     """n_steps fused steps driven from C (trs_train_steps_sgd).  stream_ui None: the steps' ids are already in
     user/pos/neg_buf.  events: optional flat list of 4*n_steps raw hipEvent_t handles.  opt: None (SGD with lr) or a
-    _lib.TrsOpt (SparseAdam / Adagrad on the presorted path; keep the tensors it points to alive)."""
-    ev = None
+    _lib.TrsOpt (SparseAdam / Adagrad on the presorted path; keep the tensors it points to alive).  item_dup: the
+    presort's item-duplicate flags (plain SGD without metadata): K1 also updates item rows referenced once."""
+    a = _lib.TrsTrainArgs()
+    a.net, a.n_steps, a.tables, a.batch, a.lr = NET_ID[net], int(n_steps), C.pointer(T), int(batch), float(lr)
+    a.first_stamp = int(first_stamp)
+    a.stream_ui_dev, a.neg_static_dev = ptr(stream_ui), ptr(neg_static)
+    a.N = 0 if stream_ui is None else stream_ui.shape[0]
+    a.shuffle_key, a.sample_seed, a.first_pos = int(shuffle_key), int(sample_seed), int(first_pos)
+    a.user_buf_dev, a.pos_buf_dev, a.neg_buf_dev = ptr(user_buf), ptr(pos_buf), ptr(neg_buf)
+    a.gz_buf_dev, a.du_buf_dev, a.loss_sums_dev = ptr(gz_buf), ptr(du_buf), ptr(loss_sums)
+    a.err_flag_dev, a.scratch_dev = ptr(err_flag), ptr(scratch)
+    a.sorted_keys_dev, a.sorted_vals_dev, a.key_bytes = sorted_keys, sorted_vals, int(key_bytes)
+    a.user_dup_flags_dev, a.item_dup_flags_dev, a.ustage_buf_dev = ptr(user_dup), ptr(item_dup), ptr(ustage)
+    if user_sorted is not None:
+        a.sorted_ukeys_dev, a.sorted_uvals_dev, a.ukey_bytes, a.slice_pos0 = user_sorted
+    if opt is not None:
+        a.opt = C.pointer(opt)
+    if meta is not None:
+        a.meta = C.pointer(meta)
     if events is not None:
         ev = (C.c_void_p * len(events))(*events)  # raw hipEvent_t handles (or None = step not timed)
-    N = 0 if stream_ui is None else stream_ui.shape[0]
-    check(_lib.load().trs_train_steps_sgd(NET_ID[net], C.byref(T), ptr(stream_ui), ptr(neg_static),
-                                          N, int(shuffle_key), int(sample_seed), int(first_pos), int(batch),
-                                          int(n_steps), float(lr), ptr(user_buf), ptr(pos_buf), ptr(neg_buf),
-                                          ptr(gz_buf), ptr(du_buf), ptr(loss_sums), ptr(err_flag), ptr(scratch),
-                                          int(first_stamp), sorted_keys, sorted_vals, int(key_bytes), ptr(user_dup),
-                                          ptr(ustage), *(user_sorted or (None, None, 0, 0)),
-                                          C.byref(opt) if opt is not None else None,
-                                          C.byref(meta) if meta is not None else None, ev, _stream()),
-          "trs_train_steps_sgd")
+        a.events = C.cast(ev, C.POINTER(C.c_void_p))
+    check(_lib.load().trs_train_steps_sgd(C.byref(a), _stream()), "trs_train_steps_sgd")
 
 
 def rows_scatter_add(table, idx, vals, alpha, ld=None, err_flag=None):
