@@ -67,15 +67,19 @@ CONFIGS = {
 }
 
 
-def synth_stream(n_users, n_items, n, device, seed):
-    """Uniform synthetic interactions with guaranteed dense id coverage, generated in HBM."""
+def synth_stream(n_users, n_items, n, device, seed, rank=0, world=1):
+    """Uniform synthetic interactions with guaranteed dense id coverage, generated in HBM.  world > 1: this
+    rank's shard of a stream partitioned by user (fit()'s dp_partition='user'): the users u with u % world == rank, each
+    of them present, uniform otherwise; items uniform over the whole catalogue."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    users = torch.cat([torch.arange(n_users, device=device, dtype=torch.int32),
-                       torch.randint(0, n_users, (n - n_users,), device=device, dtype=torch.int32, generator=g)])
-    reps = -(-n_users // n_items)
-    items = torch.cat([torch.arange(n_items, device=device, dtype=torch.int32).repeat(reps)[:n_users],
-                       torch.randint(0, n_items, (n - n_users,), device=device, dtype=torch.int32, generator=g)])
+    own = torch.arange(rank, n_users, world, device=device, dtype=torch.int32)
+    n_own = own.numel()
+    users = torch.cat([own, torch.randint(0, n_own, (n - n_own,), device=device, dtype=torch.int32, generator=g)
+                       * world + rank])
+    reps = -(-n_own // n_items)
+    items = torch.cat([torch.arange(n_items, device=device, dtype=torch.int32).repeat(reps)[:n_own],
+                       torch.randint(0, n_items, (n - n_own,), device=device, dtype=torch.int32, generator=g)])
     perm = torch.randperm(n, device=device, generator=g)
     return users[perm].contiguous(), items[perm].contiguous()
 
@@ -88,9 +92,10 @@ def slice_fractions(runner):
     if ps is None:
         return None
     n = ps.n_batches * ps.batch
-    return {"users_alone": 1.0 - float(ps.user_dup[:n].float().mean()),
+    return {"k1_takes_lone_items": ps.key_bytes == 0,  # EpochFlags (accumulate mode); the sorted runs take every item reference
+            "users_alone": 1.0 - float(ps.user_dup[:n].float().mean()),
             "item_refs_alone": 1.0 - float(ps.item_dup[:n].float().mean()),
-            "triples_staging_user_row": float((ps.item_dup[:n].amax(dim=1) > 0).float().mean())}
+            "note": "shares of the references whose row no other reference of the batch names (flags of the presort)"}
 
 
 def kernel_algorithmic_bytes(R, row, state_rows, seen, frac):
@@ -98,14 +103,21 @@ def kernel_algorithmic_bytes(R, row, state_rows, seen, frac):
     once, every row it must write counted once, ids and per-triple scalars; no staging traffic is credited."""
     inline_user = "sorted_updates_fused_kernel" in seen or "sorted_item_update_kernel" in seen
     ua = frac["users_alone"] if frac else 1.0       # K1 writes these user rows itself
-    ia = frac["item_refs_alone"] if (frac and state_rows == 0 and R == 3) else 0.0  # ... and these item rows
+    ia = frac["item_refs_alone"] if (frac and frac.get("k1_takes_lone_items")) else 0.0  # ... and these item rows
     k1 = 16 + R * row + 8 + ((ua + 2 * ia) * (1 + 2 * state_rows) * row if inline_user else 0)
     # K2 (sorted runs): reads ids/coefficients, reads + writes the item rows K1 left (at most one row per reference:
     # an upper bound of the distinct rows) and the user rows of duplicated users
     k2 = 12 + ((2 * (1 - ia)) * 2 + (1 - ua) * 2) * (1 + state_rows) * row
+    acc_apply = 0.0
+    if "flagged_update_kernel" in seen:  # flag mode (sparse regime): K1 reads the triple's R rows and writes the rows of
+        # the references that are alone in the batch; the second launch reads + writes (atomically) one table row per
+        # flagged reference.  Staging (gz, the old user row / gradient row of flagged references) is not credited.
+        k1 = 16 + R * row + (ua + 2 * ia) * row
+        acc_apply = 15 + ((1 - ua) + 2 * (1 - ia)) * 2 * row
     return {"score_kernel<fwd_bwd>": 16 + R * row + 8, "score_sgd_update_kernel": 12 + R * row,
             "fwd_stage_kernel": k1, "item_update_kernel": 12 + 3 * row, "sorted_item_update_kernel": 12 + 3 * row,
-            "sorted_updates_fused_kernel": k2, "user_update_kernel": 4 + row, "sorted_user_dup_update_kernel": 4 + row}
+            "sorted_updates_fused_kernel": k2, "user_update_kernel": 4 + row, "sorted_user_dup_update_kernel": 4 + row,
+            "flagged_update_kernel": acc_apply}
 
 
 def time_pass(model, runner, B, D, R, dev):
@@ -198,7 +210,7 @@ def main():
     cfg = CONFIGS[args.config]
     net, n_users, n_items, n_inter, D, B, desc = (cfg[k] for k in ("net", "n_users", "n_items", "n", "D", "B", "desc"))
     dynamic = args.config != "c1"
-    users, items = synth_stream(n_users, n_items, n_inter, dev, seed=1000 + rank)
+    users, items = synth_stream(n_users, n_items, n_inter, dev, seed=1000 + rank, rank=rank, world=world)
     meta = None
     if cfg["meta"]:  # one categorical id per item and column, every category present
         g = torch.Generator(device=dev)
@@ -216,8 +228,9 @@ def main():
         kw = dict(hidden_layers=cfg["hidden"]) if net == "mlp" else {}
         model = TorchRecSys.from_tensors(users, items, n_users=n_users, n_items=n_items, item_metadata=meta,
                                          n_factors=D, net_type=net, split_ratio=0.8, dynamic_neg_sampling=dynamic,
-                                         use_amp=cfg["amp"], rng="device", seed=7 + rank, pre_sharded=True, **kw)
-        # pre_sharded: every rank generated its own interaction shard
+                                         use_amp=cfg["amp"], rng="device", seed=7 + rank, pre_sharded=True,
+                                         dp_partition="user", **kw)
+        # pre_sharded: every rank generated its own interaction shard, cut by user (each user row has one writer)
     del users, items
     if args.optimizer == "sgd":
         opt = torch.optim.SGD(model.parameters(), lr=1e-2)
@@ -312,8 +325,10 @@ def main():
         "config": {"workload": desc, "global_batch": B * world, "per_gpu_batch": B,
                    "parallelism": (f"dp{world}: interaction stream sharded, tables replicated, one flat all-reduce of the "
                                    f"dense gradients per step" if is_mlp else
-                                   f"dp{world}: interaction stream sharded, tables replicated, no per-step collective "
-                                   f"(FM/Linear have no dense parameters)"),
+                                   f"dp{world}: interaction stream sharded by user_id % {world}, tables replicated, no "
+                                   f"per-step collective (FM/Linear have no dense parameters); item tables averaged per "
+                                   f"epoch, user rows gathered from their owners after fit() — both OUTSIDE the timed "
+                                   f"steps, measured in `replica_sync`"),
                    "rng": "device (Feistel epoch shuffle + Philox4x32-10 negative sampler)"},
     }
     if not is_mlp:
@@ -381,6 +396,25 @@ def main():
     # ---- the north-star pass alone: fused pos+neg gather + pairwise score (trs_score_forward), read-only ----
     if not is_mlp and not args.no_pass and M == 0:
         out["roofline_pass"] = time_pass(model, runner, B, D, R, dev)
+    # ---- data parallel: what fit() adds around the steps (not in the timed region): the per-epoch average of the tables
+    # with several writers and the end-of-fit all-gather of the owners' user rows
+    if world > 1 and not is_mlp:
+        def timed(fn):
+            barrier()
+            t1 = time.perf_counter()
+            fn()
+            barrier()
+            return time.perf_counter() - t1
+        from torchrecsys_amd import dist as tdist
+        model._sync_replicas()  # warm-up of the communicator
+        t_avg = timed(model._sync_replicas)
+        t_gather = timed(lambda: [tdist.gather_owned_rows_(t_.data) for t_ in model._user_tables()])
+        shared = [p_ for p_ in model.net.table_params() if all(p_ is not u_ for u_ in model._user_tables())]
+        out["replica_sync"] = {
+            "per_epoch_average_ms": 1e3 * t_avg, "averaged_bytes": sum(4 * p_.numel() for p_ in shared),
+            "steps_per_epoch": full, "amortised_us_per_step": 1e6 * t_avg / full,
+            "end_of_fit_user_gather_ms": 1e3 * t_gather,
+            "user_table_bytes": sum(4 * t_.numel() for t_ in model._user_tables())}
     # ---- CPU baseline: the op-sequence port of the reference's fit() loop on this box's host cores ----
     # (torch.optim.Adam rejects the sparse gradients of the CPU port's nn.Embedding(sparse=True): no CPU leg for it)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.optimizer != "adam":

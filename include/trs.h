@@ -252,7 +252,12 @@ typedef struct trs_train_args {
   const uint8_t* item_dup_flags_dev; /* (n_steps*batch, 2) NULL, or per triple {pos, neg}: 1 = the item row has another
                                         reference in the batch.  Given (plain SGD, no metadata): K1 also applies the
                                         item update of every reference that is ALONE on its row in place, and the
-                                        sorted-run launch only walks rows referenced more than once */
+                                        sorted-run launch only walks rows referenced more than once.
+                                        FLAG MODE (the sparse regime: most rows of a batch referenced once) = both flag
+                                        arrays (trs_epoch_flags; they may be conservative), given ids, ustage, and NO
+                                        sorted references: the flagged references follow K1 in a small second launch
+                                        that adds their contributions into the tables with float atomics (all reads of
+                                        the step happened in K1, so this is exact up to the order of those sums) */
   float* ustage_buf_dev;     /* (batch, D) */
   const void* sorted_ukeys_dev;
   const void* sorted_uvals_dev;
@@ -281,6 +286,17 @@ int trs_train_steps_sgd(const trs_train_args* args, void* stream);
  * duplicated users: with the slice's sorted (user, position) pairs (offset to the call's first batch; slice_pos0 = that
  * batch's first position in the slice) each run of equal users is summed by one lane group and applied with one plain
  * read-modify-write.  The step then contains no float atomic except for cut runs of hot item rows. */
+/* The sparse regime's whole presort in ONE launch, no sort: the ids of n_batches whole batches (generated as
+ * trs_epoch_presort does, or taken as given) and per-reference duplicate flags — user_dup_flags (n_pos), item_dup_flags
+ * (n_pos, 2) — found with a 2^20-bit bitmap in LDS, one 1024-thread workgroup per batch (set / re-set by the later
+ * arrivals / test).  Tables with more rows than bits are hashed: the flags are then CONSERVATIVE (never 0 for a shared
+ * row, possibly 1 for a lone one), which the flag mode of trs_train_steps_sgd tolerates.  Replaces the shuffle +
+ * slicing + sampler loop of dataset/dataset.py:364-373,414-447 for the slice. */
+int trs_epoch_flags(const int32_t* stream_ui_dev, const int32_t* neg_static_dev, int64_t N, uint64_t shuffle_key,
+                    uint64_t sample_seed, int64_t first_pos, int64_t n_batches, int64_t batch, int64_t n_users,
+                    int64_t n_items, int32_t* user_dev, int32_t* pos_dev, int32_t* neg_dev,
+                    uint8_t* user_dup_flags_out_dev, uint8_t* item_dup_flags_out_dev, int32_t* err_flag_dev,
+                    void* stream);
 int trs_epoch_user_dups_sizes(int64_t n_batches, int64_t batch, int64_t n_users, int64_t* ukeys_bytes_out,
                               int64_t* uvals_bytes_out, int64_t* temp_bytes_out);
 int trs_epoch_user_dups(const int32_t* user_dev, int64_t n_batches, int64_t batch, int64_t n_users, void* ukeys_dev,
@@ -430,13 +446,18 @@ int trs_bn_relu_forward(const void* y_dev, int32_t y_bf16, int64_t rows_per_pass
  * preceding Linear's bias, summed per pass first like trs_colsum.  dy_dev (fp32) and/or dy_bf16_dev (bf16 image for
  * the bf16-resident GEMMs; needs H % 4 == 0), row stride ldd elements.  y_bf16 / dx_bf16 != 0: that input is a bf16
  * image (row strides ld / ldd in elements).  workspace:
- * trs_bn_backward_workspace_floats(...) floats. */
+ * trs_bn_backward_workspace_floats(...) floats.
+ * Synchronised BatchNorm under data parallelism (statistics over the GLOBAL batch): phase 1 only reduces —
+ * sums_dev (passes,2,H) receives this rank's sum(d) and sum(d*xhat) per pass, dgamma / dbeta are written; the caller
+ * all-reduces sums_dev (SUM) and calls phase 2, which applies with those sums and stat_rows = world * rows_per_pass as
+ * the divisor.  phase 0 (sums_dev NULL, stat_rows 0) = both at once on the local batch. */
 int64_t trs_bn_backward_workspace_floats(int64_t rows_per_pass, int32_t H, int32_t passes);
 int trs_bn_relu_backward(const void* y_dev, int32_t y_bf16, const void* dx_dev, int32_t dx_bf16, int64_t rows_per_pass,
                          int32_t passes, int32_t H,
                          int64_t ld, int64_t ldd, int32_t use_bn, const float* mean_dev, const float* var_dev,
                          const float* gamma_dev, const float* beta_dev, float eps, float* dy_dev, void* dy_bf16_dev,
-                         float* dgamma_dev, float* dbeta_dev, float* dy_colsum_dev, float* workspace_dev, void* stream);
+                         float* dgamma_dev, float* dbeta_dev, float* dy_colsum_dev, float* workspace_dev,
+                         int32_t phase, float* sums_dev, int64_t stat_rows, void* stream);
 
 /* out[h] = sum_r w[r] * x[r][h] over the passes*rows_per_pass rows (row_weight NULL: plain column sums): bias
  * gradients and the output layer's weight gradient.  Summed per pass first (identical chunking in both passes), so a

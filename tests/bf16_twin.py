@@ -83,6 +83,8 @@ def train_step_bf16(P, ids, y_bf16=True):
             gr[f"fcs.{l}.bias"] = dy.double().sum(0).float()
             dy16 = rnd(dy)
             gr[f"fcs.{l}.weight"] = mm(dy16.T, c["x"][l])
+            # sum of |products| per element: the scale of the fp32-accumulation error of this reduction over all rows
+            gr[f"absbound.fcs.{l}.weight"] = mm(dy16.abs().T, c["x"][l].abs())
             dx = mm(dy16, W[l])
             if l > 0 and (y_bf16 or not use_bn):
                 dx = rnd(dx)
@@ -96,5 +98,5 @@ def train_step_bf16(P, ids, y_bf16=True):
     loss = torch.clamp(h, min=0).mean()
     gp, dxp = backward(-act, cp)
     gn, dxn = backward(act, cn)
-    grads = {k: gp[k] + gn[k] for k in gp}
+    grads = {k: gp[k] + gn[k] for k in gp}  # (absbound.*: the two passes' bounds add up as well)
     return sp, sn, loss, grads, (dxp, dxn)

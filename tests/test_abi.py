@@ -56,3 +56,34 @@ def test_bad_arguments_return_error_codes_without_a_gpu():
     assert lib.trs_sample_neg(None, 3, 10, 5, 0, 0, None, None) == -1
     with pytest.raises(_lib.TrsError):
         _lib.check(-1, "x")
+
+
+def _header_struct_fields(name):
+    """Member names of `typedef struct NAME { ... } NAME;` in include/trs.h, in declaration order."""
+    import re
+    src = open(os.path.join(ROOT, "include", "trs.h")).read()
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), src, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    out = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        # "float *a, *b"  /  "const void* keys[TRS_MAX_META]"  /  "int32_t x"
+        first, *rest = decl.split(",")
+        out.append(re.sub(r"\[.*\]", "", first.split()[-1]).lstrip("*"))
+        out += [re.sub(r"\[.*\]", "", r_.strip()).lstrip("*").strip() for r_ in rest]
+    return out
+
+
+def test_ctypes_structs_follow_the_header_member_by_member():
+    """A ctypes mirror with a member missing or out of order would shift every device pointer after it by one slot."""
+    import re
+    from torchrecsys_amd import _lib
+    for cname, mirror in (("trs_train_args", _lib.TrsTrainArgs), ("trs_opt", _lib.TrsOpt),
+                          ("trs_meta_stage", _lib.TrsMetaStage), ("trs_tables", _lib.TrsTables),
+                          ("trs_batch", _lib.TrsBatch)):
+        assert _header_struct_fields(cname) == [f[0] for f in mirror._fields_], cname
+    src = open(os.path.join(ROOT, "include", "trs.h")).read()
+    assert int(re.search(r"#define TRS_ABI_VERSION (\d+)", src).group(1)) == _lib.ABI_VERSION
+    assert _lib.load().trs_train_steps_sgd(None, None) == -1  # validated on the host, no launch

@@ -61,16 +61,43 @@ def _worker(rank, world, port, ret):
         assert torch.allclose(t, torch.full((6, 3), 11.0))
         tot = tdist.allreduce_scalar_sum([1.0, float(rank)], torch.device("cpu"))
         assert tot == [2.0, 1.0]
-        # --- the model's per-rank view of a split: cut by rank, unless the caller ingested its own shard already
+        # --- per-layer segments of the bucket: reduced one by one (as the backward produces them), scaled once
+        segs = bucket.segments([[params[0]], [params[1]]])
+        assert segs == [(0, 32), (32, 37)]
+        bucket.flat.fill_(float(rank + 1))
+        works = [bucket.allreduce_segment_async(sg) for sg in reversed(segs)]
+        bucket.finish_segments(works)
+        assert torch.allclose(bucket.flat, torch.full_like(bucket.flat, 1.5))
+        # --- user-partitioned replicas: every rank owns the rows r, r+world, ...; one all-gather makes the table whole
+        tab = torch.full((7, 3), -1.0)
+        tab[rank::world] = torch.arange(7.0)[rank::world, None] * 10 + rank
+        tdist.gather_owned_rows_(tab)
+        want = torch.arange(7.0)[:, None] * 10 + (torch.arange(7) % world)[:, None].float()
+        assert torch.equal(tab, want.expand(7, 3))
+        assert tdist.allreduce_min_int(10 + rank, torch.device("cpu")) == 10
+        # --- the model's per-rank view of a split: cut by user (default) or in contiguous blocks, always truncated to
+        # the shortest rank's length; a caller's own shards (pre_sharded) are only truncated
         from torchrecsys_amd.model import TorchRecSys
-        data = {"user_id": torch.arange(10), "pos_item_id": torch.arange(10)}
+        data = {"user_id": torch.tensor([0, 1, 2, 3, 4, 5, 6, 8, 10, 12]), "pos_item_id": torch.arange(10)}
         m = TorchRecSys.__new__(TorchRecSys)
         m._dev_cache = {}
-        s10, e10 = tdist.equal_shard_bounds(10, rank, world)
-        assert torch.equal(m._rank_rows(data)["user_id"], torch.arange(10)[s10:e10])
+        m.dp_partition = "user"
+        mine = m._rank_rows(data)  # even users: 0 2 4 6 8 10 12 (7 rows), odd users: 1 3 5 (3 rows) -> 3 rows each
+        assert ((mine["user_id"] % world) == rank).all() and mine["user_id"].numel() == 3
+        assert torch.equal(mine["pos_item_id"], torch.arange(10)[(data["user_id"] % world) == rank][:3])
+        assert m._rank_rows(data) is mine  # cached: the MIN all-reduce runs once per split
+        m2 = TorchRecSys.__new__(TorchRecSys)
+        m2._dev_cache = {}
+        m2.dp_partition = "contiguous"
+        data11 = {"user_id": torch.arange(11), "pos_item_id": torch.arange(11)}
+        assert torch.equal(m2._rank_rows(data11)["user_id"], torch.arange(11)[rank * 5:rank * 5 + 5])
         assert tdist.equal_shard_bounds(11, rank, world) == (rank * 5, rank * 5 + 5)  # same length on every rank
-        m.pre_sharded = True
-        assert m._rank_rows(data) is data
+        m3 = TorchRecSys.__new__(TorchRecSys)
+        m3._dev_cache = {}
+        m3.dp_partition = "user"
+        m3.pre_sharded = True  # unequal shards handed in by the caller: every rank keeps the common 7 rows
+        own = {"user_id": torch.arange(10 - 3 * rank), "pos_item_id": torch.arange(10 - 3 * rank)}
+        assert m3._rank_rows(own)["user_id"].numel() == 7
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()

@@ -22,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, net_type, n, ret):
+def _worker(rank, world, port, net_type, n, ret, partition="user"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
@@ -40,6 +40,7 @@ def _worker(rank, world, port, net_type, n, ret):
             kw = {"hidden_layers": [32, 16]} if net_type == "mlp" else {}
             model = TorchRecSys(df, "user", "item", n_factors=16, net_type=net_type, dynamic_neg_sampling=True,
                                 rng="device", seed=3, **kw)
+            model.dp_partition = partition
             w0 = model.net.user.weight.detach().clone()
             g = [torch.empty_like(w0) for _ in range(world)]
             dist.all_gather(g, w0)
@@ -47,27 +48,108 @@ def _worker(rank, world, port, net_type, n, ret):
             opt = torch.optim.SGD(model.parameters(), lr=0.05)
             model.fit(opt, epochs=2, batch_size=256)
             model.evaluate(batch_size=256)
-        # after the per-epoch table average the replicas hold identical tables; dense MLP parameters never diverged
-        for name, p in model.net.named_parameters():
+        # after the per-epoch average of the shared tables (and, by-user partition, the all-gather of the owners' user
+        # rows at the end of fit) the replicas hold identical tables; dense MLP parameters never diverged
+        for name, p in list(model.net.named_parameters()) + [(n_, b_) for n_, b_ in model.net.named_buffers()
+                                                              if b_.is_floating_point()]:
             g = [torch.empty_like(p.data) for _ in range(world)]
             dist.all_gather(g, p.data.contiguous())
             assert torch.allclose(g[0], g[1], rtol=0, atol=1e-6), name
         losses = [float(x.split(":")[-1]) for x in buf.getvalue().splitlines() if "Training Loss" in x]
         assert len(losses) == 2 and losses[1] < losses[0] + 1e-3
         n_train = n - int(np.ceil(0.2 * n))
-        assert model.make_runner(opt, 256).n_train == n_train // world  # equally long shards: same step count on every rank
+        mine = model.make_runner(opt, 256).n_train  # equally long shards: same step count on every rank
+        both = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(both, torch.tensor([mine]))
+        assert int(both[0]) == int(both[1]) and 0.4 * n_train <= mine <= n_train // world + (partition == "user") * 200
+        if partition == "user":  # the rank trains only its own users, and those rows really moved
+            users = model._rank_rows(model.data_processor.train_data)["user_id"]
+            assert bool(((users % world) == rank).all())
+        else:
+            assert mine == n_train // world
         ret[rank] = losses
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("net_type,n", [("fm", 6000), ("mlp", 6000), ("mlp", 5762)])
-def test_two_rank_data_parallel_fit(net_type, n):
+@pytest.mark.parametrize("net_type,n,partition", [("fm", 6000, "user"), ("mlp", 6000, "user"), ("mlp", 5762, "user"),
+                                                  ("linear", 6000, "user"), ("fm", 6000, "contiguous"),
+                                                  ("mlp", 5762, "contiguous")])
+def test_two_rank_data_parallel_fit(net_type, n, partition):
     """n = 5762: the training split (4608 + 1 rows) does not divide by the world size and sits right at a batch boundary —
-    with unequal shards one rank would run a 10th batch and wait forever in the per-step gradient all-reduce."""
+    with unequal shards one rank would run a 10th batch and wait forever in the per-step gradient all-reduce.
+    partition 'user' (default): stream cut by user_id % world, user rows gathered from their owners after fit()."""
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), net_type, n, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), net_type, n, ret, partition), nprocs=world, join=True)
     assert sorted(ret.keys()) == [0, 1]
     assert ret[0] == ret[1]  # the printed loss is the mean over ranks: identical on both
+
+
+def _sync_bn_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from torchrecsys_amd import ops
+        from torchrecsys_amd.collaborative.mlp import MLP
+        from torchrecsys_amd.dist import FlatGradBucket
+        NU, NI, D, B = 300, 200, 32, 256  # B per rank; the single-process reference sees 2B
+        torch.manual_seed(7)  # same weights on both ranks
+        net = MLP(NU, NI, {"c": 11}, D, use_metadata=True, hidden_layers=[64, 32]).to("cuda:0")
+        net.train()
+        rs = np.random.RandomState(3)
+        full = {"user": rs.randint(0, NU, 2 * B), "pos": rs.randint(0, NI, 2 * B), "neg": rs.randint(0, NI, 2 * B),
+                "pos_meta": rs.randint(0, 11, (2 * B, 1)), "neg_meta": rs.randint(0, 11, (2 * B, 1))}
+        dev = lambda d: {k: torch.from_numpy(v).to("cuda:0").contiguous() for k, v in d.items()}
+        state0 = {k: v.clone() for k, v in net.state_dict().items()}
+        # ---- one process, batch 2B, ordinary BatchNorm
+        net.compute.sync_bn = False
+        sc, ctx = net.compute.forward(dev(full), 2, True)
+        g = torch.cat([torch.full((2 * B,), -1.0 / (2 * B)), torch.full((2 * B,), 1.0 / (2 * B))]).to("cuda:0")
+        g = g * torch.linspace(0.5, 1.5, 4 * B, device="cuda:0")  # not a constant: every BN sum matters
+        ref_grads, ref_dx0 = net.compute.backward(ctx, g)
+        ref_state = {k: v.clone() for k, v in net.state_dict().items()}
+        ref_scores = sc.clone()
+        # ---- two ranks, batch B each, synchronised statistics
+        net.load_state_dict(state0)
+        net.compute.sync_bn = True
+        half = {k: v[rank * B:(rank + 1) * B] for k, v in full.items()}
+        sc, ctx = net.compute.forward(dev(half), 2, True)
+        gh = torch.cat([g[:2 * B][rank * B:(rank + 1) * B], g[2 * B:][rank * B:(rank + 1) * B]]) * world  # 1/B_local scaling
+        bucket = FlatGradBucket(net.dense_params())
+        grads, dx0 = net.compute.backward(ctx, gh, grad_of=bucket.grad_of)
+        bucket.allreduce_mean_()
+        want = torch.cat([ref_scores[:2 * B][rank * B:(rank + 1) * B], ref_scores[2 * B:][rank * B:(rank + 1) * B]])
+        err = float((sc - want).abs().max() / want.abs().max())
+        assert err < 1e-5, ("scores", err)
+        for p in net.dense_params():
+            a, b = bucket.grad_of(p), ref_grads[p]
+            e = float((a - b).abs().max() / max(float(b.abs().max()), 1e-12))
+            assert e < 2e-5 or float(b.abs().max()) < 1e-7, (e, tuple(p.shape))
+        # this rank's rows of the embedding gradient: dx0 is scaled by world relative to the global-mean loss
+        ref_rows = torch.cat([ref_dx0[:2 * B][rank * B:(rank + 1) * B], ref_dx0[2 * B:][rank * B:(rank + 1) * B]])
+        e = float((dx0 / world - ref_rows).abs().max() / ref_rows.abs().max())
+        assert e < 2e-5, ("dx0", e)
+        for k, v in net.state_dict().items():
+            if "running" in k:
+                e = float((v - ref_state[k]).abs().max() / ref_state[k].abs().max())
+                assert e < 1e-5, (k, e)
+            if "num_batches_tracked" in k:
+                assert int(v) == int(ref_state[k]) == 2
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sync_batchnorm_equals_one_process():
+    """fit(sync_bn=True): two ranks with batch B each compute, on the dense path, what one process computes with batch
+    2B — scores at 1e-5, the all-reduced dense gradients, the embedding-gradient rows and the BatchNorm running
+    statistics (forward statistics and the two backward sums are all-reduced per layer and pass)."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_sync_bn_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: "ok", 1: "ok"}

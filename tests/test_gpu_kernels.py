@@ -601,6 +601,69 @@ def test_gemm_fused_bn_statistics(B, passes, K, H, bf16):
 
 
 @pytest.mark.parametrize("net,D,skew", [("fm", 64, False), ("fm", 64, True), ("fm", 16, True), ("linear", 32, True),
+                                        ("fm", 80, False), ("fm", 10, True), ("fm", 128, False)])
+@pytest.mark.parametrize("n_users", [300, 3_000_000])
+def test_flag_mode_matches_oracle(net, D, skew, n_users):
+    """The sparse regime's step (trs_epoch_flags + K1 taking every lone reference + flagged_update_kernel): rows
+    referenced once in the batch updated in place by K1, the flagged references added with float atomics afterwards — 3
+    batches in one C call == oracle SGD steps.  n_users = 3M: more rows than bitmap bits, so the user flags are
+    hashed (conservative) — flagged lone rows must still be exact.  Flags: exact where the table fits the bitmap."""
+    ops = _ops()
+    rs = np.random.RandomState(D + skew)
+    NU, NI, B, nb, lr = n_users, 57 if n_users == 300 else 5000, 512, 3, 0.05
+    p, _, _ = make_case(net, D, 0, 8, NU=300, NI=NI, seed=2)
+    urows = np.sort(rs.choice(NU, 300, replace=False)) if NU > 300 else np.arange(300)  # the users that occur
+    u_small = rs.randint(0, 300, nb * B)
+    u = urows[u_small]
+    i = rs.randint(0, NI, nb * B)
+    j = rs.randint(0, NI, nb * B)
+    if skew:
+        i[rs.rand(nb * B) < 0.4] = 7
+        j[rs.rand(nb * B) < 0.4] = 7
+    lin = ("user_bias.weight", "item_bias.weight") if net == "linear" else ("linear_user.weight", "linear_item.weight")
+    t = {k: torch.from_numpy(v.copy()).to(DEV) for k, v in p.items()}
+    if NU > 300:  # full-size user tables holding the 300 small rows at their places
+        big = torch.zeros((NU, D), device=DEV)
+        big[torch.from_numpy(urows).to(DEV)] = t["user.weight"]
+        big1 = torch.zeros((NU, 1), device=DEV)
+        big1[torch.from_numpy(urows).to(DEV)] = t[lin[0]]
+        t["user.weight"], t[lin[0]] = big, big1
+    T, keep = ops.make_tables(t["user.weight"], t["item.weight"], t[lin[0]], t[lin[1]])
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ef = ops.EpochFlags(nb, B, NU, NI, DEV)
+    ef.run(None, None, 0, 0, 0, err, given_ids=[torch.from_numpy(a.astype(np.int32)).to(DEV) for a in (u, i, j)])
+    ids, udup, idup = ef.step_args(0)
+    for b in range(nb):
+        sl = slice(b * B, (b + 1) * B)
+        ucnt = np.unique(u[sl], return_counts=True)
+        want_u = np.array([dict(zip(ucnt[0], ucnt[1]))[x] > 1 for x in u[sl]])
+        got_u = udup[sl].cpu().numpy().astype(bool)
+        assert (got_u | ~want_u).all()  # never 0 for a shared row
+        if NU <= 1 << 20:
+            assert np.array_equal(got_u, want_u)
+        cnt = np.bincount(np.concatenate([i[sl], j[sl]]), minlength=NI)
+        want_i = np.stack([cnt[i[sl]] > 1, cnt[j[sl]] > 1], axis=1)
+        assert np.array_equal(idup[sl].cpu().numpy().astype(bool), want_i)
+    gz, du = torch.empty((2, B), device=DEV), torch.empty((B, D), device=DEV)
+    losses = torch.zeros(nb, device=DEV)
+    ops.train_steps_sgd(net, T, None, None, 0, 0, 0, B, nb, lr, *ids, gz, du, losses, err,
+                        ops.train_scratch(NU, NI, B, D, DEV), 1, None, user_dup=udup, item_dup=idup,
+                        ustage=torch.empty((B, D), device=DEV))
+    torch.cuda.synchronize()
+    ref = {k: v.copy() for k, v in p.items()}
+    for b in range(nb):
+        batch = {"user_id": u_small[b * B:(b + 1) * B], "pos_item_id": i[b * B:(b + 1) * B], "neg_item_id": j[b * B:(b + 1) * B]}
+        _, _, loss, grads = onets.train_forward_backward(net, ref, batch)
+        ooptim.sgd_step(ref, grads, lr)
+        assert abs(losses[b].item() / B - float(loss)) <= TOL * max(abs(float(loss)), 1e-3)
+    ut = torch.from_numpy(urows).to(DEV)
+    for k, v in ref.items():
+        got = t[k][ut] if (NU > 300 and k in ("user.weight", lin[0])) else t[k]
+        assert rel_err(got.cpu().numpy(), v) < TOL, k
+    assert err.item() == 0
+
+
+@pytest.mark.parametrize("net,D,skew", [("fm", 64, False), ("fm", 64, True), ("fm", 16, True), ("linear", 32, True),
                                         ("fm", 80, False), ("fm", 10, True)])
 @pytest.mark.parametrize("inline_user", [False, True, "items"])
 def test_presorted_item_update_matches_oracle(net, D, skew, inline_user):

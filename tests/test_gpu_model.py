@@ -471,7 +471,8 @@ def test_mlp_bf16_resident_step_matches_the_bf16_oracle(use_bn, M, shape):
                 continue  # mathematically zero in front of train-mode BatchNorm: rounding noise on both sides
             # BatchNorm's gamma / beta gradients are cancelling sums over the batch (sum d*xhat, sum d): an element of
             # y_l that rounds to the neighbouring bf16 value moves them a little further than the GEMM outputs
-            assert rel_err(grads[p_].cpu().numpy(), og[k]) < (5e-3 if k.startswith("bns") else TOL16), k
+            # (likewise the output layer's: g = -+1/B, the positive and the negative pass nearly cancel)
+            assert rel_err(grads[p_].cpu().numpy(), og[k]) < (5e-3 if k.startswith(("bns", "output_layer")) else TOL16), k
     dx = dx0.cpu().numpy().astype(np.float64)
     gu = np.zeros((n_u, D))
     np.add.at(gu, h["user"], dx[:B, :D] + dx[B:, :D])

@@ -67,10 +67,18 @@ def test_presorted_step_random_shapes(case):
             o.user_s2, o.item_s2, o.user_lin_s2, o.item_lin_s2 = (ops.ptr(s2[k]) for k in names)
         o.gacc, o.gacc_lin, o.cut_rows, o.cut_count = ops.ptr(gacc), ops.ptr(gacc_lin), ops.ptr(cut_rows), ops.ptr(cut_count)
         o.cut_capacity = cut_rows.numel()
-    ops.train_steps_sgd(net, T, None, None, 0, 0, 0, B, nb, lr, *ids, gz, du, losses, err,
-                        ops.train_scratch(NU, NI, B, D, DEV), 1, None, sk, sv, ps.key_bytes, udup,
-                        torch.empty((B, D), device=DEV), usorted, o,
-                        item_dup=idup if kind == "sgd" else None)  # plain SGD: K1 also takes item rows referenced once
+    if kind == "sgd" and seed_ % 2 == 0:  # every other SGD case: the sparse regime's flag mode (no sorted runs)
+        ef = ops.EpochFlags(nb, B, NU, NI, DEV)
+        ef.run(None, None, 0, 0, 0, err, given_ids=[torch.from_numpy(a.astype(np.int32)).to(DEV) for a in (u, i, j)])
+        fids, fu, fi = ef.step_args(0)
+        ops.train_steps_sgd(net, T, None, None, 0, 0, 0, B, nb, lr, *fids, gz, du, losses, err,
+                            ops.train_scratch(NU, NI, B, D, DEV), 1, None, user_dup=fu, item_dup=fi,
+                            ustage=torch.empty((B, D), device=DEV))
+    else:
+        ops.train_steps_sgd(net, T, None, None, 0, 0, 0, B, nb, lr, *ids, gz, du, losses, err,
+                            ops.train_scratch(NU, NI, B, D, DEV), 1, None, sk, sv, ps.key_bytes, udup,
+                            torch.empty((B, D), device=DEV), usorted, o,
+                            item_dup=idup if kind == "sgd" else None)  # plain SGD: K1 also takes item rows referenced once
     torch.cuda.synchronize()
     ref = {k: v.copy() for k, v in p.items()}
     r1 = {k: np.zeros_like(v) for k, v in p.items()}

@@ -89,7 +89,8 @@ class TrsTrainArgs(C.Structure):
                 ("sorted_keys_dev", C.c_void_p), ("sorted_vals_dev", C.c_void_p), ("key_bytes", C.c_int32),
                 ("ukey_bytes", C.c_int32), ("user_dup_flags_dev", C.c_void_p), ("item_dup_flags_dev", C.c_void_p),
                 ("ustage_buf_dev", C.c_void_p), ("sorted_ukeys_dev", C.c_void_p), ("sorted_uvals_dev", C.c_void_p),
-                ("slice_pos0", C.c_int64), ("opt", C.POINTER(TrsOpt)), ("meta", C.POINTER(TrsMetaStage)),
+                ("slice_pos0", C.c_int64),
+                ("opt", C.POINTER(TrsOpt)), ("meta", C.POINTER(TrsMetaStage)),
                 ("events", C.POINTER(C.c_void_p))]
 
 
@@ -119,6 +120,8 @@ PROTOTYPES = {
     "trs_train_steps_sgd": (C.c_int, [C.POINTER(TrsTrainArgs), _vp]),
     "trs_epoch_presort_meta": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _i64, _vp,
                                          C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp, _vp, _vp]),
+    "trs_epoch_flags": (C.c_int, [_vp, _vp, _i64, _u64, _u64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
+                                  _vp]),
     "trs_epoch_user_dups_sizes": (C.c_int, [_i64, _i64, _i64, c_int64_p, c_int64_p, c_int64_p]),
     "trs_epoch_user_dups": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, C.POINTER(C.c_void_p),
                                       C.POINTER(C.c_void_p), c_int32_p, _vp]),
@@ -148,7 +151,7 @@ PROTOTYPES = {
                                       _i64, _vp]),
     "trs_bn_backward_workspace_floats": (C.c_int64, [_i64, _i32, _i32]),
     "trs_bn_relu_backward": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _i32, _i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _f,
-                                       _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                       _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp]),
     "trs_colsum_workspace_floats": (C.c_int64, [_i64, _i32, _i32]),
     "trs_colsum": (C.c_int, [_vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
     "trs_rowdot": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),

@@ -12,6 +12,7 @@ from ._scorer import _NO_GPU, as_id_matrix, check_err_flag
 
 
 class MLP(torch.nn.Module):
+    PREDICT_CHUNK = 262_144  # items scored per pass by score_all_items (eval mode: the result does not depend on it)
 
     def __init__(self, n_users, n_items, n_metadata, n_factors, use_metadata=True, use_batch_norm: bool = True,
                  hidden_layers: List[int] = None, use_cuda=False, use_bf16=False):
@@ -135,10 +136,20 @@ class MLP(torch.nn.Module):
         if not 0 <= user_id < self.n_users:
             raise IndexError(f"index out of range in self (user_id {user_id} outside [0, {self.n_users}))")
         dev = self.user.weight.device
-        ids = {"user": torch.full((self.n_items,), user_id, dtype=torch.int64, device=dev),
-               "pos": torch.arange(self.n_items, dtype=torch.int64, device=dev)}
-        if self.n_meta_tables():
-            ids["pos_meta"] = item_meta_dev.long().contiguous()
-        out, _ = self.compute.forward(ids, 1, self.training)
+        # item chunks (the reference's prediction_batch_size loop, model.py:384): a whole-catalogue pass would keep every
+        # layer's activations of all n_items rows alive at once (c5: 1M items x [1280, 1024, 512, 256] floats > 10 GB)
+        out = torch.empty(self.n_items, dtype=torch.float32, device=dev)
+        chunk = self.PREDICT_CHUNK
+        if self.training and self.use_batch_norm:
+            chunk = self.n_items  # train-mode BatchNorm normalises with the statistics of the rows it is given
+        for s in range(0, self.n_items, chunk):
+            e = min(s + chunk, self.n_items)
+            ids = {"user": torch.full((e - s,), user_id, dtype=torch.int64, device=dev),
+                   "pos": torch.arange(s, e, dtype=torch.int64, device=dev)}
+            if self.n_meta_tables():
+                ids["pos_meta"] = item_meta_dev[s:e].long().contiguous()
+            part, ctx = self.compute.forward(ids, 1, self.training)
+            out[s:e] = part
+            del ctx
         self._check_err("predict")
         return out

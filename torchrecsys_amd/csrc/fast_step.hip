@@ -112,7 +112,7 @@ __device__ __forceinline__ RawIds issue_ids(const FastArgs& a, int64_t t) {
   r.dup = 1;
   r.idup = 0x0101;
   if (INL) r.dup = a.udup_pos[tc];
-  if (INL == 2) r.idup = reinterpret_cast<const uint16_t*>(a.idup_pos)[tc];
+  if (INL >= 2) r.idup = reinterpret_cast<const uint16_t*>(a.idup_pos)[tc];
   return r;
 }
 
@@ -329,6 +329,74 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
 #pragma unroll
     for (int w = 0; w < TRS_BLOCK / TRS_WAVE; ++w) L += s_loss[w];
     if (L != 0.f) atomicAdd(a.loss_sum, L);
+  }
+}
+
+// Flag mode (the sparse regime: duplicate flags from trs_epoch_flags, no sorted runs), second launch of a step.  K1 has
+// updated every row whose reference is alone in the batch and staged, for the flagged references, what their update
+// needs: gz, the old user row (ustage) for item references, the gradient row (du) for users.  All reads of the step
+// happened in K1, so the flagged references now add their contributions straight into the tables with float atomics:
+//   item[row] += (-lr * gz) * ustage[t]      user[u] += -lr * du[t]      (+ the 1-wide terms)
+// One lane per reference of the batch for detection (3B: users, positives, negatives; FLG_REFS per wave, ids and flags
+// read coalesced), then the wave walks its flagged references FLG_U at a time: the staged rows of a round are loaded
+// together, every lane one element per instruction — a row is adjacent dwords, the full-rate atomic shape
+// (MI355X_MICROARCH.md "Global float atomics").  c4: 6 % of the item references, 3 % of the users (hashed flags).
+constexpr int FLG_REFS = 32, FLG_U = 4;
+
+template <int KD>  // ceil(D / 64)
+__global__ __launch_bounds__(TRS_BLOCK) void flagged_update_kernel(const FastArgs a) {
+  const trs_tables& T = a.T;
+  const int D = T.D;
+  const int64_t B = a.B, n = 3 * a.B;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x) >> 6;
+  const int64_t nwave = ((int64_t)gridDim.x * TRS_BLOCK) >> 6;
+  for (int64_t base = wave * FLG_REFS; base < n; base += nwave * FLG_REFS) {
+    const int64_t r = base + lane;
+    const bool valid = lane < FLG_REFS && r < n;
+    const int64_t rc = valid ? r : base;
+    const int which = (int)(rc / B);  // 0 user, 1 positive, 2 negative
+    const int t = (int)(rc - (int64_t)which * B);
+    const int32_t row = which == 0 ? a.user[t] : (which == 1 ? a.pos[t] : a.neg[t]);
+    const uint8_t flag = which == 0 ? a.udup_pos[t] : a.idup_pos[2 * t + (which - 1)];
+    // coefficient of the staged row: -lr for a user's gradient row, -lr*gz of the pass for an item reference
+    const float gp = a.gz[t], gn = a.gz[B + t];
+    const float c = which == 0 ? -a.lr : (-a.lr * (which == 1 ? gp : gn));
+    const float clin = which == 0 ? -a.lr * (gp + gn) : c;
+    uint64_t mask = __ballot(valid && flag != 0);
+    while (mask) {
+      int l[FLG_U];
+      bool has[FLG_U];
+      float x[FLG_U][KD], cc[FLG_U];
+      float* dst[FLG_U];
+#pragma unroll
+      for (int k = 0; k < FLG_U; ++k) {
+        has[k] = mask != 0;
+        l[k] = has[k] ? __ffsll((unsigned long long)mask) - 1 : 0;
+        mask &= mask - 1;  // (0 & anything stays 0)
+        const int wk = __shfl(which, l[k], 64);
+        const int64_t tk = __shfl(t, l[k], 64), rk = __shfl(row, l[k], 64);
+        cc[k] = __shfl(c, l[k], 64);
+        const float* src = (wk == 0 ? a.du : a.ustage) + tk * (int64_t)D;
+        dst[k] = (wk == 0 ? T.user : T.item) + rk * (int64_t)D;
+#pragma unroll
+        for (int q = 0; q < KD; ++q) {
+          const int e = q * TRS_WAVE + lane;
+          x[k][q] = src[e < D ? e : 0];  // unconditional (clamped) loads: all FLG_U rows in flight together
+        }
+        const float cl = __shfl(clin, l[k], 64);  // (every lane shuffles: a shuffle under `lane == 0` reads a dead lane)
+        if (lane == 0 && has[k]) atomicAdd((wk == 0 ? T.user_lin : T.item_lin) + rk, cl);
+      }
+#pragma unroll
+      for (int k = 0; k < FLG_U; ++k) {
+        if (!has[k]) continue;
+#pragma unroll
+        for (int q = 0; q < KD; ++q) {
+          const int e = q * TRS_WAVE + lane;
+          if (e < D) atomicAdd(dst[k] + e, cc[k] * x[k][q]);
+        }
+      }
+    }
   }
 }
 
@@ -1096,6 +1164,18 @@ static int launch_fwd_stage(const FastArgs& a, hipStream_t s) {
   return TRS_E_ARG;
 }
 
+static int launch_flagged_update(const FastArgs& a, hipStream_t s) {
+  const dim3 gr(trs_grid((3 * a.B + FLG_REFS - 1) / FLG_REFS, TRS_BLOCK / TRS_WAVE)), bl(TRS_BLOCK);
+  const int kd = (a.T.D + TRS_WAVE - 1) / TRS_WAVE;
+  if (kd <= 1) hipLaunchKernelGGL(flagged_update_kernel<1>, gr, bl, 0, s, a);
+  else if (kd <= 2) hipLaunchKernelGGL(flagged_update_kernel<2>, gr, bl, 0, s, a);
+  else if (kd <= 4) hipLaunchKernelGGL(flagged_update_kernel<4>, gr, bl, 0, s, a);
+  else if (kd <= 8) hipLaunchKernelGGL(flagged_update_kernel<8>, gr, bl, 0, s, a);
+  else hipLaunchKernelGGL(flagged_update_kernel<16>, gr, bl, 0, s, a);
+  TRS_CHECK_LAUNCH("flagged_update_kernel");
+  return TRS_OK;
+}
+
 template <int WHICH>  // 0: item owners (K2a), 1: users (K3), 2: duplicated users only (K3')
 static int launch_plain(const FastArgs& a, hipStream_t s) {
   RowCfg c;
@@ -1280,8 +1360,15 @@ extern "C" int trs_train_steps_sgd(const trs_train_args* args, void* stream) {
   }
   const bool adaptive = opt && opt->kind != TRS_OPT_SGD;
   // K1 takes the item references that are alone on their row: plain SGD without metadata on the fused two-launch step
+  // flag mode (sparse regime): both flag arrays, no sorted references — K1 takes every reference that is alone on its
+  // row, the flagged ones follow in flagged_update_kernel
+  const bool flgm = !sorted && user_dup_flags_dev && args->item_dup_flags_dev;
+  if (flgm)
+    TRS_REQUIRE(!from_stream && !adaptive && !meta && ustage_buf_dev,
+                "trs_train_steps_sgd: the flag mode takes given ids, both flag arrays and the (batch,D) staging buffer "
+                "(plain SGD, no metadata, no sorted references)");
   const bool item_inl = args->item_dup_flags_dev && inl && !adaptive && !meta && key_bytes == 4 && ukey_bytes == 4;
-  TRS_REQUIRE(!args->item_dup_flags_dev || item_inl,
+  TRS_REQUIRE(!args->item_dup_flags_dev || item_inl || flgm,
               "trs_train_steps_sgd: item-duplicate flags need the presorted plain-SGD step without metadata");
   if (meta) {
     TRS_REQUIRE(sorted_keys_dev && user_dup_flags_dev && key_bytes == 4 && ukey_bytes == 4,
@@ -1361,6 +1448,11 @@ extern "C" int trs_train_steps_sgd(const trs_train_args* args, void* stream) {
       a.ustage = ustage_buf_dev;
       if (item_inl) a.idup_pos = args->item_dup_flags_dev + (int64_t)st * 2 * batch;
     }
+    if (flgm) {
+      a.udup_pos = user_dup_flags_dev + (int64_t)st * batch;
+      a.idup_pos = args->item_dup_flags_dev + (int64_t)st * 2 * batch;
+      a.ustage = ustage_buf_dev;
+    }
     if (adaptive) {  // this step's effective learning rate, in double like the Python floats of torch.optim
       OptArgs& o = a.o;
       const double t = (double)(opt->step0 + st + 1);
@@ -1419,6 +1511,15 @@ extern "C" int trs_train_steps_sgd(const trs_train_args* args, void* stream) {
     }
     if (rc) return rc;
     if (ev) (void)hipEventRecord(ev[1], s);
+    if (flgm) {  // the flagged references: float atomics into the tables (every read of the step is behind us)
+      rc = launch_flagged_update(a, s);
+      if (rc) return rc;
+      if (ev) {
+        (void)hipEventRecord(ev[2], s);
+        (void)hipEventRecord(ev[3], s);
+      }
+      continue;
+    }
     if (sorted) {  // K2: per-run owner update from the presorted references, then K3
       const char* ks = (const char*)sorted_keys_dev + (int64_t)st * 2 * batch * key_bytes;
       const char* vs = (const char*)sorted_vals_dev + (int64_t)st * 2 * batch * 4;

@@ -282,6 +282,7 @@ struct BnBwdArgs {
   unsigned short* dy16;  // optional bf16 copy of dy (row stride ldd elements): what the bf16-resident GEMMs read
   const unsigned short* y16;   // bf16 images of y / dx when the fp32 pointers are NULL (bf16-resident path)
   const unsigned short* dx16;
+  float inv_n;  // 1 / rows the statistics were taken over (rows_per_pass; world * rows_per_pass under sync-BatchNorm)
 };
 
 __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_final_kernel(const float* __
 __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_apply_kernel(const BnBwdArgs a) {
   const int64_t rows = a.rows_per_pass * a.passes;
   const int64_t total = rows * a.H;
-  const float invB = 1.0f / (float)a.rows_per_pass;
+  const float invB = a.inv_n;
   const int64_t stride = (int64_t)gridDim.x * TRS_BLOCK;
   for (int64_t e = (int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x; e < total; e += stride) {
     const int64_t row = e / a.H;
@@ -615,7 +616,7 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_apply_v4_kernel(const BnBwdA
   const int64_t r0 = (int64_t)chunk * CHUNK_ROWS;
   const int64_t r1 = (r0 + CHUNK_ROWS < a.rows_per_pass) ? r0 + CHUNK_ROWS : a.rows_per_pass;
   const int64_t base = (int64_t)pass * a.rows_per_pass;
-  const float invB = 1.0f / (float)a.rows_per_pass;
+  const float invB = a.inv_n;
   float mu[4], is[4], ga[4], be[4], m1[4], m2[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -829,26 +830,32 @@ extern "C" int trs_bn_relu_backward(const void* y_dev, int32_t y_bf16, const voi
                                     int32_t H, int64_t ld, int64_t ldd, int32_t use_bn, const float* mean_dev,
                                     const float* var_dev, const float* gamma_dev, const float* beta_dev, float eps,
                                     float* dy_dev, void* dy_bf16_dev, float* dgamma_dev, float* dbeta_dev,
-                                    float* dy_colsum_dev, float* workspace_dev, void* stream) {
-  TRS_REQUIRE(y_dev && dx_dev && (dy_dev || dy_bf16_dev) && workspace_dev, "trs_bn_relu_backward: NULL argument");
+                                    float* dy_colsum_dev, float* workspace_dev, int32_t phase, float* sums_dev,
+                                    int64_t stat_rows, void* stream) {
+  TRS_REQUIRE(y_dev && dx_dev && (dy_dev || dy_bf16_dev || phase == 1) && workspace_dev,
+              "trs_bn_relu_backward: NULL argument");
+  TRS_REQUIRE(phase >= 0 && phase <= 2 && (phase == 0 || (sums_dev && use_bn)) && stat_rows >= 0,
+              "trs_bn_relu_backward: phases 1 / 2 need BatchNorm and the (passes,2,H) sums buffer");
   TRS_REQUIRE(rows_per_pass > 0 && H > 0 && ld >= H && ldd >= H && passes >= 1 && passes <= 2,
               "trs_bn_relu_backward: bad shape");
   TRS_REQUIRE(!use_bn || (mean_dev && var_dev && gamma_dev && beta_dev), "trs_bn_relu_backward: BN tensors are NULL");
   const int nc = n_chunks_of(rows_per_pass);
   const int gx = (H + TRS_BLOCK - 1) / TRS_BLOCK;
   hipStream_t s = (hipStream_t)stream;
-  float* sums = workspace_dev + (int64_t)passes * nc * 2 * H;  // (passes,2,H) behind the partials
-  float* cs_part = sums + (int64_t)passes * 2 * H;             // (passes,nc,H) column-sum partials of dy
+  float* sums = sums_dev ? sums_dev : workspace_dev + (int64_t)passes * nc * 2 * H;  // (passes,2,H) behind the partials
+  float* cs_part = workspace_dev + (int64_t)passes * nc * 2 * H + (int64_t)passes * 2 * H;  // (passes,nc,H) column-sum partials of dy
   const bool h16 = y_bf16 || dx_bf16;
   BnBwdArgs a = {y_bf16 ? nullptr : (const float*)y_dev, dx_bf16 ? nullptr : (const float*)dx_dev, dy_dev,
                  rows_per_pass, ld, ldd, H, passes, use_bn, nc, mean_dev, var_dev, gamma_dev, beta_dev, eps,
                  workspace_dev, sums, dy_colsum_dev ? cs_part : nullptr, (unsigned short*)dy_bf16_dev,
-                 y_bf16 ? (const unsigned short*)y_dev : nullptr, dx_bf16 ? (const unsigned short*)dx_dev : nullptr};
+                 y_bf16 ? (const unsigned short*)y_dev : nullptr, dx_bf16 ? (const unsigned short*)dx_dev : nullptr,
+                 1.0f / (float)(stat_rows > 0 ? stat_rows : rows_per_pass)};
   const bool v4in = H % 4 == 0 && ld % 4 == 0 && ldd % 4 == 0 && ((uintptr_t)y_dev & (y_bf16 ? 7 : 15)) == 0 &&
                     ((uintptr_t)dx_dev & (dx_bf16 ? 7 : 15)) == 0 && v4_ok(workspace_dev, H, 4);
   const bool v4a = v4in && (!dy_dev || v4_ok(dy_dev, H, ldd)) && (!dy_bf16_dev || ((uintptr_t)dy_bf16_dev & 7) == 0);
-  TRS_REQUIRE(v4a || (dy_dev && !dy_bf16_dev && !h16),
+  TRS_REQUIRE(v4a || phase == 1 || (dy_dev && !dy_bf16_dev && !h16),
               "trs_bn_relu_backward: bf16 images need H %% 4 == 0 and aligned rows");
+  TRS_REQUIRE(phase != 1 || v4in || !h16, "trs_bn_relu_backward: bf16 images need H %% 4 == 0 and aligned rows");
   const V4Shape v = v4_shape(H % 4 == 0 ? H : 4);
   const dim3 g4(v.gx, nc, passes), bl(TRS_BLOCK);
   // (y, dx) image types of the bf16-resident path: (bf16, bf16) inside the net, (bf16, fp32) at the last hidden layer
@@ -860,7 +867,7 @@ extern "C" int trs_bn_relu_backward(const void* y_dev, int32_t y_bf16, const voi
     else hipLaunchKernelGGL((KERNEL<false, false>), g4, bl, 0, s, a, v.tpr);                 \
   }
   TRS_REQUIRE(!dx_bf16 || y_bf16, "trs_bn_relu_backward: a bf16 dx comes with a bf16 y");
-  if (use_bn) {
+  if (use_bn && phase != 2) {
     if (v4in) {
       TRS_BWD(bn_bwd_reduce_v4_kernel)
     } else {
@@ -871,6 +878,7 @@ extern "C" int trs_bn_relu_backward(const void* y_dev, int32_t y_bf16, const voi
                        dgamma_dev, dbeta_dev);
     TRS_CHECK_LAUNCH("bn_bwd_final_kernel");
   }
+  if (phase == 1) return TRS_OK;  // the caller reduces `sums` over ranks, then calls phase 2 with stat_rows = world * rows
   if (v4a) {
     TRS_BWD(bn_bwd_apply_v4_kernel)
     TRS_CHECK_LAUNCH("bn_bwd_apply_kernel");

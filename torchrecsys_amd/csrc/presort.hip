@@ -113,6 +113,167 @@ __global__ __launch_bounds__(TRS_BLOCK) void epoch_refs_kernel(const EpochArgs a
   }
 }
 
+// ---------------------------------------------------------------------------------------------- duplicate flags only
+// The sparse regime (c4: 65 536 item references over 1M rows, 32 768 users over 10M per step) needs no grouping at all:
+// 94 % of the item references and 99.7 % of the users are alone on their row in the batch, K1 updates those rows in
+// place, and the few shared rows meet in a gradient accumulator (fast_step.hip, INL 3).  All K1 needs from the epoch is
+// one flag per reference: "another reference of this batch names the same row".  One 1024-thread workgroup per batch
+// finds them with a bitmap in LDS (2^20 bits = 128 KB of the CU's 160 KB):
+//   A  every reference sets its row's bit (ds_or returning the old word): a bit already set = a LATER arrival;
+//   B  bitmap cleared; the later arrivals set their row's bit again: the bitmap is now the set of shared rows;
+//   C  every reference reads its row's bit = its flag.
+// Tables with more rows than bits are hashed into the bitmap (multiplicative hash): a collision only raises a flag for a
+// row that is in fact alone, and a flagged lone row is still updated exactly (through the accumulator) — the flags are
+// conservative, never wrong.  The same kernel writes the batch's ids first (what epoch_refs_kernel does), so the whole
+// presort of the sparse regime is this one launch: no sort, no vendor library.
+struct FlagArgs {
+  const int2* sui;  // resident stream {user, item} or NULL (ids given in user/pos/neg)
+  const int32_t* neg_static;
+  int64_t N;
+  uint64_t shuffle_key;
+  int hb;
+  uint64_t sample_seed;
+  int64_t first_pos, batch;
+  int64_t n_users, n_items;
+  int32_t *user, *pos, *neg;  // (n_batches * batch) in/out
+  uint8_t* uflags;            // (n_batches * batch)
+  uint8_t* iflags;            // (n_batches * batch, 2)
+  int32_t* err;
+  int log2_bits;              // bitmap size
+  int item_hash, user_hash;   // 0: row id = bit (table fits the bitmap), 1: hashed
+};
+
+constexpr int FLAG_THREADS = 1024;
+
+__device__ __forceinline__ uint32_t flag_bit(int32_t row, int hashed, int log2_bits) {
+  return hashed ? ((uint32_t)row * 2654435761u) >> (32 - log2_bits) : (uint32_t)row;
+}
+
+// Every pass walks the batch FLAG_U triples per thread at a time with all their global loads issued before the first
+// LDS operation: the kernel is one workgroup per batch, i.e. a chain of load latencies, not bandwidth.  A thread owns
+// the same triples in every pass (t = tid + k * 1024), so what phase A learns ("my reference came later") stays in
+// registers — one bit per reference — until phase B needs it; only the final flags go to memory.
+constexpr int FLAG_U = 8;
+constexpr int FLAG_MAX_ROUNDS = 8;   // batch <= 1024 * FLAG_U * FLAG_MAX_ROUNDS = 65 536 triples
+
+template <int SRC>
+__global__ __launch_bounds__(FLAG_THREADS) void batch_flags_kernel(const FlagArgs a) {
+  extern __shared__ uint32_t bm[];
+  const int words = 1 << (a.log2_bits - 5);
+  const int64_t q0 = (int64_t)blockIdx.x * a.batch;
+  const int B = (int)a.batch;
+  const int lb = a.log2_bits;
+  uint16_t* iflags16 = reinterpret_cast<uint16_t*>(a.iflags);  // {pos, neg} of a position as one 16-bit word
+  constexpr int STEP = FLAG_THREADS * FLAG_U;
+  constexpr int GEN_U = 8;  // triples per thread whose random stream reads are in flight together
+  // ---- the batch's ids (as epoch_refs_kernel: generated from the resident stream, or clamped in place)
+  for (int t0 = threadIdx.x; t0 < B; t0 += FLAG_THREADS * GEN_U) {
+    int64_t u[GEN_U], i[GEN_U], j[GEN_U], p[GEN_U];
+    bool in[GEN_U];
+#pragma unroll
+    for (int k = 0; k < GEN_U; ++k) {
+      const int t = t0 + k * FLAG_THREADS;
+      in[k] = t < B;
+      const int64_t q = q0 + (in[k] ? t : 0);
+      if (SRC != 0) {
+        p[k] = trs_feistel_perm(a.first_pos + q, a.N, a.shuffle_key, a.hb);
+        const int2 ui = a.sui[p[k]];
+        u[k] = ui.x;
+        i[k] = ui.y;
+        j[k] = SRC == 2 ? (int64_t)a.neg_static[p[k]] : 0;
+      } else {
+        u[k] = a.user[q];
+        i[k] = a.pos[q];
+        j[k] = a.neg[q];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < GEN_U; ++k) {
+      const int64_t q = q0 + t0 + k * FLAG_THREADS;
+      if (SRC == 1) j[k] = trs_sample_one_neg(a.sample_seed, (uint64_t)(a.first_pos + q), i[k], a.n_items);
+      bool ok = true;
+      if ((uint64_t)u[k] >= (uint64_t)a.n_users) { ok = false; u[k] = 0; }
+      if ((uint64_t)i[k] >= (uint64_t)a.n_items) { ok = false; i[k] = 0; }
+      if ((uint64_t)j[k] >= (uint64_t)a.n_items) { ok = false; j[k] = 0; }
+      if (in[k]) {
+        if (!ok && a.err) atomicOr(a.err, 1);
+        if (SRC != 0 || !ok) {
+          a.user[q] = (int32_t)u[k];
+          a.pos[q] = (int32_t)i[k];
+          a.neg[q] = (int32_t)j[k];
+        }
+      }
+    }
+  }
+  // ---- item references, then users: phases A / B / C over the same LDS bitmap
+  for (int what = 0; what < 2; ++what) {
+    const int hashed = what == 0 ? a.item_hash : a.user_hash;
+    const int32_t* ida = what == 0 ? a.pos : a.user;
+    uint64_t lat0 = 0, lat1 = 0;  // bit rd * FLAG_U + k: the first / second id of triple (round rd, k) came later
+    for (int w = threadIdx.x; w < words; w += FLAG_THREADS) bm[w] = 0u;
+    __syncthreads();  // (also: the ids written above are visible to the whole workgroup)
+#pragma unroll 1
+    for (int rd = 0; rd * STEP < B; ++rd) {  // A: set; a bit already set = a later arrival
+      const int t0 = threadIdx.x + rd * STEP;
+      uint32_t b0[FLAG_U], b1[FLAG_U];
+#pragma unroll
+      for (int k = 0; k < FLAG_U; ++k) {
+        const int t = t0 + k * FLAG_THREADS;
+        const int64_t q = q0 + (t < B ? t : 0);
+        b0[k] = flag_bit(ida[q], hashed, lb);
+        b1[k] = what == 0 ? flag_bit(a.neg[q], hashed, lb) : 0u;
+      }
+#pragma unroll
+      for (int k = 0; k < FLAG_U; ++k) {
+        if (t0 + k * FLAG_THREADS < B) {
+          const uint32_t o0 = atomicOr(&bm[b0[k] >> 5], 1u << (b0[k] & 31));
+          lat0 |= (uint64_t)((o0 >> (b0[k] & 31)) & 1u) << (rd * FLAG_U + k);
+          if (what == 0) {
+            const uint32_t o1 = atomicOr(&bm[b1[k] >> 5], 1u << (b1[k] & 31));
+            lat1 |= (uint64_t)((o1 >> (b1[k] & 31)) & 1u) << (rd * FLAG_U + k);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < words; w += FLAG_THREADS) bm[w] = 0u;
+    __syncthreads();
+    for (uint64_t m = lat0; m; m &= m - 1) {  // B: the later arrivals mark their row as shared (few: ids re-read)
+      const int bit = __ffsll((unsigned long long)m) - 1;
+      const int64_t q = q0 + threadIdx.x + (int64_t)(bit / FLAG_U) * STEP + (bit % FLAG_U) * FLAG_THREADS;
+      const uint32_t b = flag_bit(ida[q], hashed, lb);
+      atomicOr(&bm[b >> 5], 1u << (b & 31));
+    }
+    for (uint64_t m = lat1; m; m &= m - 1) {
+      const int bit = __ffsll((unsigned long long)m) - 1;
+      const int64_t q = q0 + threadIdx.x + (int64_t)(bit / FLAG_U) * STEP + (bit % FLAG_U) * FLAG_THREADS;
+      const uint32_t b = flag_bit(a.neg[q], hashed, lb);
+      atomicOr(&bm[b >> 5], 1u << (b & 31));
+    }
+    __syncthreads();
+    for (int t0 = threadIdx.x; t0 < B; t0 += STEP) {  // C: flag = "my row is shared"
+      uint32_t b0[FLAG_U], b1[FLAG_U];
+#pragma unroll
+      for (int k = 0; k < FLAG_U; ++k) {
+        const int t = t0 + k * FLAG_THREADS;
+        const int64_t q = q0 + (t < B ? t : 0);
+        b0[k] = flag_bit(ida[q], hashed, lb);
+        b1[k] = what == 0 ? flag_bit(a.neg[q], hashed, lb) : 0u;
+      }
+#pragma unroll
+      for (int k = 0; k < FLAG_U; ++k) {
+        const int t = t0 + k * FLAG_THREADS;
+        if (t < B) {
+          const uint32_t s0 = (bm[b0[k] >> 5] >> (b0[k] & 31)) & 1u;
+          if (what == 0) iflags16[q0 + t] = (uint16_t)(s0 | (((bm[b1[k] >> 5] >> (b1[k] & 31)) & 1u) << 8));
+          else a.uflags[q0 + t] = (uint8_t)s0;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- per-step update
 struct SortedArgs {
   trs_tables T;
@@ -742,6 +903,65 @@ extern "C" int trs_epoch_presort(const int32_t* stream_ui_dev, const int32_t* ne
                        2 * batch, item_dup_flags_out_dev);
     TRS_CHECK_LAUNCH("item_flags_kernel");
   }
+  return TRS_OK;
+}
+
+// Ids + conservative duplicate flags of an epoch slice in one launch (the sparse regime's whole presort).
+extern "C" int trs_epoch_flags(const int32_t* stream_ui_dev, const int32_t* neg_static_dev, int64_t N,
+                               uint64_t shuffle_key, uint64_t sample_seed, int64_t first_pos, int64_t n_batches,
+                               int64_t batch, int64_t n_users, int64_t n_items, int32_t* user_dev, int32_t* pos_dev,
+                               int32_t* neg_dev, uint8_t* user_dup_flags_out_dev, uint8_t* item_dup_flags_out_dev,
+                               int32_t* err_flag_dev, void* stream) {
+  TRS_REQUIRE(batch <= (int64_t)FLAG_THREADS * FLAG_U * FLAG_MAX_ROUNDS,
+              "trs_epoch_flags: batch %lld exceeds %d (one workgroup per batch keeps a bit per reference in registers)",
+              (long long)batch, FLAG_THREADS * FLAG_U * FLAG_MAX_ROUNDS);
+  TRS_REQUIRE(n_batches > 0 && batch > 0 && batch < ((int64_t)1 << 30) && n_users > 0 && n_items > 0 &&
+                  n_users < ((int64_t)1 << 31) && n_items < ((int64_t)1 << 31), "trs_epoch_flags: bad sizes");
+  TRS_REQUIRE(user_dev && pos_dev && neg_dev && user_dup_flags_out_dev && item_dup_flags_out_dev,
+              "trs_epoch_flags: NULL buffer");
+  if (stream_ui_dev)
+    TRS_REQUIRE(N > 0 && first_pos >= 0 && first_pos + n_batches * batch <= N, "trs_epoch_flags: slice outside the stream");
+  FlagArgs a = {};
+  a.sui = (const int2*)stream_ui_dev;
+  a.neg_static = neg_static_dev;
+  a.N = N;
+  a.shuffle_key = shuffle_key;
+  a.hb = stream_ui_dev ? trs_feistel_half_bits(N) : 0;
+  a.sample_seed = sample_seed;
+  a.first_pos = first_pos;
+  a.batch = batch;
+  a.n_users = n_users;
+  a.n_items = n_items;
+  a.user = user_dev;
+  a.pos = pos_dev;
+  a.neg = neg_dev;
+  a.uflags = user_dup_flags_out_dev;
+  a.iflags = item_dup_flags_out_dev;
+  a.err = err_flag_dev;
+  // bitmap: as many bits as the larger table needs, between 2^10 and 2^20 (128 KB of LDS)
+  const int64_t big = n_users > n_items ? n_users : n_items;
+  int lb = 10;
+  while (lb < 20 && ((int64_t)1 << lb) < big) ++lb;
+  a.log2_bits = lb;
+  a.item_hash = n_items > ((int64_t)1 << lb) ? 1 : 0;
+  a.user_hash = n_users > ((int64_t)1 << lb) ? 1 : 0;
+  const size_t lds = ((size_t)1 << lb) / 8;
+  const int src = !stream_ui_dev ? 0 : (neg_static_dev ? 2 : 1);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 gr((unsigned)n_batches), bl(FLAG_THREADS);
+#define TRS_FL(SRC)                                                                                             \
+  {                                                                                                             \
+    static bool attr_done = false; /* > 64 KB of dynamic LDS needs the opt-in once per kernel */                \
+    if (!attr_done) {                                                                                           \
+      (void)hipFuncSetAttribute((const void*)batch_flags_kernel<SRC>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                128 * 1024);                                                                    \
+      attr_done = true;                                                                                         \
+    }                                                                                                           \
+    hipLaunchKernelGGL((batch_flags_kernel<SRC>), gr, bl, lds, s, a);                                           \
+  }
+  if (src == 0) TRS_FL(0) else if (src == 1) TRS_FL(1) else TRS_FL(2)
+#undef TRS_FL
+  TRS_CHECK_LAUNCH("batch_flags_kernel");
   return TRS_OK;
 }
 

@@ -64,6 +64,36 @@ class FlatGradBucket:
             self.views.append(v)
             o += p.numel()
 
+    def segments(self, groups):
+        """[(start, end)] of the flat buffer for consecutive groups of parameters (`groups`: lists of parameters in the
+        bucket's own order, e.g. one list per layer): lets a layer's gradients be reduced as soon as its backward has
+        written them, while the layers below are still being differentiated."""
+        out, o, i = [], 0, 0
+        for g in groups:
+            n = 0
+            for p in g:
+                assert self.params[i] is p, "segments() takes the bucket's parameters in order"
+                n += p.numel()
+                i += 1
+            out.append((o, o + n))
+            o += n
+        assert i == len(self.params)
+        return out
+
+    def allreduce_segment_async(self, seg, group=None):
+        """Start SUM over ranks of flat[seg[0]:seg[1]] on the collective stream; finish_segments() scales by 1/world."""
+        rank, world = world_info()
+        if world == 1:
+            return None
+        return dist.all_reduce(self.flat[seg[0]:seg[1]], op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+    def finish_segments(self, works):
+        works = [w for w in works if w is not None]
+        for w in works:
+            w.wait()
+        if works:
+            self.flat.mul_(1.0 / world_info()[1])
+
     def grad_of(self, p):
         for q, v in zip(self.params, self.views):
             if q is p:
@@ -85,6 +115,38 @@ class FlatGradBucket:
         if work is not None:
             work.wait()
             self.flat.mul_(1.0 / world_info()[1])
+
+
+def allreduce_min_int(value, device):
+    """MIN of one host integer over ranks (the common number of rows / steps every rank can run)."""
+    rank, world = world_info()
+    if world == 1:
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item())
+
+
+def gather_owned_rows_(table, group=None):
+    """User-partitioned data parallelism (stream sharded by user_id % world): rank r is the only writer of the rows
+    r, r + world, r + 2*world, ... of a user table; every other row of its replica is stale.  One all-gather of the
+    owned rows (1/world of the table sent per rank — half the bytes per link of an all-reduce of masked tables) makes
+    every replica whole again.  Called once at the end of fit(), not per epoch: nobody reads a foreign user row in
+    between."""
+    rank, world = world_info()
+    if world == 1:
+        return
+    n = table.shape[0]
+    per = (n + world - 1) // world
+    mine = table[rank::world]
+    send = torch.zeros((per,) + tuple(table.shape[1:]), dtype=table.dtype, device=table.device)
+    send[:mine.shape[0]].copy_(mine)
+    recv = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(recv, send, group=group)
+    for r in range(world):
+        if r != rank:
+            dst = table[r::world]
+            dst.copy_(recv[r][:dst.shape[0]])
 
 
 def average_tables_(tables, group=None):

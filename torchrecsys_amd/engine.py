@@ -216,26 +216,34 @@ class SparseScorerTrainer:
             return False
         memo = self._ps_fits
         if batch not in memo:  # decided once: two buffer sets (one being sorted while the other is read)
-            need = 2 * ops.EpochPresort.bytes_needed(self.SLICE_BATCHES, batch, n_items, self.M)
+            need = 2 * (ops.EpochFlags.bytes_needed(self.SLICE_BATCHES, batch) if self.sparse_regime(batch) else
+                        ops.EpochPresort.bytes_needed(self.SLICE_BATCHES, batch, n_items, self.M))
             free, _ = torch.cuda.mem_get_info(self.dev)
             memo[batch] = need < 0.3 * free
         return memo[batch]
 
-    def wants_item_inline(self, batch):
-        """K1 applies the item update of references that are ALONE on their row in the batch itself (item-duplicate
-        flags of the presort) when most references are: with uniform ids a reference is alone with probability
-        exp(-2B / n_items) — 0.94 at c4's per-GPU batch (65 536 references over 1M items: the step drops from 48.5 to
-        38.6 us, K2 shrinks to the 6 % duplicated references), 0.27 at c2 (131 072 over 100K: K1's extra flag loads and
-        conditional stores cost more than K2 saves, 45.7 -> 47.1 us).  TRS_ITEM_INLINE=0/1 forces it."""
-        env = os.environ.get("TRS_ITEM_INLINE")
+    def sparse_regime(self, batch):
+        """Most item references of a batch are ALONE on their row (uniform ids: probability exp(-2B / n_items) — 0.94 at
+        c4's per-GPU batch, 65 536 references over 1M items; 0.27 at c2, 131 072 over 100K).  Then K1 updates the lone
+        rows in place, the few flagged references follow in a small launch of float atomics, and the epoch needs duplicate
+        FLAGS only (trs_epoch_flags: one launch, no sort) — c4: 48.5 us per step with sorted runs for every reference ->
+        38.6 with K1 taking the lone references -> see DESIGN.md for the flag mode.  In the dense regime the sorted runs
+        stay (K1's flag loads and conditional stores cost more than they save: 45.7 -> 47.1 us at c2).
+        TRS_SPARSE_REGIME=0/1 forces the choice; plain SGD without metadata only."""
+        if self.fast_kind != "sgd" or self.M > 0:
+            return False
+        env = os.environ.get("TRS_SPARSE_REGIME")
         if env is not None:
             return env != "0"
-        return 2 * batch <= 0.7 * self.params[1].shape[0]  # expected share of lone references >= 1/2
+        return 2 * batch <= 0.7 * self.params[1].shape[0] and batch <= ops.EpochFlags.MAX_BATCH  # lone share >= 1/2
 
     def _presort_run(self, i, n_batches, batch, st, shuffle_key, sample_seed, first_pos, given_ids):
         sets = self._ps_sets
         ps = sets[i]
-        if ps is None or ps.batch != batch or ps.n_batches < n_batches:
+        if (ps is None or ps.batch != batch or ps.n_batches < n_batches) and self.sparse_regime(batch):
+            ps = sets[i] = ops.EpochFlags(max(n_batches, min(self.SLICE_BATCHES, n_batches)), batch,
+                                          self.params[0].shape[0], self.params[1].shape[0], self.dev)
+        elif ps is None or ps.batch != batch or ps.n_batches < n_batches:
             meta_kw = {}
             if self.M > 0 and os.environ.get("TRS_META_SORTED", "1") != "0":  # knob: 0 = atomic scatter of staged fields
                 meta_kw = dict(item_meta=self.item_meta, n_meta=[p.shape[0] for p in self.params[4:4 + self.M]])
@@ -243,7 +251,7 @@ class SparseScorerTrainer:
                                             self.params[0].shape[0], self.params[1].shape[0], self.dev, **meta_kw)
         if ps.n_batches != n_batches:  # a shorter tail slice: same buffers, fewer batches
             full = ps
-            ps = ops.EpochPresort.__new__(ops.EpochPresort)
+            ps = type(full).__new__(type(full))
             ps.__dict__.update(full.__dict__)
             ps.n_batches = n_batches
         if st is not None:
@@ -317,11 +325,20 @@ class SparseScorerTrainer:
 
     def fast_sorted_steps(self, ps, b_in_slice, batch, n_steps, loss_sums, item_meta=None):
         te, evs, ns = self._make_events(n_steps) if self.kernel_events is not None else (None, None, 0)
-        ids, sk, sv, udup, usorted, idup = ps.step_args(b_in_slice)
-        if self.fast_kind != "sgd" or self.M > 0 or not self.wants_item_inline(batch):
-            idup = None  # adaptive rules / metadata scorers / dense regime: every item reference goes through the runs
         if self.ustage is None:
             self.ustage = torch.empty_like(self.du)  # pre-update user rows staged by K1 for the item update
+        if isinstance(ps, ops.EpochFlags):  # sparse regime: flags only, the flagged references follow K1 with atomics
+            ids, udup, idup = ps.step_args(b_in_slice)
+            ops.train_steps_sgd(self.net.NET, self.net.tables(), None, None, 0, 0, 0, batch, n_steps, self.fast_lr, *ids,
+                                self.gz, self.du, loss_sums, self.err, self.scratch, self._stamps(n_steps), evs,
+                                user_dup=udup, item_dup=idup, ustage=self.ustage)
+            if te is not None:
+                self._collect_events(te, ns, ("fwd_stage_kernel", "flagged_update_kernel", "event_overhead"))
+            return
+        ids, sk, sv, udup, usorted, idup = ps.step_args(b_in_slice)
+        idup = None  # dense regime / adaptive rules / metadata scorers: every item reference goes through the runs
+        if os.environ.get("TRS_ITEM_INLINE", "0") == "1" and self.fast_kind == "sgd" and self.M == 0:
+            idup = ps.step_args(b_in_slice)[5]  # knob: sorted runs + K1 taking the lone item references (INL 2)
         opt = self._adaptive_rule(n_steps) if self.fast_kind != "sgd" else None
         meta = (self._meta_stage(batch, item_meta, ps.meta_step_args(b_in_slice), ps.meta_id_args(b_in_slice))
                 if self.M > 0 else None)

@@ -31,6 +31,11 @@ class MLPCompute:
         self.GEMM_EVENT_EVERY = 5   # ... of one training step in 5 (18 event records cost a step ~0.1 ms)
         self.gemm_steps_seen = self.gemm_steps_timed = 0
         self._time_gemms = False
+        # Synchronised BatchNorm under data parallelism: train-mode statistics over the GLOBAL batch — per
+        # layer and pass one all-reduce of (E[y], E[y^2]) in the forward and of (sum d, sum d*xhat) in the backward,
+        # 2*H floats each — so N ranks with batch B compute what one process computes with batch N*B.  Off (default):
+        # per-replica statistics.  Only read when torch.distributed has more than one rank.
+        self.sync_bn = False
 
     def _resident(self, rows, training):
         """bf16-resident path: use_amp, training step, every GEMM of the net made of interior tiles."""
@@ -131,11 +136,14 @@ class MLPCompute:
                     H = y.shape[1]
                     mean = torch.empty((passes, H), dtype=torch.float32, device=dev)
                     var = torch.empty((passes, H), dtype=torch.float32, device=dev)
+                    sync = self.sync_bn and tdist.world_info()[1] > 1
+                    rm, rv = (None, None) if sync else (bn.running_mean, bn.running_var)
                     if fuse_stats:
-                        ops.bn_stats_finalize(part, B, ops.GEMM_TILE_ROWS, H, passes, BN_MOMENTUM, mean, var,
-                                              bn.running_mean, bn.running_var)
+                        ops.bn_stats_finalize(part, B, ops.GEMM_TILE_ROWS, H, passes, BN_MOMENTUM, mean, var, rm, rv)
                     else:
-                        ops.bn_batch_stats(y, B, passes, BN_MOMENTUM, mean, var, bn.running_mean, bn.running_var)
+                        ops.bn_batch_stats(y, B, passes, BN_MOMENTUM, mean, var, rm, rv)
+                    if sync:
+                        self._sync_stats(mean, var, bn, B)
                     bn.num_batches_tracked += passes
                     stat_passes = passes
                 else:
@@ -154,9 +162,32 @@ class MLPCompute:
         ops.rowdot(x, net.output_layer.weight.data.reshape(-1), net.output_layer.bias.data, out)
         return out, ctx
 
-    def backward(self, ctx, g, grad_of=None):
+    @staticmethod
+    def _sync_stats(mean, var, bn, B):
+        """mean, var (passes, H): this rank's batch statistics -> the statistics of the global batch (equal B on every
+        rank), in place; running statistics updated from them pass by pass like one process with batch world*B would."""
+        import torch.distributed as dist
+        world = tdist.world_info()[1]
+        m64 = mean.double()
+        st = torch.stack([m64, var.double() + m64 * m64])  # E[y], E[y^2]
+        dist.all_reduce(st, op=dist.ReduceOp.SUM)
+        st /= world
+        gm = st[0]
+        gv = (st[1] - gm * gm).clamp_(min=0.0)
+        mean.copy_(gm)
+        var.copy_(gv)
+        n = float(world * B)
+        unb = gv * (n / max(n - 1.0, 1.0))
+        for ps in range(mean.shape[0]):
+            bn.running_mean.mul_(1.0 - BN_MOMENTUM).add_(gm[ps].float(), alpha=BN_MOMENTUM)
+            bn.running_var.mul_(1.0 - BN_MOMENTUM).add_(unb[ps].float(), alpha=BN_MOMENTUM)
+
+    def backward(self, ctx, g, grad_of=None, on_group_done=None):
         """g: (passes*B,) = dL/dscore.  grad_of(param) -> tensor to write that dense parameter's gradient into
-        (default: fresh tensors).  Returns (grads dict keyed by parameter, d x0)."""
+        (default: fresh tensors).  on_group_done(i): called once the kernels that write the dense gradients of group i
+        are enqueued — i = L for the output layer (first), then L-1 ... 0 for the hidden layers (Linear + BatchNorm
+        parameters of layer i): the data-parallel trainer starts that group's all-reduce while the layers below are
+        still being differentiated.  Returns (grads dict keyed by parameter, d x0)."""
         net = self.net
         D, M, L, use_bn = self._dims()
         B, passes = ctx["B"], ctx["passes"]
@@ -176,7 +207,10 @@ class MLPCompute:
         ops.colsum(g.reshape(-1, 1), slot(ol.bias), passes=passes)
         dx = torch.empty_like(xL)
         ops.outer(g, ol.weight.data.reshape(-1), dx)
+        if on_group_done:
+            on_group_done(L)
         res = ctx.get("resident", False)
+        sync = self.sync_bn and tdist.world_info()[1] > 1
         for l in reversed(range(L)):
             fc = net.fcs[l]
             y = ctx["y"][l]
@@ -185,7 +219,17 @@ class MLPCompute:
                 dy16 = torch.empty(y.shape, dtype=torch.bfloat16, device=y.device)
             else:
                 dy, dy16 = torch.empty_like(y), None
-            if use_bn:
+            if use_bn and sync:  # statistics of the global batch: reduce, all-reduce the 2*passes*H sums, apply
+                import torch.distributed as dist
+                bn = net.bns[l]
+                sums = torch.empty((passes, 2, y.shape[1]), dtype=torch.float32, device=y.device)
+                args = (y, dx, B, passes, True, ctx["mean"][l], ctx["var"][l], bn.weight.data, bn.bias.data, BN_EPS, dy,
+                        slot(bn.weight), slot(bn.bias))
+                ops.bn_relu_backward(*args, dy_colsum=slot(fc.bias), dy16=dy16, phase=1, sums=sums)
+                dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+                ops.bn_relu_backward(*args, dy_colsum=grads[fc.bias], dy16=dy16, phase=2, sums=sums,
+                                     stat_rows=tdist.world_info()[1] * B)
+            elif use_bn:
                 bn = net.bns[l]
                 ops.bn_relu_backward(y, dx, B, passes, True, ctx["mean"][l], ctx["var"][l], bn.weight.data, bn.bias.data,
                                      BN_EPS, dy, slot(bn.weight), slot(bn.bias), dy_colsum=slot(fc.bias), dy16=dy16)
@@ -194,12 +238,16 @@ class MLPCompute:
                                      dy_colsum=slot(fc.bias), dy16=dy16)  # db = column sums of dy, from the same kernel
             if res:
                 self._gemm16(True, dy16, ctx["x"][l], out=slot(fc.weight))   # dW = dy^T x (transposing LDS reads)
+                if on_group_done:
+                    on_group_done(l)
                 # dx = dy W through the W^T image: bf16 between layers (when the layer below keeps a bf16 y), fp32 for the
                 # embedding gradient d x0
                 dx = self._gemm16(False, dy16, self.w16t[l],
                                   out_bf16=l > 0 and ctx["y"][l - 1].dtype == torch.bfloat16)
             else:
                 self._gemm(True, False, dy, ctx["x"][l], out=slot(fc.weight), bf16=net.use_bf16)  # dW = dy^T x (split-K)
+                if on_group_done:
+                    on_group_done(l)  # before the input-gradient GEMM: the collective overlaps it and the layers below
                 dx = self._gemm(False, False, dy, fc.weight.data, bf16=net.use_bf16)      # dx = dy W
         return grads, dx
 
@@ -249,6 +297,12 @@ class MLPTrainer:
         self.kind = classify_optimizer(optimizer, self.emb_params)  # torch.optim.Adam -> lazy rows + dense Adam
         self.dev = self.emb_params[0].device
         self.bucket = tdist.FlatGradBucket(self.dense_params)
+        # one segment of the flat gradient buffer per layer (Linear + BatchNorm parameters), the output layer last: a
+        # layer's gradients are all-reduced as soon as its backward kernels are enqueued
+        per = 4 if net.use_batch_norm else 2
+        L = len(net.fcs)
+        self.segs = self.bucket.segments([self.dense_params[l * per:(l + 1) * per] for l in range(L)]
+                                         + [self.dense_params[L * per:]])
         self.err = net._err_flag()
         self.row_state = {id(p): RowState(p) for p in self.emb_params} if self.kind in ("sparse_adam", "adagrad") else {}
         self.kernel_events = None
@@ -262,9 +316,14 @@ class MLPTrainer:
         ops.hinge_auc(pos, neg, loss_slot, auc_slot)
         gp, gn = ops.hinge_backward(pos, neg)
         g = torch.cat([gp, gn])
-        grads, dx0 = net.compute.backward(ctx, g, grad_of=self.bucket.grad_of)
-        # ---- dense parameters: one flat all-reduce (data parallel), then the user's optimiser
-        self.bucket.allreduce_mean_()
+        # ---- dense parameters under data parallelism: RCCL all-reduce per layer, started as the backward produces the
+        # layer's gradients (it runs on the collective stream beside the remaining backward GEMMs and the embedding-row
+        # updates below) and awaited right before the user's optimiser steps the dense parameters
+        works = []
+        dp = tdist.world_info()[1] > 1
+        grads, dx0 = net.compute.backward(ctx, g, grad_of=self.bucket.grad_of,
+                                          on_group_done=(lambda i: works.append(
+                                              self.bucket.allreduce_segment_async(self.segs[i]))) if dp else None)
         idx_user = torch.cat([ids["user"], ids["user"]])
         idx_item = torch.cat([ids["pos"], ids["neg"]])
         tables = [(net.user.weight, idx_user, 0), (net.item.weight, idx_item, 1)]
@@ -281,14 +340,16 @@ class MLPTrainer:
                 p.grad = None
         for p in self.dense_params:
             p.grad = self.bucket.grad_of(p)
-        opt.step()
-        # ---- embedding tables: fused sparse-row updates from the column blocks of d x0
+        # ---- embedding tables: fused sparse-row updates from the column blocks of d x0 (independent of the dense
+        # gradients still being reduced)
         if self.kind == "sgd":
             for p, idx, f in tables:
                 ops.rows_scatter_add(p.data, idx, dx0[:, f * D:], -_group_of(opt, p)["lr"], ld=ld, err_flag=self.err)
         elif self.kind in ("sparse_adam", "adagrad"):
             for p, idx, f in tables:
                 self._rows(p, idx, dx0[:, f * D:], ld)
+        self.bucket.finish_segments(works)
+        opt.step()
 
     def _rows(self, p, idx, vals, ld):
         apply_rows(self.kind, self.opt, p, self.row_state[id(p)], idx, vals, ld)

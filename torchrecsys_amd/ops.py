@@ -252,6 +252,41 @@ class EpochPresort:
                                     self.ukey_bytes, o), self.item_dup[o:])
 
 
+class EpochFlags:
+    """The sparse regime's presort (trs_epoch_flags): ids of n_batches whole batches + conservative duplicate flags,
+    one launch, no sort.  Same surface as EpochPresort where the step loop needs it."""
+
+    MAX_BATCH = 65_536  # one workgroup per batch (csrc/presort.hip FLAG_THREADS * FLAG_U * FLAG_MAX_ROUNDS)
+
+    def __init__(self, n_batches, batch, n_users, n_items, device):
+        self.n_batches, self.batch, self.n_users, self.n_items = n_batches, batch, n_users, n_items
+        n_pos = n_batches * batch
+        self.ids = [torch.empty(n_pos, dtype=torch.int32, device=device) for _ in range(3)]
+        self.user_dup = torch.empty(n_pos, dtype=torch.uint8, device=device)
+        self.item_dup = torch.empty((n_pos, 2), dtype=torch.uint8, device=device)
+        self.key_bytes = self.ukey_bytes = 0
+
+    @staticmethod
+    def bytes_needed(n_batches, batch):
+        return 15 * n_batches * batch
+
+    def run(self, stream_ui, neg_static, shuffle_key, sample_seed, first_pos, err_flag, given_ids=None):
+        if given_ids is not None:
+            n_pos = self.n_batches * self.batch
+            for dst, src in zip(self.ids, given_ids):
+                dst[:n_pos].copy_(src[:n_pos])
+        N = 0 if stream_ui is None else stream_ui.shape[0]
+        check(_lib.load().trs_epoch_flags(ptr(stream_ui), ptr(neg_static), N, int(shuffle_key), int(sample_seed),
+                                          int(first_pos), self.n_batches, self.batch, self.n_users, self.n_items,
+                                          ptr(self.ids[0]), ptr(self.ids[1]), ptr(self.ids[2]), ptr(self.user_dup),
+                                          ptr(self.item_dup), ptr(err_flag), _stream()), "trs_epoch_flags")
+
+    def step_args(self, b):
+        """(id views, user-duplicate flags view, item-duplicate flags view) from batch b of the slice on."""
+        o = b * self.batch
+        return [t[o:] for t in self.ids], self.user_dup[o:], self.item_dup[o:]
+
+
 def train_steps_sgd(net, T, stream_ui, neg_static, shuffle_key, sample_seed, first_pos, batch, n_steps,
                     lr, user_buf, pos_buf, neg_buf, gz_buf, du_buf, loss_sums, err_flag, scratch=None, first_stamp=1,
                     events=None, sorted_keys=None, sorted_vals=None, key_bytes=0, user_dup=None, ustage=None,
@@ -259,7 +294,8 @@ def train_steps_sgd(net, T, stream_ui, neg_static, shuffle_key, sample_seed, fir
     """n_steps fused steps driven from C (trs_train_steps_sgd).  stream_ui None: the steps' ids are already in
     user/pos/neg_buf.  events: optional flat list of 4*n_steps raw hipEvent_t handles.  opt: None (SGD with lr) or a
     _lib.TrsOpt (SparseAdam / Adagrad on the presorted path; keep the tensors it points to alive).  item_dup: the
-    presort's item-duplicate flags (plain SGD without metadata): K1 also updates item rows referenced once."""
+    presort's item-duplicate flags (plain SGD without metadata): K1 also updates item rows referenced once.  Flag mode
+    (sparse regime): user_dup + item_dup from an EpochFlags, ustage, and no sorted references."""
     a = _lib.TrsTrainArgs()
     a.net, a.n_steps, a.tables, a.batch, a.lr = NET_ID[net], int(n_steps), C.pointer(T), int(batch), float(lr)
     a.first_stamp = int(first_stamp)
@@ -483,14 +519,17 @@ def bn_relu_forward(y, rows_per_pass, passes, use_bn, stat_passes, mean, var, ga
 
 
 def bn_relu_backward(y, dx, rows_per_pass, passes, use_bn, mean, var, gamma, beta, eps, dy, dgamma, dbeta,
-                     dy_colsum=None, dy16=None):
+                     dy_colsum=None, dy16=None, phase=0, sums=None, stat_rows=0):
+    """phase 0: whole backward on the local batch.  Synchronised BatchNorm: phase 1 (reduce: `sums` (passes,2,H) fp32
+    receives sum(d), sum(d*xhat)), all-reduce `sums`, phase 2 (apply with stat_rows = world * rows_per_pass)."""
     lib = _lib.load()
     H = y.shape[1]
     ws = _workspace(y.device, 4 * lib.trs_bn_backward_workspace_floats(rows_per_pass, H, passes))
     check(lib.trs_bn_relu_backward(ptr(y), int(y.dtype == torch.bfloat16), ptr(dx), int(dx.dtype == torch.bfloat16),
                                    rows_per_pass, passes, H, y.stride(0), dx.stride(0), int(use_bn),
                                    ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps), ptr(dy), ptr(dy16),
-                                   ptr(dgamma), ptr(dbeta), ptr(dy_colsum), ptr(ws), _stream()), "trs_bn_relu_backward")
+                                   ptr(dgamma), ptr(dbeta), ptr(dy_colsum), ptr(ws), int(phase), ptr(sums),
+                                   int(stat_rows), _stream()), "trs_bn_relu_backward")
 
 
 def colsum(x, out, row_weight=None, passes=1):
