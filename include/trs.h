@@ -91,6 +91,28 @@ int trs_events_destroy(int32_t n, void** handles);
 int trs_events_elapsed_ms(void* start, void* stop, float* ms_out);
 
 /* ------------------------------------------------------------------------- loader / sampler (a9, a10) */
+/* Sampler options beyond the reference's (the reference only rejects the row's own positive,
+ * dataset/dataset.py:435-447).  NULL everywhere below = the reference's sampler.  Counter-based like the plain sampler
+ * (try 0 with every option off IS the plain sampler's draw):
+ *   k_neg      every interaction is visited k_neg times per epoch, each time with a fresh negative: the epoch has
+ *              N * k_neg positions, position q maps to row perm_{N*k_neg}(q) % N;
+ *   popularity candidates are drawn as the item of a uniformly random interaction (pop_items[r], r < pop_n), i.e.
+ *              proportionally to the item's frequency in the stream, instead of uniformly over the catalogue;
+ *   seen_off / seen_items   CSR of every user's positives (seen_off (n_users+1), seen_items sorted per user): a
+ *              candidate the user has interacted with is rejected and redrawn (key = seed + try * golden ratio), at
+ *              most max_tries candidates; the last one is kept whatever it is (bounded work).
+ * The negative always differs from the row's positive. */
+typedef struct trs_sampler {
+  int32_t k_neg;      /* >= 1 */
+  int32_t popularity; /* 0 | 1 */
+  int32_t max_tries;  /* >= 1 */
+  int32_t reserved;
+  const int64_t* seen_off;
+  const int32_t* seen_items;
+  const int32_t* pop_items;
+  int64_t pop_n;
+} trs_sampler;
+
 /* Counter-based dynamic negative sampler: neg[t] uniform over {0..n_items-1} \ {pos[t]} — the distribution of the
  * rejection loop at dataset/dataset.py:440-445 (reject only the row's own positive).  Stream: Philox4x32-10,
  * key = seed, counter = offset + t; r = mulhi64(x, n_items-1); neg = r + (r >= pos).  Not the numpy legacy
@@ -110,7 +132,8 @@ int trs_batch_prepare(const int32_t* stream_user_dev, const int32_t* stream_item
                       const int32_t* neg_static_dev, int64_t N, uint64_t shuffle_key, int64_t t0, int64_t B,
                       int64_t n_items, uint64_t sample_seed, uint64_t sample_offset,
                       const int32_t* item_meta_dev, int32_t M, int32_t* user_out, int32_t* pos_out,
-                      int32_t* neg_out, int32_t* pos_meta_out, int32_t* neg_meta_out, void* stream);
+                      int32_t* neg_out, int32_t* pos_meta_out, int32_t* neg_meta_out, const trs_sampler* sampler,
+                      void* stream);
 
 /* ------------------------------------------------------------------ scorers: forward only (a2, a3, a6) */
 /* Fused positive+negative scoring pass; the user row is gathered once for both passes.
@@ -296,7 +319,7 @@ int trs_epoch_flags(const int32_t* stream_ui_dev, const int32_t* neg_static_dev,
                     uint64_t sample_seed, int64_t first_pos, int64_t n_batches, int64_t batch, int64_t n_users,
                     int64_t n_items, int32_t* user_dev, int32_t* pos_dev, int32_t* neg_dev,
                     uint8_t* user_dup_flags_out_dev, uint8_t* item_dup_flags_out_dev, int32_t* err_flag_dev,
-                    void* stream);
+                    const trs_sampler* sampler, void* stream);
 int trs_epoch_user_dups_sizes(int64_t n_batches, int64_t batch, int64_t n_users, int64_t* ukeys_bytes_out,
                               int64_t* uvals_bytes_out, int64_t* temp_bytes_out);
 int trs_epoch_user_dups(const int32_t* user_dev, int64_t n_batches, int64_t batch, int64_t n_users, void* ukeys_dev,
@@ -308,7 +331,8 @@ int trs_epoch_presort(const int32_t* stream_ui_dev, const int32_t* neg_static_de
                       uint64_t sample_seed, int64_t first_pos, int64_t n_batches, int64_t batch, int64_t n_users,
                       int64_t n_items, int32_t* user_dev, int32_t* pos_dev, int32_t* neg_dev, void* keys_dev,
                       void* vals_dev, void* temp_dev, int64_t temp_bytes, int32_t* err_flag_dev,
-                      void** sorted_keys_out, void** sorted_vals_out, uint8_t* item_dup_flags_out_dev, void* stream);
+                      void** sorted_keys_out, void** sorted_vals_out, uint8_t* item_dup_flags_out_dev,
+                      const trs_sampler* sampler, void* stream);
 
 /* ---------------------------------------------------------------- sparse row optimisers (a7, App. A.5) */
 /* table[idx[t]] += alpha * vals[t]  for t < n, rows of D floats, vals row t at vals + t*ld.  Float atomics, one

@@ -109,6 +109,35 @@ def device_negatives(pos, n_items, seed, offset):
     return v + (v >= pos)
 
 
+def device_negatives_opt(users, pos, n_items, seed, offset, popularity=False, seen=None, pop_items=None, max_tries=8):
+    """trs_sample_neg_opt (csrc/trs_common.h): the sampler with the options of trs_sampler (SURVEY 8f-4 — the reference
+    itself only rejects the row's own positive, dataset/dataset.py:435-447).  Candidate of try k: Philox(counter,
+    key = seed + k * 0x9E3779B97F4A7C15): words (x, y) -> uniform over the items other than the positive, words (z, w)
+    -> popularity draw pop_items[mulhi(zw, len)] (a candidate equal to the positive is skipped); rejected while the
+    user's positives (`seen`: dict user -> set, or CSR (offsets, items)) contain it; the last candidate is kept."""
+    users, pos = np.asarray(users, dtype=np.int64), np.asarray(pos, dtype=np.int64)
+    if isinstance(seen, tuple):
+        off, items = (np.asarray(a) for a in seen)
+        seen = {int(u): set(items[off[u]:off[u + 1]].tolist()) for u in np.unique(users)}
+    out = np.zeros(pos.size, dtype=np.int64)
+    G = 0x9E3779B97F4A7C15
+    for t in range(pos.size):
+        c = 0
+        for k in range(max_tries):
+            x, y, z, w = philox4x32_10(np.array([offset + t], dtype=np.uint64), (int(seed) + k * G) & 0xFFFFFFFFFFFFFFFF)
+            v = ((int(y[0]) << 32 | int(x[0])) * (n_items - 1)) >> 64
+            c = v + (1 if v >= pos[t] else 0)
+            if popularity:
+                cp = int(pop_items[((int(w[0]) << 32 | int(z[0])) * len(pop_items)) >> 64])
+                if cp == pos[t]:
+                    continue
+                c = cp
+            if seen is None or c not in seen.get(int(users[t]), ()):
+                break
+        out[t] = c
+    return out
+
+
 def _mix32(x, k):
     x = (x ^ k) & 0xFFFFFFFF
     x = (x * 0x9E3779B1) & 0xFFFFFFFF
@@ -145,14 +174,21 @@ def feistel_perm(q, N, key):
             return x
 
 
-def device_batch(stream_user, stream_item, neg_static, shuffle_key, t0, B, n_items, seed, offset, item_meta=None):
-    """trs_batch_prepare restated.  Returns dict user/pos/neg (+ pos_meta/neg_meta)."""
+def device_batch(stream_user, stream_item, neg_static, shuffle_key, t0, B, n_items, seed, offset, item_meta=None,
+                 sampler=None):
+    """trs_batch_prepare restated.  Returns dict user/pos/neg (+ pos_meta/neg_meta).  sampler: None or a dict
+    k / popularity / seen / max_tries (trs_sampler): k > 1 = k * N epoch positions, position q -> row perm(q) % N."""
     N = len(stream_user)
-    rows = np.array([feistel_perm(t0 + t, N, shuffle_key) for t in range(B)], dtype=np.int64)
+    k = (sampler or {}).get("k", 1)
+    rows = np.array([feistel_perm(t0 + t, N * k, shuffle_key) % N for t in range(B)], dtype=np.int64)
     u = np.asarray(stream_user)[rows].astype(np.int64)
     p = np.asarray(stream_item)[rows].astype(np.int64)
     if neg_static is not None:
         n = np.asarray(neg_static)[rows].astype(np.int64)
+    elif sampler:
+        n = device_negatives_opt(u, p, n_items, seed, offset, popularity=sampler.get("popularity", False),
+                                 seen=sampler.get("seen"), pop_items=np.asarray(stream_item),
+                                 max_tries=sampler.get("max_tries", 8))
     else:
         n = device_negatives(p, n_items, seed, offset)
     out = {"user": u, "pos": p, "neg": n}

@@ -12,14 +12,21 @@ def rnd(a):
     return a.float().bfloat16().float()
 
 
+WIDE = torch.float64  # accumulation type of every reduction; torch.float32 = "a plain fp32 implementation of the same
+#                       rounding points", used to calibrate how ill-conditioned a gradient is at a given size
+
+
 def mm(a, b):
-    return (a.double() @ b.double()).float()
+    return (a.to(WIDE) @ b.to(WIDE)).float()
 
 
-def train_step_bf16(P, ids, y_bf16=True):
-    """P: dict name -> fp32 GPU tensor (state_dict layout; embedding tables may be compacted); ids: dict user/pos/neg
+def train_step_bf16(P, ids, y_bf16=True, wide=torch.float64):
+    """wide: accumulation dtype of the reductions (float64 = the judge; float32 = the calibration run).
+    P: dict name -> fp32 GPU tensor (state_dict layout; embedding tables may be compacted); ids: dict user/pos/neg
     [/pos_meta/neg_meta] of int64 GPU tensors.  Returns (pos, neg, loss, grads, dx0 rows per pass) — running statistics
     in P are updated in place."""
+    global WIDE
+    WIDE = wide
     L = 0
     while f"fcs.{L}.weight" in P:
         L += 1
@@ -40,7 +47,7 @@ def train_step_bf16(P, ids, y_bf16=True):
             y = mm(x, W[l].T) + P[f"fcs.{l}.bias"]
             mu = invstd = None
             if use_bn:
-                y64 = y.double()
+                y64 = y.to(WIDE)
                 mu = y64.mean(0).float()
                 var = y64.var(0, unbiased=False).float()
                 unb = var * (B / max(B - 1, 1))
@@ -57,15 +64,16 @@ def train_step_bf16(P, ids, y_bf16=True):
             if l < L - 1:
                 x = rnd(x)
             c["x"].append(x)
-        out = (x.double() @ P["output_layer.weight"].double().T).float() + P["output_layer.bias"]
+        out = (x.to(WIDE) @ P["output_layer.weight"].to(WIDE).T).float() + P["output_layer.bias"]
         return out.reshape(-1), c
 
     def backward(g, c):
         g = g.reshape(-1, 1)
         gr = {}
         xL = c["x"][L]
-        gr["output_layer.weight"] = (g.double().T @ xL.double()).float()
-        gr["output_layer.bias"] = g.double().sum(0).float()
+        gr["output_layer.weight"] = (g.to(WIDE).T @ xL.to(WIDE)).float()
+        gr["absbound.output_layer.weight"] = (g.to(WIDE).abs().T @ xL.to(WIDE).abs()).float()
+        gr["output_layer.bias"] = g.to(WIDE).sum(0).float()
         dx = g @ P["output_layer.weight"]
         B = g.shape[0]
         for l in reversed(range(L)):
@@ -74,13 +82,15 @@ def train_step_bf16(P, ids, y_bf16=True):
                 mu, invstd, gamma = c["mu"][l], c["invstd"][l], P[f"bns.{l}.weight"]
                 xhat = (y - mu) * invstd
                 d = torch.where(xhat * gamma + P[f"bns.{l}.bias"] > 0, dx, torch.zeros_like(dx))
-                s1 = d.double().sum(0).float()
-                s2 = (d.double() * xhat.double()).sum(0).float()
+                s1 = d.to(WIDE).sum(0).float()
+                s2 = (d.to(WIDE) * xhat.to(WIDE)).sum(0).float()
                 gr[f"bns.{l}.weight"], gr[f"bns.{l}.bias"] = s2, s1
+                gr[f"absbound.bns.{l}.bias"] = d.to(WIDE).abs().sum(0).float()
+                gr[f"absbound.bns.{l}.weight"] = (d.to(WIDE) * xhat.to(WIDE)).abs().sum(0).float()
                 dy = (gamma * invstd) * (d - s1 / B - xhat * (s2 / B))
             else:
                 dy = torch.where(y > 0, dx, torch.zeros_like(dx))
-            gr[f"fcs.{l}.bias"] = dy.double().sum(0).float()
+            gr[f"fcs.{l}.bias"] = dy.to(WIDE).sum(0).float()
             dy16 = rnd(dy)
             gr[f"fcs.{l}.weight"] = mm(dy16.T, c["x"][l])
             # sum of |products| per element: the scale of the fp32-accumulation error of this reduction over all rows

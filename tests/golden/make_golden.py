@@ -255,10 +255,59 @@ def g4_g5():
             np.savez_compressed(os.path.join(OUT, f"g4_{net_type}_{'dyn' if dyn else 'static'}.npz"), **out)
 
 
+def g4_meta():
+    """G4 with the ONE metadata front-end shape the reference can run end to end: a single metadata column
+    whose cells are string-encoded one-element lists ("[k]", one category per item).  fit() + evaluate() for every net,
+    static and dynamic negatives: epoch losses, final weights, printed metrics; plus eval-mode scores of one user against
+    every item computed at the net level with the (n_items, 1) metadata ids (TorchRecSys.predict() itself raises with
+    metadata in the reference, model.py:401)."""
+    n_users, n_items, n_cat, N = 300, 100, 7, 10000
+    df = synth_df(n_users, n_items, N, np.random.RandomState(0))
+    item_cat = np.random.RandomState(1).randint(0, n_cat, n_items)
+    item_cat[:n_cat] = np.arange(n_cat)  # every category occurs
+    df["cat"] = [f"[{item_cat[i]}]" for i in df["item"].values]
+    for net_type in ("linear", "fm", "mlp"):
+        for dyn in (False, True):
+            seed(7)
+            buf = io.StringIO()
+            try:
+                with contextlib.redirect_stdout(buf):
+                    model = TorchRecSys(dataset=df.copy(), user_id_col="user", item_id_col="item", n_factors=16,
+                                        net_type=net_type, metadata_id_col=["cat"], dynamic_neg_sampling=dyn)
+                    init = sd_np(model, "init")
+                    opt = torch.optim.SGD(model.parameters(), lr=0.05)
+                    model.fit(optimizer=opt, epochs=2, batch_size=256)
+                    final = sd_np(model, "final")
+                    if not dyn:
+                        model.evaluate(batch_size=256)
+            except Exception as e:  # recorded, not hidden: the fixture then says the reference cannot run this case
+                print(f"g4_meta {net_type} dyn={dyn}: reference raised {type(e).__name__}: {e}")
+                continue
+            txt = buf.getvalue()
+            out = {"df_user": df["user"].values, "df_item": df["item"].values, "item_cat": item_cat,
+                   "n_cat": np.int64(n_cat)}
+            out["epoch_losses"] = np.asarray([float(x) for x in re.findall(r"Training Loss: ([0-9.]+)", txt)])
+            if not dyn:
+                out["eval_loss"] = np.float64(re.findall(r"Testing loss: ([0-9.]+)", txt)[0])
+                out["eval_auc"] = np.float64(re.findall(r"Testing auc: ([0-9.]+)", txt)[0])
+            out["stdout"] = np.asarray(txt)
+            out.update(init)
+            out.update(final)
+            model.net.eval()
+            with torch.no_grad():
+                sc = model.net.forward({"user_id": torch.full((n_items,), 3, dtype=torch.long),
+                                        "pos_item_id": torch.arange(n_items),
+                                        "pos_metadata_id": torch.from_numpy(item_cat).long().reshape(-1, 1)},
+                                       "user_id", "pos_item_id", "pos_metadata_id")
+            out["scores_user3"] = sc.reshape(-1).numpy()
+            out["top10_user3"] = torch.sort(sc.reshape(-1).float(), descending=True)[1][:10].numpy()
+            np.savez_compressed(os.path.join(OUT, f"g4m_{net_type}_{'dyn' if dyn else 'static'}.npz"), **out)
+
+
 if __name__ == "__main__":
     assert os.path.isdir("/root/reference"), "run in the build container"
-    g1_g2()
-    g3()
-    g4_g5()
+    parts = sys.argv[1:] or ["g1_g2", "g3", "g4_g5", "g4_meta"]
+    for part in parts:
+        {"g1_g2": g1_g2, "g3": g3, "g4_g5": g4_g5, "g4_meta": g4_meta}[part]()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))
     print("golden vectors written:", len([f for f in os.listdir(OUT) if f.endswith('.npz')]), "files,", tot, "bytes")

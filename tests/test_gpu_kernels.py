@@ -226,6 +226,61 @@ def test_batch_prepare_bit_exact(M, static):
     assert np.array_equal(out["user"].cpu().numpy(), su[10:30])
 
 
+@pytest.mark.parametrize("opts", [dict(k=1, reject_seen=True), dict(k=3), dict(k=1, popularity=True),
+                                  dict(k=2, popularity=True, reject_seen=True, max_tries=4)])
+def test_sampler_options_bit_exact_and_properties(opts):
+    """Sampler options beyond the reference's (reject all of the user's positives, popularity-weighted
+    candidates, k negatives per positive) in every generator of the device RNG mode — trs_batch_prepare, trs_epoch_flags,
+    trs_epoch_presort — bit-exact against oracle/loader.py's restatement, plus what each option promises."""
+    ops = _ops()
+    rs = np.random.RandomState(11)
+    N, NU, NI, B = 1200, 40, 37, 200
+    su = rs.randint(0, NU, N).astype(np.int32)
+    si = (rs.zipf(1.6, N) % NI).astype(np.int32)  # skewed popularity
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    k = opts.get("k", 1)
+    seen = ops.Sampler.seen_csr(d(su), d(si), NU, NI) if opts.get("reject_seen") else None
+    sm = ops.Sampler(k=k, popularity=opts.get("popularity", False), seen=seen, stream_item=d(si),
+                     max_tries=opts.get("max_tries", 8))
+    oracle_opts = dict(k=k, popularity=opts.get("popularity", False), max_tries=opts.get("max_tries", 8),
+                       seen=None if seen is None else (seen[0].cpu().numpy(), seen[1].cpu().numpy()))
+    key, seed_ = 0xC0FFEE1234, 77
+    nb = (N * k) // B
+    got = {q: [] for q in ("user", "pos", "neg")}
+    for b in range(nb):
+        out = ops.batch_prepare(d(su), d(si), None, key, b * B, B, NI, seed_, b * B, sampler=sm)
+        ref = oloader.device_batch(su, si, None, key, b * B, B, NI, seed_, b * B, sampler=oracle_opts)
+        for q in got:
+            assert np.array_equal(out[q].cpu().numpy().astype(np.int64), ref[q]), (q, b)
+            got[q].append(ref[q])
+    u, p, n = (np.concatenate(got[q]) for q in ("user", "pos", "neg"))
+    assert (n != p).all() and n.min() >= 0 and n.max() < NI
+    # k negatives per positive: over the epoch's k*N positions every stream row is visited exactly k times
+    if (N * k) % B == 0:
+        pairs, cnt = np.unique(u * NI + p, return_counts=True)
+        ref_pairs, ref_cnt = np.unique(su.astype(np.int64) * NI + si, return_counts=True)
+        assert np.array_equal(pairs, ref_pairs) and np.array_equal(cnt, ref_cnt * k)
+    if opts.get("reject_seen") and not opts.get("popularity"):
+        # uniform candidates, 8 tries: a seen negative needs 8 seen candidates in a row (users hold ~13 of 37 items)
+        pos_of = {uu: set(si[su == uu].tolist()) for uu in range(NU)}
+        bad = sum(int(nn in pos_of[uu]) for uu, nn in zip(u, n))
+        assert bad <= max(1, int(0.002 * n.size)), bad
+    if opts.get("popularity") and not opts.get("reject_seen"):  # negatives follow the stream's item frequencies (minus
+        f_neg = np.bincount(n, minlength=NI) / n.size           # the draws that hit the row's own positive)
+        f_pop = np.bincount(si, minlength=NI) / N
+        assert np.corrcoef(f_neg, f_pop)[0, 1] > 0.9 and f_neg[np.argmax(f_pop)] > 3.0 / NI
+    # the epoch-level generators produce the same triples (flags kernel and sorted presort)
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ui = ops.interleave_stream(d(su), d(si))
+    for cls in (ops.EpochFlags, ops.EpochPresort):
+        ep = cls(nb, B, NU, NI, DEV)
+        ep.run(ui, None, key, seed_, 0, err, sampler=sm)
+        torch.cuda.synchronize()
+        for q, arr in zip(("user", "pos", "neg"), ep.ids):
+            assert np.array_equal(arr[:nb * B].cpu().numpy().astype(np.int64), np.concatenate(got[q])), (cls.__name__, q)
+    assert err.item() == 0
+
+
 def test_hinge_auc():
     ops = _ops()
     rs = np.random.RandomState(0)

@@ -213,6 +213,9 @@ def test_generic_backward_path_with_any_optimizer(name):
 def run_model(net_type, dyn, g, rng="reference", **kw):
     from torchrecsys_amd.model import TorchRecSys
     df = pd.DataFrame({"user": g["df_user"], "item": g["df_item"]})
+    if "item_cat" in g:  # the metadata front-end shape the reference can run: one column of "[k]" strings
+        df["cat"] = [f"[{g['item_cat'][i]}]" for i in df["item"].values]
+        kw = dict(kw, metadata_id_col=["cat"])
     seed(7)
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
@@ -230,8 +233,13 @@ def run_model(net_type, dyn, g, rng="reference", **kw):
 
 @pytest.mark.parametrize("net_type", SPARSE_NETS + ["mlp"])
 @pytest.mark.parametrize("dyn", [False, True])
-def test_g4_end_to_end_fit_evaluate_predict(net_type, dyn):
-    g = load_golden(f"g4_{net_type}_{'dyn' if dyn else 'static'}.npz")
+@pytest.mark.parametrize("fixture", ["g4", "g4m"])
+def test_g4_end_to_end_fit_evaluate_predict(net_type, dyn, fixture):
+    """fit() / evaluate() / predict() through the public API against the REFERENCE's own run of the same script
+    (tests/golden/make_golden.py).  g4m: with one metadata column of string-encoded one-element lists — the only
+    metadata front-end shape the reference can run end to end; its predict() raises with metadata
+    (model.py:401), so the top-10 fixture is the reference's net-level eval-mode scores sorted the reference's way."""
+    g = load_golden(f"{fixture}_{net_type}_{'dyn' if dyn else 'static'}.npz")
     model, init, final, top, txt = run_model(net_type, dyn, g)
     for k, v in sub(g, "init").items():  # seeded construction: bit-identical initial weights
         assert np.array_equal(init[k], v), k
@@ -513,6 +521,45 @@ def test_amp_training_run_and_profiling_run(net_type):
     out = buf.getvalue()
     assert out.count("Training Loss") == 2 and "Profiler Results" in out
     assert all(np.isfinite(v.cpu().numpy()).all() for v in model.state_dict().values())
+
+
+@pytest.mark.parametrize("net_type", ["fm", "mlp"])
+def test_fit_with_sampler_options(net_type):
+    """neg_sampling through the public API: k = 2 doubles the epoch's steps, reject_seen keeps the user's
+    training positives out of the negatives fit() sees, training still converges; the reference-RNG mode refuses the
+    options (it replays the reference's sampler)."""
+    from torchrecsys_amd import ops
+    from torchrecsys_amd.model import TorchRecSys
+    rs = np.random.RandomState(4)
+    n_u, n_i, n = 80, 500, 6000  # ~60 training positives per user out of 500 items
+    users = torch.from_numpy(np.concatenate([np.arange(n_u), rs.randint(0, n_u, n - n_u)]).astype(np.int64)).to(DEV)
+    items = torch.from_numpy(np.concatenate([np.arange(n_i), rs.randint(0, n_i, n - n_i)]).astype(np.int64)).to(DEV)
+    seed(3)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        kw = dict(hidden_layers=[32, 16]) if net_type == "mlp" else {}
+        model = TorchRecSys.from_tensors(users, items, n_users=n_u, n_items=n_i, n_factors=16, net_type=net_type,
+                                         dynamic_neg_sampling=True, seed=1,
+                                         neg_sampling=dict(reject_seen=True, k=2, max_tries=16), **kw)
+        opt = torch.optim.SGD(model.parameters(), lr=0.1)
+        runner = model.make_runner(opt, 128)
+        n_train = model.data_processor.train_data["user_id"].shape[0]
+        assert runner.n_train == 2 * n_train and runner.num_batches == -(-2 * n_train // 128)
+        model.fit(opt, epochs=3, batch_size=128)
+        model.evaluate(batch_size=128)
+    losses = [float(x) for x in re.findall(r"Training Loss: ([0-9.]+)", buf.getvalue())]
+    assert len(losses) == 3 and all(np.isfinite(losses))
+    # the negatives of a training batch avoid the user's training positives
+    st = model._device_stream("train")
+    out = ops.batch_prepare(st["user"], st["pos"], None, 0x55, 0, 512, n_i, 9, 0, sampler=model._sampler())
+    u, neg = out["user"].cpu().numpy(), out["neg"].cpu().numpy()
+    su, si = st["user"].cpu().numpy(), st["pos"].cpu().numpy()
+    pos_of = {uu: set(si[su == uu].tolist()) for uu in np.unique(u)}
+    assert sum(int(nn in pos_of[uu]) for uu, nn in zip(u, neg)) == 0
+    with pytest.raises(ValueError):
+        with contextlib.redirect_stdout(io.StringIO()):
+            TorchRecSys.from_tensors(users.cpu(), items.cpu(), n_users=n_u, n_items=n_i, n_factors=8,
+                                     dynamic_neg_sampling=True, neg_sampling=dict(k=2))  # CPU tensors -> reference RNG
 
 
 def test_bench_line_contract():

@@ -77,6 +77,12 @@ class TrsMetaStage(C.Structure):
                 ("pos_meta_ids", C.c_void_p), ("neg_meta_ids", C.c_void_p)]
 
 
+class TrsSampler(C.Structure):
+    """struct trs_sampler (include/trs.h): sampler options beyond the reference's."""
+    _fields_ = [("k_neg", C.c_int32), ("popularity", C.c_int32), ("max_tries", C.c_int32), ("reserved", C.c_int32),
+                ("seen_off", C.c_void_p), ("seen_items", C.c_void_p), ("pop_items", C.c_void_p), ("pop_n", C.c_int64)]
+
+
 class TrsTrainArgs(C.Structure):
     """struct trs_train_args (include/trs.h): arguments of trs_train_steps_sgd."""
     _fields_ = [("net", C.c_int32), ("n_steps", C.c_int32), ("tables", C.POINTER(TrsTables)), ("batch", C.c_int64),
@@ -107,7 +113,7 @@ PROTOTYPES = {
     "trs_events_elapsed_ms": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
     "trs_sample_neg": (C.c_int, [_vp, C.c_int, _i64, _i64, _u64, _u64, _vp, _vp]),
     "trs_batch_prepare": (C.c_int, [_vp, _vp, _vp, _i64, _u64, _i64, _i64, _i64, _u64, _u64, _vp, _i32,
-                                    _vp, _vp, _vp, _vp, _vp, _vp]),
+                                    _vp, _vp, _vp, _vp, _vp, C.POINTER(TrsSampler), _vp]),
     "trs_score_forward": (C.c_int, [C.c_int, _T, _Bp, _vp, _vp, _vp]),
     "trs_score_fwd_bwd": (C.c_int, [C.c_int, _T, _Bp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "trs_score_backward": (C.c_int, [C.c_int, _T, _Bp, _vp, _vp, _vp, _vp, _vp]),
@@ -121,13 +127,14 @@ PROTOTYPES = {
     "trs_epoch_presort_meta": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _i64, _vp,
                                          C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp, _vp, _vp]),
     "trs_epoch_flags": (C.c_int, [_vp, _vp, _i64, _u64, _u64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
-                                  _vp]),
+                                  C.POINTER(TrsSampler), _vp]),
     "trs_epoch_user_dups_sizes": (C.c_int, [_i64, _i64, _i64, c_int64_p, c_int64_p, c_int64_p]),
     "trs_epoch_user_dups": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, C.POINTER(C.c_void_p),
                                       C.POINTER(C.c_void_p), c_int32_p, _vp]),
     "trs_epoch_presort_sizes": (C.c_int, [_i64, _i64, _i64, c_int64_p, c_int64_p, c_int64_p, c_int64_p]),
     "trs_epoch_presort": (C.c_int, [_vp, _vp, _i64, _u64, _u64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp,
-                                    _vp, _i64, _vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp, _vp]),
+                                    _vp, _i64, _vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp,
+                                    C.POINTER(TrsSampler), _vp]),
     "trs_hinge_auc": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "trs_hinge_auc_batches": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "trs_hinge_backward": (C.c_int, [_vp, _vp, _i64, _f, _vp, _vp, _vp]),

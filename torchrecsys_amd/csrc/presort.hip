@@ -78,6 +78,7 @@ struct EpochArgs {
   void* keys;  // (2*n_pos) uint32 or uint64
   RefPayload* vals;
   int32_t* err;
+  TrsSampler S;  // sampler options (max_tries == 0: the reference's sampler); k_neg: the epoch has N * k_neg positions
 };
 
 template <typename KeyT, int SRC>
@@ -87,12 +88,15 @@ __global__ __launch_bounds__(TRS_BLOCK) void epoch_refs_kernel(const EpochArgs a
   for (int64_t q = (int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x; q < a.n_pos; q += stride) {
     int64_t u, i, j;
     if (SRC != 0) {
-      const int64_t p = trs_feistel_perm(a.first_pos + q, a.N, a.shuffle_key, a.hb);
+      // (k_neg > 1: N * k_neg epoch positions, every stream row visited k_neg times, each time with its own negative)
+      const int64_t p = trs_feistel_perm(a.first_pos + q, a.N * a.S.k_neg, a.shuffle_key, a.hb) % a.N;
       const int2 ui = a.sui[p];
       u = ui.x;
       i = ui.y;
       j = SRC == 2 ? (int64_t)a.neg_static[p]
-                   : trs_sample_one_neg(a.sample_seed, (uint64_t)(a.first_pos + q), i, a.n_items);
+                   : ((uint64_t)u < (uint64_t)a.n_users && (uint64_t)i < (uint64_t)a.n_items
+                          ? trs_sample_neg_opt(a.sample_seed, (uint64_t)(a.first_pos + q), u, i, a.n_items, a.S)
+                          : 0);
     } else {
       u = a.user[q];
       i = a.pos[q];
@@ -108,8 +112,10 @@ __global__ __launch_bounds__(TRS_BLOCK) void epoch_refs_kernel(const EpochArgs a
       a.pos[q] = (int32_t)i;
       a.neg[q] = (int32_t)j;
     }
-    keys[2 * q] = (KeyT)i;
-    keys[2 * q + 1] = (KeyT)j;
+    if (keys) {  // (NULL: ids only — the sparse regime's flags need no sort keys)
+      keys[2 * q] = (KeyT)i;
+      keys[2 * q + 1] = (KeyT)j;
+    }
   }
 }
 
@@ -847,19 +853,24 @@ extern "C" int trs_epoch_presort(const int32_t* stream_ui_dev, const int32_t* ne
                                  int64_t batch, int64_t n_users, int64_t n_items, int32_t* user_dev, int32_t* pos_dev,
                                  int32_t* neg_dev, void* keys_dev, void* vals_dev, void* temp_dev, int64_t temp_bytes,
                                  int32_t* err_flag_dev, void** sorted_keys_out, void** sorted_vals_out,
-                                 uint8_t* item_dup_flags_out_dev, void* stream) {
+                                 uint8_t* item_dup_flags_out_dev, const trs_sampler* sampler, void* stream) {
   TRS_REQUIRE(n_batches > 0 && batch > 0 && n_users > 0 && n_items > 0, "trs_epoch_presort: bad sizes");
+  TRS_REQUIRE(!sampler || (sampler->k_neg >= 1 && (!sampler->popularity || (sampler->pop_items && sampler->pop_n > 0)) &&
+                           ((sampler->seen_off == nullptr) == (sampler->seen_items == nullptr))),
+              "trs_epoch_presort: bad sampler options");
   TRS_REQUIRE(user_dev && pos_dev && neg_dev && keys_dev && vals_dev && temp_dev, "trs_epoch_presort: NULL buffer");
   TRS_REQUIRE(sorted_keys_out && sorted_vals_out, "trs_epoch_presort: NULL output");
   const int64_t n_pos = n_batches * batch;
+  const int64_t kn = sampler && sampler->k_neg > 1 ? sampler->k_neg : 1;
   if (stream_ui_dev)
-    TRS_REQUIRE(N > 0 && first_pos >= 0 && first_pos + n_pos <= N, "trs_epoch_presort: slice outside the stream");
+    TRS_REQUIRE(N > 0 && first_pos >= 0 && first_pos + n_pos <= N * kn, "trs_epoch_presort: slice outside the stream");
   EpochArgs a = {};
+  a.S = trs_sampler_args(sampler);
   a.sui = (const int2*)stream_ui_dev;
   a.neg_static = neg_static_dev;
   a.N = N;
   a.shuffle_key = shuffle_key;
-  a.hb = stream_ui_dev ? trs_feistel_half_bits(N) : 0;
+  a.hb = stream_ui_dev ? trs_feistel_half_bits(N * kn) : 0;
   a.sample_seed = sample_seed;
   a.first_pos = first_pos;
   a.n_pos = n_pos;
@@ -911,7 +922,11 @@ extern "C" int trs_epoch_flags(const int32_t* stream_ui_dev, const int32_t* neg_
                                uint64_t shuffle_key, uint64_t sample_seed, int64_t first_pos, int64_t n_batches,
                                int64_t batch, int64_t n_users, int64_t n_items, int32_t* user_dev, int32_t* pos_dev,
                                int32_t* neg_dev, uint8_t* user_dup_flags_out_dev, uint8_t* item_dup_flags_out_dev,
-                               int32_t* err_flag_dev, void* stream) {
+                               int32_t* err_flag_dev, const trs_sampler* sampler, void* stream) {
+  const int64_t kn = sampler && sampler->k_neg > 1 ? sampler->k_neg : 1;
+  TRS_REQUIRE(!sampler || (sampler->k_neg >= 1 && (!sampler->popularity || (sampler->pop_items && sampler->pop_n > 0)) &&
+                           ((sampler->seen_off == nullptr) == (sampler->seen_items == nullptr))),
+              "trs_epoch_flags: bad sampler options");
   TRS_REQUIRE(batch <= (int64_t)FLAG_THREADS * FLAG_U * FLAG_MAX_ROUNDS,
               "trs_epoch_flags: batch %lld exceeds %d (one workgroup per batch keeps a bit per reference in registers)",
               (long long)batch, FLAG_THREADS * FLAG_U * FLAG_MAX_ROUNDS);
@@ -920,7 +935,8 @@ extern "C" int trs_epoch_flags(const int32_t* stream_ui_dev, const int32_t* neg_
   TRS_REQUIRE(user_dev && pos_dev && neg_dev && user_dup_flags_out_dev && item_dup_flags_out_dev,
               "trs_epoch_flags: NULL buffer");
   if (stream_ui_dev)
-    TRS_REQUIRE(N > 0 && first_pos >= 0 && first_pos + n_batches * batch <= N, "trs_epoch_flags: slice outside the stream");
+    TRS_REQUIRE(N > 0 && first_pos >= 0 && first_pos + n_batches * batch <= N * kn,
+                "trs_epoch_flags: slice outside the stream");
   FlagArgs a = {};
   a.sui = (const int2*)stream_ui_dev;
   a.neg_static = neg_static_dev;
@@ -946,8 +962,26 @@ extern "C" int trs_epoch_flags(const int32_t* stream_ui_dev, const int32_t* neg_
   a.item_hash = n_items > ((int64_t)1 << lb) ? 1 : 0;
   a.user_hash = n_users > ((int64_t)1 << lb) ? 1 : 0;
   const size_t lds = ((size_t)1 << lb) / 8;
-  const int src = !stream_ui_dev ? 0 : (neg_static_dev ? 2 : 1);
+  int src = !stream_ui_dev ? 0 : (neg_static_dev ? 2 : 1);
   hipStream_t s = (hipStream_t)stream;
+  if (src != 0) {
+    // The ids first, by a WIDE launch (a thread per triple: the shuffle's 8-byte reads out of the resident stream cost a
+    // 64-byte sector each and want every CU's loads in flight — 0.43 ms per 16.7M triples); the per-batch bitmap
+    // kernel then reads them back contiguously.  One workgroup per batch doing both took 216 us per batch whatever
+    // the slice length; split, a 16-batch slice takes ~60 us.
+    EpochArgs e = {};
+    e.sui = a.sui; e.neg_static = a.neg_static; e.N = a.N; e.shuffle_key = a.shuffle_key; e.hb = a.hb;
+    e.sample_seed = a.sample_seed; e.first_pos = a.first_pos; e.n_pos = n_batches * batch; e.batch = batch;
+    e.n_users = n_users; e.n_items = n_items; e.user = user_dev; e.pos = pos_dev; e.neg = neg_dev; e.keys = nullptr;
+    e.err = err_flag_dev;
+    e.S = trs_sampler_args(sampler);
+    e.hb = trs_feistel_half_bits(N * kn);
+    const dim3 ge(trs_grid(e.n_pos, TRS_BLOCK)), be(TRS_BLOCK);
+    if (src == 1) hipLaunchKernelGGL((epoch_refs_kernel<uint32_t, 1>), ge, be, 0, s, e);
+    else hipLaunchKernelGGL((epoch_refs_kernel<uint32_t, 2>), ge, be, 0, s, e);
+    TRS_CHECK_LAUNCH("epoch_refs_kernel");
+    src = 0;  // the ids now exist (validated and clamped): the flags kernel takes them as given
+  }
   const dim3 gr((unsigned)n_batches), bl(FLAG_THREADS);
 #define TRS_FL(SRC)                                                                                             \
   {                                                                                                             \

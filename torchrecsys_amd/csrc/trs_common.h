@@ -95,6 +95,58 @@ __host__ __device__ __forceinline__ int64_t trs_sample_one_neg(uint64_t seed, ui
   return v + (v >= pos ? 1 : 0);
 }
 
+// Sampler with the options of trs_sampler (include/trs.h); S.max_tries == 0 means "no options" (plain sampler).
+struct TrsSampler {  // trs_sampler by value, for kernel arguments
+  int k_neg, popularity, max_tries;
+  const int64_t* seen_off;
+  const int32_t* seen_items;
+  const int32_t* pop_items;
+  int64_t pop_n;
+};
+static inline TrsSampler trs_sampler_args(const trs_sampler* s) {
+  TrsSampler r = {1, 0, 0, nullptr, nullptr, nullptr, 0};
+  if (s) {
+    r.k_neg = s->k_neg < 1 ? 1 : s->k_neg;
+    r.popularity = s->popularity;
+    r.max_tries = s->max_tries < 1 ? 1 : s->max_tries;
+    r.seen_off = s->seen_off;
+    r.seen_items = s->seen_items;
+    r.pop_items = s->pop_items;
+    r.pop_n = s->pop_n;
+  }
+  return r;
+}
+__device__ __forceinline__ bool trs_user_has_item(const TrsSampler& S, int64_t u, int64_t item) {
+  int64_t lo = S.seen_off[u], hi = S.seen_off[u + 1];
+  while (lo < hi) {  // binary search in the user's sorted positives
+    const int64_t mid = (lo + hi) >> 1;
+    const int64_t v = S.seen_items[mid];
+    if (v == item) return true;
+    if (v < item) lo = mid + 1; else hi = mid;
+  }
+  return false;
+}
+__device__ __forceinline__ int64_t trs_sample_neg_opt(uint64_t seed, uint64_t ctr, int64_t u, int64_t pos,
+                                                      int64_t n_items, const TrsSampler& S) {
+  if (S.max_tries == 0) return trs_sample_one_neg(seed, ctr, pos, n_items);
+  if (n_items <= 1) return 0;
+  int64_t c = 0;
+  for (int k = 0; k < S.max_tries; ++k) {
+    const trs_u4 r = trs_philox4x32_10(ctr, seed + (uint64_t)k * 0x9E3779B97F4A7C15ull);
+    const uint64_t x = ((uint64_t)r.y << 32) | (uint64_t)r.x;
+    const int64_t v = (int64_t)trs_mulhi64(x, (uint64_t)(n_items - 1));
+    c = v + (v >= pos ? 1 : 0);  // uniform over the items other than the positive
+    if (S.popularity) {
+      const uint64_t x2 = ((uint64_t)r.w << 32) | (uint64_t)r.z;
+      const int64_t cp = S.pop_items[(int64_t)trs_mulhi64(x2, (uint64_t)S.pop_n)];
+      if (cp == pos) continue;  // the row's own positive: next candidate (the uniform c stays as the fallback)
+      c = cp;
+    }
+    if (!S.seen_off || !trs_user_has_item(S, u, c)) return c;
+  }
+  return c;
+}
+
 // ------------------------------------------------------------------------------------------ Feistel shuffle
 // Keyed bijection of [0,N): 4-round balanced Feistel network on 2*hb bits (2*hb >= ceil(log2 N)), cycle-walked back
 // into range.  Restated in oracle/philox.py::feistel_perm.

@@ -131,30 +131,61 @@ class TensorProcessData:
     from id tensors without a DataFrame.  At 1e8-1e9 rows the pandas copies of the reference (dataset.py:162,240)
     dominate start-up and host memory; here ids go straight to int32 in HBM.
 
-    user_ids, item_ids : (N,) integer tensors, CPU or GPU, dense ids 0..n-1
+    user_ids, item_ids : (N,) integer tensors, CPU or GPU
     item_metadata      : optional (n_items, M) integer tensor — the metadata ids of every item ((B,M) contract)
-    Split: CPU tensors use the reference's RandomState(42) permutation (identical rows to ProcessData); GPU tensors are
-    split on the device with a seeded torch.randperm (same proportions, different rows — one-time ingest, not the
-    training path)."""
+    remap_ids          : False (default, the reference's semantics: ids index the tables raw, dataset.py:30-31,268-269 —
+                         an id >= the table size raises IndexError HERE, at ingest, not in the first kernel) or True:
+                         arbitrary ids are mapped to dense 0..n-1 by rank (sorted unique values; `user_index` /
+                         `item_index` keep the original ids, TorchRecSys.predict translates both ways)
+    split              : 'reference' (default up to 2^31-1 rows): the reference's split — sklearn train_test_split(
+                         random_state=42) = np.random.RandomState(42).permutation(N), first ceil((1-ratio) N) rows test
+                         (dataset.py:237-249) — for CPU AND GPU tensors: the permutation is drawn on the host (8 B per
+                         row of host memory, ~0.1 s per 10M rows), uploaded as indices and applied on the device, so a
+                         GPU-resident stream is cut into exactly the rows the reference would train on.  Static
+                         negatives likewise come from the reference's single legacy-stream draw (dataset.py:56-64).
+                         'device': a seeded torch.randperm on the GPU (same proportions, other rows; no host pass)."""
 
     def __init__(self, user_ids, item_ids, n_users=None, n_items=None, item_metadata=None, metadata_names=None,
-                 split_ratio=0.8, dynamic_neg_sampling=False):
+                 split_ratio=0.8, dynamic_neg_sampling=False, remap_ids=False, split=None):
         assert user_ids.dim() == 1 and user_ids.shape == item_ids.shape
+        assert split in (None, 'reference', 'device')
         self.dynamic_neg_sampling = dynamic_neg_sampling
         self.split_ratio = split_ratio
         N = user_ids.shape[0]
-        self.num_users = int(n_users) if n_users is not None else (int(user_ids.max()) + 1 if N else 0)
-        self.num_items = int(n_items) if n_items is not None else (int(item_ids.max()) + 1 if N else 0)
+        self.split = split or ('reference' if N < 2 ** 31 else 'device')
+        if self.split == 'reference' and N >= 2 ** 31:
+            raise ValueError("split='reference' replays numpy's permutation on the host: at most 2^31-1 rows")
+        self.user_index = self.item_index = None
+        if remap_ids:  # dense ids by rank of the original value
+            self.user_index, user_ids = torch.unique(user_ids, sorted=True, return_inverse=True)
+            self.item_index, item_ids = torch.unique(item_ids, sorted=True, return_inverse=True)
+            if item_metadata is not None and item_metadata.shape[0] != self.item_index.numel():
+                item_metadata = item_metadata[self.item_index.to(item_metadata.device).long()]  # rows of the items present
+            n_users = n_users if n_users is not None and n_users >= self.user_index.numel() else self.user_index.numel()
+            n_items = n_items if n_items is not None and n_items >= self.item_index.numel() else self.item_index.numel()
+        if N:  # one reduction per column, on the device the ids live on
+            u_lo, u_hi = int(user_ids.min()), int(user_ids.max())
+            i_lo, i_hi = int(item_ids.min()), int(item_ids.max())
+        else:
+            u_lo = i_lo = 0
+            u_hi = i_hi = -1
+        self.num_users = int(n_users) if n_users is not None else u_hi + 1
+        self.num_items = int(n_items) if n_items is not None else i_hi + 1
+        if u_lo < 0 or i_lo < 0 or u_hi >= self.num_users or i_hi >= self.num_items:
+            raise IndexError(f"index out of range in self (ingest: user ids span [{u_lo}, {u_hi}] for a table of "
+                             f"{self.num_users} rows, item ids [{i_lo}, {i_hi}] for {self.num_items}; ids must be dense "
+                             f"0..n-1 as in the reference, dataset/dataset.py:30-31,268-269 — or pass remap_ids=True)")
         self._users, self._items = user_ids, item_ids
         self._neg = None
         if not dynamic_neg_sampling:
-            if user_ids.is_cuda:
+            if user_ids.is_cuda and self.split == 'device':
                 g = torch.Generator(device=user_ids.device)
                 g.manual_seed(int(np.random.randint(0, 2 ** 31 - 1)))
                 self._neg = torch.randint(0, self.num_items, (N,), device=user_ids.device, dtype=item_ids.dtype,
                                           generator=g)
             else:  # the reference's single legacy-stream draw (dataset.py:56-64)
-                self._neg = torch.from_numpy(np.random.randint(low=0, high=self.num_items, size=N)).to(item_ids.dtype)
+                self._neg = torch.from_numpy(np.random.randint(low=0, high=self.num_items, size=N)).to(
+                    item_ids.dtype).to(item_ids.device)
         self.item_meta_table = None
         self.metadata_id_col = None
         self.metadata_size = {}
@@ -172,12 +203,14 @@ class TensorProcessData:
         self.config = {"num_users": self.num_users, "num_items": self.num_items, "num_metadata": self.metadata_size}
         if self.split_ratio < 1:
             n_test = int(math.ceil((1 - self.split_ratio) * N))
-            if self._users.is_cuda:
+            if self.split == 'device' and self._users.is_cuda:
                 g = torch.Generator(device=self._users.device)
                 g.manual_seed(42)
                 perm = torch.randperm(N, device=self._users.device, generator=g)
-            else:
+            else:  # the reference's permutation, drawn where numpy lives and applied where the ids live
                 perm = torch.from_numpy(np.random.RandomState(42).permutation(N))
+                if self._users.is_cuda:
+                    perm = (perm.to(torch.int32) if N < 2 ** 31 else perm).to(self._users.device).long()
             tr, te = perm[n_test:], perm[:n_test]
         else:
             tr = torch.arange(N, device=self._users.device)

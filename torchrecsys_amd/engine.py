@@ -255,7 +255,7 @@ class SparseScorerTrainer:
             ps.__dict__.update(full.__dict__)
             ps.n_batches = n_batches
         if st is not None:
-            ps.run(st["ui"], st["neg"], shuffle_key, sample_seed, first_pos, self.err)
+            ps.run(st["ui"], st["neg"], shuffle_key, sample_seed, first_pos, self.err, sampler=getattr(self, "sampler", None))
         else:
             ps.run(None, None, 0, 0, 0, self.err, given_ids=given_ids)
         return ps

@@ -80,8 +80,10 @@ class TorchRecSys(torch.nn.Module):
                  hidden_layers: List[int] = None,
                  use_batch_norm: bool = True,
                  rng: str = 'reference',
-                 seed: int = 0):
+                 seed: int = 0,
+                 neg_sampling: dict = None):
         super().__init__()
+        self.neg_sampling = neg_sampling
         data_processor = ProcessData(dataset=dataset, user_id_col=user_id_col, item_id_col=item_id_col,
                                      metadata_id_col=metadata_id_col, split_ratio=split_ratio,
                                      dynamic_neg_sampling=dynamic_neg_sampling)
@@ -92,18 +94,21 @@ class TorchRecSys(torch.nn.Module):
     def from_tensors(cls, user_ids, item_ids, n_users=None, n_items=None, item_metadata=None, metadata_names=None,
                      n_factors=80, net_type='linear', split_ratio=0.8, dynamic_neg_sampling=False, use_amp=False,
                      use_cuda=False, debug=False, path='./', hidden_layers=None, use_batch_norm=True, rng=None,
-                     seed=0, pre_sharded=False, dp_partition='user'):
+                     seed=0, pre_sharded=False, dp_partition='user', remap_ids=False, split=None, neg_sampling=None):
         """Tensor-native ingest (no DataFrame): id tensors on the CPU or already in HBM.  GPU tensors default to
         rng='device' (stream resident in HBM, on-device shuffle and sampler).  pre_sharded=True: under data parallelism
         the given interactions already ARE this rank's shard (each rank ingested its own part), so they are not cut
         again by rank; shards may differ in length (every rank then trains on the common number of rows, see
         _rank_rows).  dp_partition: how the stream is (pre_sharded: was) cut — 'user' = by user_id % world (each user
-        row has ONE writer, see fit()), 'contiguous' = equal contiguous blocks."""
+        row has ONE writer, see fit()), 'contiguous' = equal contiguous blocks.  remap_ids / split: see
+        dataset.TensorProcessData (dense re-mapping of arbitrary ids; 'reference' = the reference's RandomState(42)
+        split also for GPU tensors, 'device' = a seeded permutation drawn on the GPU)."""
         from .dataset.dataset import TensorProcessData
         self = cls.__new__(cls)
         torch.nn.Module.__init__(self)
+        self.neg_sampling = neg_sampling
         dp = TensorProcessData(user_ids, item_ids, n_users, n_items, item_metadata, metadata_names, split_ratio,
-                               dynamic_neg_sampling)
+                               dynamic_neg_sampling, remap_ids=remap_ids, split=split)
         if rng is None:
             rng = 'device' if user_ids.is_cuda else 'reference'
         if user_ids.is_cuda and rng != 'device':
@@ -118,6 +123,12 @@ class TorchRecSys(torch.nn.Module):
     def _setup(self, data_processor, metadata_id_col, n_factors, net_type, dynamic_neg_sampling, use_amp, use_cuda,
                debug, path, hidden_layers, use_batch_norm, rng, seed):
         assert rng in ('reference', 'device'), 'rng must be "reference" or "device"'
+        ns = getattr(self, "neg_sampling", None)
+        if ns:
+            unknown = set(ns) - {"reject_seen", "popularity", "k", "max_tries"}
+            if unknown or rng != 'device' or not dynamic_neg_sampling:
+                raise ValueError("neg_sampling takes reject_seen / popularity / k / max_tries and needs rng='device' with "
+                                 "dynamic_neg_sampling=True (the reference-RNG mode replays the reference's sampler)")
         self.path = path
         self.dynamic_neg_sampling = dynamic_neg_sampling
         self.use_amp = use_amp
@@ -258,6 +269,31 @@ class TorchRecSys(torch.nn.Module):
             self._dev_cache[which] = d
         return self._dev_cache[which]
 
+    def _sampler(self):
+        """ops.Sampler of the neg_sampling options, or None = the reference's sampler: uniform over the
+        items other than the row's positive (dataset/dataset.py:435-447).  reject_seen uses the TRAIN split's (user, item)
+        pairs; popularity the train split's item frequencies."""
+        ns = getattr(self, "neg_sampling", None)
+        if not ns:
+            return None
+        if 'sampler' not in self._dev_cache:
+            st = self._device_stream('train')
+            seen = ops.Sampler.seen_csr(st['user'], st['pos'], self.n_users, self.n_items) if ns.get("reject_seen") else None
+            self._dev_cache['sampler'] = ops.Sampler(k=ns.get("k", 1), popularity=ns.get("popularity", False), seen=seen,
+                                                     stream_item=st['pos'], max_tries=ns.get("max_tries", 8))
+        return self._dev_cache['sampler']
+
+    def _eval_sampler(self):
+        """evaluate(): the same candidate rules (reject_seen / popularity), every test row once."""
+        sm = self._sampler()
+        if sm is None or sm.k == 1:
+            return sm
+        if 'eval_sampler' not in self._dev_cache:
+            ns = self.neg_sampling
+            self._dev_cache['eval_sampler'] = ops.Sampler(k=1, popularity=ns.get("popularity", False), seen=sm.keep[0],
+                                                          stream_item=sm.keep[1], max_tries=ns.get("max_tries", 8))
+        return self._dev_cache['eval_sampler']
+
     def _item_meta_dev(self):
         tab = self.data_processor.item_meta_table
         if tab is None:
@@ -381,7 +417,7 @@ class TorchRecSys(torch.nn.Module):
                 ids = {k: v[s:e] for k, v in ep.items()}
             else:
                 ids = ops.batch_prepare(st['user'], st['pos'], st['neg'], 0, s, e - s, self.n_items, sample_seed, s,
-                                        st['item_meta'])
+                                        st['item_meta'], sampler=self._eval_sampler())
             pos, neg = self.net.score_ids(ids)
             ops.hinge_auc_batches(pos, neg, batch_size, loss_sums[b0:b1], auc_counts[b0:b1])
         ls, ac = loss_sums.cpu().numpy(), auc_counts.cpu().numpy()
@@ -409,11 +445,25 @@ class TorchRecSys(torch.nn.Module):
         `prediction_batch_size` is accepted for compatibility; the fused kernel streams the item table once and the
         result does not depend on it."""
         self.net = self.net.eval()
-        scores = self.net.score_all_items(int(user_id), self._item_meta_dev())
+        scores = self.net.score_all_items(self._dense_user(user_id), self._item_meta_dev())
         k = min(int(top_k), self.n_items)
         if k <= 0:
             return torch.empty(0, dtype=torch.int64)
-        return ops.topk(scores, k).cpu()
+        return self._original_items(ops.topk(scores, k).cpu())
+
+    def _dense_user(self, user_id):
+        """Table row of a caller's user id (identity unless the ingest re-mapped ids, TensorProcessData(remap_ids=True))."""
+        idx = getattr(self.data_processor, "user_index", None)
+        if idx is None:
+            return int(user_id)
+        pos = int(torch.searchsorted(idx, torch.tensor(int(user_id), dtype=idx.dtype, device=idx.device)))
+        if pos >= idx.numel() or int(idx[pos]) != int(user_id):
+            raise IndexError(f"user id {user_id} does not occur in the ingested interactions")
+        return pos
+
+    def _original_items(self, rows):
+        idx = getattr(self.data_processor, "item_index", None)
+        return rows if idx is None else idx.cpu()[rows].to(torch.int64)
 
 
     @_host_side
@@ -422,14 +472,14 @@ class TorchRecSys(torch.nn.Module):
         equals `predict(user_ids[r], top_k)`; the per-user kernels are queued back to back and read back once."""
         self.net = self.net.eval()
         k = min(int(top_k), self.n_items)
-        users = [int(u) for u in (user_ids.tolist() if hasattr(user_ids, "tolist") else user_ids)]
+        users = [self._dense_user(u) for u in (user_ids.tolist() if hasattr(user_ids, "tolist") else user_ids)]
         if k <= 0 or not users:
             return torch.empty((len(users), max(k, 0)), dtype=torch.int64)
         meta = self._item_meta_dev()
         out = torch.empty((len(users), k), dtype=torch.int64, device=_device())
         for r, u in enumerate(users):
             out[r] = ops.topk(self.net.score_all_items(u, meta), k)
-        return out.cpu()
+        return self._original_items(out.cpu())
 
 
 class FitRunner:
@@ -441,7 +491,9 @@ class FitRunner:
         self.batch_size = batch_size
         self.dev = _device()
         self.data = model._rank_rows(model.data_processor.train_data)
-        self.n_train = self.data['user_id'].shape[0]
+        self.sampler = model._sampler() if model.rng == 'device' else None
+        # k negatives per positive: the epoch visits every training row k times (k * N positions)
+        self.n_train = self.data['user_id'].shape[0] * (self.sampler.k if self.sampler else 1)
         self.loader = FastDataLoader(data=self.data, batch_size=batch_size, shuffle=True,
                                      dynamic_neg_sampling=model.dynamic_neg_sampling, n_items=model.n_items,
                                      item_to_metadata_map=model.data_processor.item_meta_table,
@@ -450,6 +502,7 @@ class FitRunner:
         self.trainer = model._make_trainer(optimizer, min(batch_size, max(self.n_train, 1)))
         if getattr(self.trainer, "M", 0) > 0:
             self.trainer.item_meta = model._item_meta_dev()  # metadata scorers: the presort groups each column too
+        self.trainer.sampler = self.sampler
         self.loss_sums = torch.zeros(max(self.num_batches, 1), dtype=torch.float32, device=self.dev)
         self.next_batch = 0
         self.ep = None
@@ -532,9 +585,11 @@ class FitRunner:
                     n = min(n, s0 + ps.n_batches - b)
                     self.trainer.fast_sorted_steps(ps, b - s0, B, n, self.loss_sums[b:b + n],
                                                    m._item_meta_dev() if has_meta else None)
-                elif m.rng == 'device':
+                elif m.rng == 'device' and self.sampler is None:
                     self.trainer.fast_stream_steps(self.st, self.shuffle_key, self.sample_seed, b * B, B, n,
                                                    self.loss_sums[b:b + n])
+                elif m.rng == 'device':  # sampler options live in the presort / batch_prepare generators
+                    break
                 else:
                     self.trainer.fast_array_steps(self.ep, b * B, B, n, self.loss_sums[b:b + n])
                 self.next_batch += n
@@ -548,7 +603,7 @@ class FitRunner:
                 st = self.st
                 out = self.prep_out if (self.prep_out is not None and e - s == B) else None
                 ids = ops.batch_prepare(st['user'], st['pos'], st['neg'], self.shuffle_key, s, e - s, m.n_items,
-                                        self.sample_seed, s, st['item_meta'], out)
+                                        self.sample_seed, s, st['item_meta'], out, sampler=self.sampler)
                 if e - s == B:
                     self.prep_out = ids
             self.trainer.step(ids, self.loss_sums[b:b + 1])

@@ -155,6 +155,41 @@ def interleave_stream(stream_user, stream_item):
     return torch.stack([stream_user, stream_item], dim=1).contiguous()
 
 
+class Sampler:
+    """trs_sampler (include/trs.h): negative-sampler options beyond the reference's, for the device RNG mode.
+      k            negatives per positive (the epoch then has k * N positions)
+      popularity   draw candidates proportionally to the items' frequency in `stream_item`
+      seen         (offsets (n_users+1,) int64, items int32 sorted per user): reject items the user has interacted with
+      max_tries    candidates tried before the last one is kept"""
+
+    def __init__(self, k=1, popularity=False, seen=None, stream_item=None, max_tries=8):
+        self.c = _lib.TrsSampler()
+        self.c.k_neg, self.c.popularity, self.c.max_tries = int(k), int(bool(popularity)), int(max_tries)
+        self.keep = [seen, stream_item]
+        if seen is not None:
+            off, items = seen
+            _dev(off, "seen offsets", torch.int64)
+            _dev(items, "seen items", torch.int32)
+            self.c.seen_off, self.c.seen_items = ptr(off), ptr(items)
+        if popularity:
+            _dev(stream_item, "stream items", torch.int32)
+            self.c.pop_items, self.c.pop_n = ptr(stream_item), stream_item.numel()
+        self.k = int(k)
+
+    @staticmethod
+    def seen_csr(user, item, n_users, n_items):
+        """CSR of the distinct (user, item) pairs of a device-resident stream: (offsets int64 (n_users+1,), items int32)."""
+        key = torch.unique(user.long() * int(n_items) + item.long())
+        u = torch.div(key, int(n_items), rounding_mode="floor")
+        off = torch.zeros(n_users + 1, dtype=torch.int64, device=user.device)
+        off[1:] = torch.cumsum(torch.bincount(u, minlength=n_users), 0)
+        return off, (key - u * int(n_items)).to(torch.int32).contiguous()
+
+
+def _samp(sampler):
+    return C.byref(sampler.c) if sampler is not None else None
+
+
 class EpochPresort:
     """Buffers + result of trs_epoch_presort for n_batches whole batches: id arrays and the item references of every
     batch sorted by row.  `step_args(b)` gives what trs_train_steps_sgd needs to start at batch b of the slice."""
@@ -199,7 +234,7 @@ class EpochPresort:
         return (12 * n_batches * batch + (1 + n_meta_cols) * (ktot.value + vtot.value) + tmp.value
                 + 19 * n_batches * batch)
 
-    def run(self, stream_ui, neg_static, shuffle_key, sample_seed, first_pos, err_flag, given_ids=None):
+    def run(self, stream_ui, neg_static, shuffle_key, sample_seed, first_pos, err_flag, given_ids=None, sampler=None):
         """Generate (stream_ui given) or adopt (given_ids = (user, pos, neg) int32 tensors) the ids and sort the refs."""
         if given_ids is not None:
             n_pos = self.n_batches * self.batch  # may be a shorter tail slice in the same buffers
@@ -211,7 +246,7 @@ class EpochPresort:
                                             int(first_pos), self.n_batches, self.batch, self.n_users, self.n_items,
                                             ptr(self.ids[0]), ptr(self.ids[1]), ptr(self.ids[2]), ptr(self.keys),
                                             ptr(self.vals), ptr(self.temp), self.temp_bytes, ptr(err_flag),
-                                            C.byref(sk), C.byref(sv), ptr(self.item_dup), _stream()),
+                                            C.byref(sk), C.byref(sv), ptr(self.item_dup), _samp(sampler), _stream()),
               "trs_epoch_presort")
         self.sorted_keys, self.sorted_vals = sk.value, sv.value
         uk, uv, ukb = C.c_void_p(), C.c_void_p(), C.c_int32()
@@ -270,7 +305,7 @@ class EpochFlags:
     def bytes_needed(n_batches, batch):
         return 15 * n_batches * batch
 
-    def run(self, stream_ui, neg_static, shuffle_key, sample_seed, first_pos, err_flag, given_ids=None):
+    def run(self, stream_ui, neg_static, shuffle_key, sample_seed, first_pos, err_flag, given_ids=None, sampler=None):
         if given_ids is not None:
             n_pos = self.n_batches * self.batch
             for dst, src in zip(self.ids, given_ids):
@@ -279,7 +314,8 @@ class EpochFlags:
         check(_lib.load().trs_epoch_flags(ptr(stream_ui), ptr(neg_static), N, int(shuffle_key), int(sample_seed),
                                           int(first_pos), self.n_batches, self.batch, self.n_users, self.n_items,
                                           ptr(self.ids[0]), ptr(self.ids[1]), ptr(self.ids[2]), ptr(self.user_dup),
-                                          ptr(self.item_dup), ptr(err_flag), _stream()), "trs_epoch_flags")
+                                          ptr(self.item_dup), ptr(err_flag), _samp(sampler), _stream()),
+              "trs_epoch_flags")
 
     def step_args(self, b):
         """(id views, user-duplicate flags view, item-duplicate flags view) from batch b of the slice on."""
@@ -371,7 +407,7 @@ def sample_neg(pos, n_items, seed, offset):
 
 
 def batch_prepare(stream_user, stream_item, neg_static, shuffle_key, t0, B, n_items, seed, offset, item_meta=None,
-                  out=None):
+                  out=None, sampler=None):
     """Returns dict of int32 GPU tensors user/pos/neg[/pos_meta/neg_meta] for epoch positions [t0, t0+B)."""
     dev = stream_user.device
     M = 0 if item_meta is None else item_meta.shape[1]
@@ -383,7 +419,7 @@ def batch_prepare(stream_user, stream_item, neg_static, shuffle_key, t0, B, n_it
     check(_lib.load().trs_batch_prepare(ptr(stream_user), ptr(stream_item), ptr(neg_static), stream_user.numel(),
                                         int(shuffle_key), int(t0), int(B), int(n_items), int(seed), int(offset),
                                         ptr(item_meta), M, ptr(out["user"]), ptr(out["pos"]), ptr(out["neg"]),
-                                        ptr(out.get("pos_meta")), ptr(out.get("neg_meta")), _stream()),
+                                        ptr(out.get("pos_meta")), ptr(out.get("neg_meta")), _samp(sampler), _stream()),
           "trs_batch_prepare")
     return out
 
