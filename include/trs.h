@@ -40,6 +40,13 @@ extern "C" {
 #define TRS_NET_LINEAR 0
 #define TRS_NET_FM 1
 
+/* Pairwise training loss over (positive score, negative score), mean over the batch.  HINGE is the reference's
+ * (helper/loss.py:5-9: clamp(neg - pos + 1, min=0)); BPR = -log sigmoid(pos - neg) is the alternative BASELINE.json's
+ * north_star names — the reference has no such loss and fit() no loss argument, so BPR is pinned by its formula
+ * (oracle/nets.py::bpr_loss against torch autograd), not by reference outputs. */
+#define TRS_LOSS_HINGE 0
+#define TRS_LOSS_BPR 1
+
 /* Embedding tables of one scorer.  Row-major (n_rows, D) fp32, as nn.Embedding.weight
  * (embeddings/init_embeddings.py:5-50,53-97).
  *   Linear (collaborative/linear.py:43-51): user,item = self.user,self.item; user_lin,item_lin = user_bias,item_bias
@@ -155,7 +162,7 @@ int trs_score_forward(int net, const trs_tables* tables, const trs_batch* batch,
  * (atomic float / int adds): zero them before the first call. */
 int trs_score_fwd_bwd(int net, const trs_tables* tables, const trs_batch* batch, float inv_B,
                       float* pos_score_dev, float* neg_score_dev, float* loss_sum_dev,
-                      int32_t* auc_count_dev, float* grad_rows_dev, float* grad_lin_dev, void* stream);
+                      int32_t* auc_count_dev, float* grad_rows_dev, float* grad_lin_dev, int32_t loss, void* stream);
 
 /* Backward only, from upstream d(loss)/d(score) (B,) per pass — the autograd.Function backward used when a caller
  * drives net.forward + its own loss (any objective), same staging as above. */
@@ -249,6 +256,7 @@ typedef struct trs_train_args {
   const trs_tables* tables;
   int64_t batch;
   float lr;                  /* plain SGD (opt == NULL) */
+  int32_t loss;              /* TRS_LOSS_HINGE (0, the reference) | TRS_LOSS_BPR */
   uint32_t first_stamp;      /* with scratch: step counter of the first step, non-zero, strictly increasing */
   /* ids: derived from the resident stream (stream_ui != NULL; {user,item} int32 pairs, (N,2)) or given in the buffers */
   const int32_t* stream_ui_dev;
@@ -362,17 +370,18 @@ int trs_rows_apply_adagrad(float* table_dev, float* acc_dev, float* state_sum_de
                            int32_t step_id, float clr, float eps, void* stream);
 
 /* ------------------------------------------------------------------------------ hinge / AUC (a5, a12) */
-/* loss_sum += sum_t max(neg-pos+1, 0); auc_count += #(pos > neg).  (helper/loss.py:5-9, evaluate/metrics.py:23-31) */
+/* loss_sum += sum_t max(neg-pos+1, 0); auc_count += #(pos > neg).  (helper/loss.py:5-9, evaluate/metrics.py:23-31)
+ * loss = TRS_LOSS_BPR: the sum of softplus(neg - pos) instead (same for the two functions below). */
 int trs_hinge_auc(const float* pos_dev, const float* neg_dev, int64_t B, float* loss_sum_dev,
-                  int32_t* auc_count_dev, void* stream);
+                  int32_t* auc_count_dev, int32_t loss, void* stream);
 /* The same for consecutive batches of `batch` rows of (n_total,) score arrays in one launch: loss_sums_dev[b] /
  * auc_counts_dev[b] (b < ceil(n_total / batch) <= 65535) accumulate batch b's sums — evaluate()'s per-batch metrics
  * (model.py:300-330) without one launch and one host round trip per batch. */
 int trs_hinge_auc_batches(const float* pos_dev, const float* neg_dev, int64_t n_total, int64_t batch,
-                          float* loss_sums_dev, int32_t* auc_counts_dev, void* stream);
+                          float* loss_sums_dev, int32_t* auc_counts_dev, int32_t loss, void* stream);
 /* d(mean hinge)/d(pos), d(.)/d(neg): -a/B, +a/B with a = [neg-pos+1 >= 0] (torch clamp subgradient). */
 int trs_hinge_backward(const float* pos_dev, const float* neg_dev, int64_t B, float inv_B, float* gpos_dev,
-                       float* gneg_dev, void* stream);
+                       float* gneg_dev, int32_t loss, void* stream);
 
 /* ---------------------------------------------------------------------------------- predict (a13) */
 /* Scores of ONE user against items [item0, item0+n) (model.py:341-452: net.forward over item chunks, pos keys

@@ -309,28 +309,44 @@ def _add(a, b):
     return {k: (a[k] + b[k]).astype(F32) for k in a}
 
 
-def train_forward_backward(net_type, params, batch):
+def bpr_loss(pos, neg):
+    """mean(-log sigmoid(pos - neg)) = mean softplus(neg - pos).  NOT in the reference (helper/loss.py holds hinge_loss
+    only): BASELINE.json's north_star names it beside hinge; pinned by its formula against torch autograd
+    (tests/test_oracle_golden.py), there is no reference output for it."""
+    x = (np.asarray(neg, np.float64) - np.asarray(pos, np.float64)).reshape(-1)
+    return F32(np.mean(np.maximum(x, 0) + np.log1p(np.exp(-np.abs(x)))))
+
+
+def bpr_grad(pos, neg):
+    """d bpr_loss / d pos, d neg: -+ sigmoid(neg - pos) / B."""
+    x = (np.asarray(neg, F32) - np.asarray(pos, F32)).astype(F32)
+    s = (F32(1) / (F32(1) + np.exp(-x))).astype(F32) / F32(x.size)
+    return (-s).astype(F32).reshape(np.shape(pos)), s.astype(F32).reshape(np.shape(neg))
+
+
+def train_forward_backward(net_type, params, batch, loss="hinge"):
     """TorchRecSys.forward + hinge_loss + loss.backward() (model.py:171-185, 280-284, 188-197) on one batch dict
     with keys user_id, pos_item_id, neg_item_id[, pos_metadata_id, neg_metadata_id].
     Returns (pos_score, neg_score, loss, dense-equivalent grads).  MLP: `params` running stats are updated in place."""
     u, p, n = batch["user_id"], batch["pos_item_id"], batch["neg_item_id"]
     pm, nm = batch.get("pos_metadata_id"), batch.get("neg_metadata_id")
+    _lg = bpr_grad if loss == "bpr" else hinge_grad
     if net_type == "linear":
         sp, sn = linear_forward(params, u, p, pm), linear_forward(params, u, n, nm)
-        gp, gn = hinge_grad(sp, sn)
+        gp, gn = _lg(sp, sn)
         grads = _add(linear_backward(params, u, p, pm, gp), linear_backward(params, u, n, nm, gn))
     elif net_type == "fm":
         sp, sn = fm_forward(params, u, p, pm), fm_forward(params, u, n, nm)
-        gp, gn = hinge_grad(sp, sn)
+        gp, gn = _lg(sp, sn)
         grads = _add(fm_backward(params, u, p, pm, gp), fm_backward(params, u, n, nm, gn))
     elif net_type == "mlp":
         sp, cp = mlp_forward(params, u, p, pm, training=True)
         sn, cn = mlp_forward(params, u, n, nm, training=True)
-        gp, gn = hinge_grad(sp, sn)
+        gp, gn = _lg(sp, sn)
         grads = _add(mlp_backward(params, u, p, pm, gp, cp), mlp_backward(params, u, n, nm, gn, cn))
     else:
         raise ValueError(net_type)
-    return sp, sn, hinge_loss(sp, sn), grads
+    return sp, sn, (bpr_loss if loss == "bpr" else hinge_loss)(sp, sn), grads
 
 
 def touched_rows(net_type, params, batch):

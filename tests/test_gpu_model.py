@@ -523,6 +523,54 @@ def test_amp_training_run_and_profiling_run(net_type):
     assert all(np.isfinite(v.cpu().numpy()).all() for v in model.state_dict().values())
 
 
+@pytest.mark.parametrize("net_type,M", [("linear", 0), ("fm", 0), ("fm", 1), ("mlp", 1)])
+def test_bpr_training_step_matches_the_oracle(net_type, M):
+    """loss='bpr' (BASELINE.json north_star; the reference has hinge only): one fused training step on the golden G1
+    batch == the oracle's step with BPR's score gradients — scores, loss, every updated parameter — on the generic staged
+    path and, without metadata, on the presorted fast path too; helper.loss.bpr_loss is differentiable like hinge_loss."""
+    from torchrecsys_amd.engine import SparseScorerTrainer
+    from torchrecsys_amd.helper.loss import bpr_loss
+    from torchrecsys_amd.mlp_engine import MLPTrainer
+    from oracle import optim as ooptim
+    g = load_golden(f"g1_{net_type}_M{M}.npz")
+    b = golden_batch(g)
+    B = b["user_id"].shape[0]
+    lr = 0.05
+    params = {k: v.copy() for k, v in sub(g, "init").items()}
+    batch = {k: v.numpy() for k, v in b.items()}
+    _, _, oloss, ograds = onets.train_forward_backward(net_type, params, batch, loss="bpr")
+    ooptim.sgd_step(params, {k: v for k, v in ograds.items()}, lr)
+    for path in (("generic", "fast") if (net_type != "mlp" and M == 0) else ("generic",)):
+        net = build_net(net_type, M, g)
+        net.train()
+        opt = torch.optim.SGD(net.parameters(), lr=lr)
+        dev = net.user.weight.device
+        idt = torch.int32 if path == "fast" else torch.int64
+        ids = {"user": b["user_id"].to(dev).to(idt), "pos": b["pos_item_id"].to(dev).to(idt),
+               "neg": b["neg_item_id"].to(dev).to(idt)}
+        if M:
+            ids["pos_meta"] = b["pos_metadata_id"].reshape(B, M).to(dev).contiguous()
+            ids["neg_meta"] = b["neg_metadata_id"].reshape(B, M).to(dev).contiguous()
+        tr = (MLPTrainer if net_type == "mlp" else SparseScorerTrainer)(net, opt, B)
+        tr.loss_id = 1
+        slot = torch.zeros(1, device=dev)
+        tr.step(ids, slot)
+        tr.check_errors()
+        assert abs(slot.item() / B - float(oloss)) < TOL * max(float(oloss), 1e-3), path
+        for k, p_ in net.state_dict().items():
+            if p_.dtype == torch.float32 and "running" not in k:
+                if net_type == "mlp" and k.startswith("fcs") and k.endswith("bias"):
+                    continue
+                assert rel_err(p_.cpu().numpy(), params[k]) < TOL, (path, k)
+    # the differentiable helper: same value, same gradients as torch's own formula
+    net = build_net(net_type, M, g)
+    net.train()
+    pos, neg = net.forward_pair(b)
+    l = bpr_loss(pos, neg)
+    l.backward()
+    assert abs(l.item() - float(oloss)) < TOL * max(float(oloss), 1e-3)
+
+
 @pytest.mark.parametrize("net_type", ["fm", "mlp"])
 def test_fit_with_sampler_options(net_type):
     """neg_sampling through the public API: k = 2 doubles the epoch's steps, reject_seen keeps the user's

@@ -203,6 +203,27 @@ def test_device_sampler_properties():
     assert cnt[0] == 0 and (np.abs(cnt[1:] - 10000) < 500).all()
 
 
+@pytest.mark.parametrize("name", ["linear", "fm", "mlp"])
+def test_bpr_oracle_against_torch_autograd(name):
+    """BPR (-log sigmoid(pos - neg), BASELINE.json north_star) is not in the reference, so there is no golden vector:
+    oracle/nets.py's loss and gradient are pinned by torch autograd of the formula on the golden G1 scores, and the
+    whole-step gradients by linearity — d loss / d params = the hinge machinery driven with BPR's score gradients."""
+    import torch
+    g = load_golden(f"g1_{name}_M1.npz")
+    pos, neg = g["pos"].reshape(-1), g["neg"].reshape(-1)
+    tp = torch.tensor(pos, dtype=torch.float64, requires_grad=True)
+    tn = torch.tensor(neg, dtype=torch.float64, requires_grad=True)
+    loss = -torch.nn.functional.logsigmoid(tp - tn).mean()
+    loss.backward()
+    assert abs(float(nets.bpr_loss(pos, neg)) - float(loss)) < 1e-6
+    gp, gn = nets.bpr_grad(pos, neg)
+    assert rel_err(gp, tp.grad.numpy()) < TOL and rel_err(gn, tn.grad.numpy()) < TOL
+    params, batch = _params(g), _batch(g)
+    sp, sn, l, grads = nets.train_forward_backward(name, params, batch, loss="bpr")
+    assert abs(float(l) - float(nets.bpr_loss(sp, sn))) < 1e-7
+    assert all(np.isfinite(v).all() for v in grads.values())
+
+
 def test_option_sampler_reduces_to_the_plain_sampler_and_rejects_seen_items():
     """oracle/loader.py::device_negatives_opt (trs_sampler, SURVEY 8f-4) with every option off IS device_negatives; with
     `seen` it never returns one of the user's positives while an unseen item exists within the tries."""

@@ -10,6 +10,7 @@ import os
 TRS_MAX_META = 8
 TRS_NET_LINEAR = 0
 TRS_NET_FM = 1
+LOSS_ID = {"hinge": 0, "bpr": 1}  # TRS_LOSS_HINGE / TRS_LOSS_BPR
 ABI_VERSION = 2  # == TRS_ABI_VERSION of include/trs.h (tests/test_abi.py)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -86,7 +87,7 @@ class TrsSampler(C.Structure):
 class TrsTrainArgs(C.Structure):
     """struct trs_train_args (include/trs.h): arguments of trs_train_steps_sgd."""
     _fields_ = [("net", C.c_int32), ("n_steps", C.c_int32), ("tables", C.POINTER(TrsTables)), ("batch", C.c_int64),
-                ("lr", C.c_float), ("first_stamp", C.c_uint32),
+                ("lr", C.c_float), ("loss", C.c_int32), ("first_stamp", C.c_uint32),
                 ("stream_ui_dev", C.c_void_p), ("neg_static_dev", C.c_void_p), ("N", C.c_int64),
                 ("shuffle_key", C.c_uint64), ("sample_seed", C.c_uint64), ("first_pos", C.c_int64),
                 ("user_buf_dev", C.c_void_p), ("pos_buf_dev", C.c_void_p), ("neg_buf_dev", C.c_void_p),
@@ -115,7 +116,7 @@ PROTOTYPES = {
     "trs_batch_prepare": (C.c_int, [_vp, _vp, _vp, _i64, _u64, _i64, _i64, _i64, _u64, _u64, _vp, _i32,
                                     _vp, _vp, _vp, _vp, _vp, C.POINTER(TrsSampler), _vp]),
     "trs_score_forward": (C.c_int, [C.c_int, _T, _Bp, _vp, _vp, _vp]),
-    "trs_score_fwd_bwd": (C.c_int, [C.c_int, _T, _Bp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "trs_score_fwd_bwd": (C.c_int, [C.c_int, _T, _Bp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "trs_score_backward": (C.c_int, [C.c_int, _T, _Bp, _vp, _vp, _vp, _vp, _vp]),
     "trs_rows_scatter_add": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _i64, _i64, _f, _vp, _vp]),
     "trs_score_sgd_update": (C.c_int, [C.c_int, _T, _Bp, _vp, _vp, _f, _vp]),
@@ -135,9 +136,9 @@ PROTOTYPES = {
     "trs_epoch_presort": (C.c_int, [_vp, _vp, _i64, _u64, _u64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _i64, _vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp,
                                     C.POINTER(TrsSampler), _vp]),
-    "trs_hinge_auc": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
-    "trs_hinge_auc_batches": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
-    "trs_hinge_backward": (C.c_int, [_vp, _vp, _i64, _f, _vp, _vp, _vp]),
+    "trs_hinge_auc": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i32, _vp]),
+    "trs_hinge_auc_batches": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i32, _vp]),
+    "trs_hinge_backward": (C.c_int, [_vp, _vp, _i64, _f, _vp, _vp, _i32, _vp]),
     "trs_score_all_items": (C.c_int, [C.c_int, _T, _i64, _i64, _i64, _vp, _vp, _vp]),
     "trs_topk_workspace_bytes": (C.c_int64, [_i64, _i32]),
     "trs_topk": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _i64, _vp]),

@@ -49,6 +49,7 @@ struct FastArgs {
   float* du;  // (B,D)
   float inv_B;
   float lr;
+  int loss;  // TRS_LOSS_HINGE | TRS_LOSS_BPR
   float* loss_sum;
   // duplicate detection (all NULL: every update is atomic)
   uint64_t* uown;  // (n_users) last reference of the step that named the row: (stamp << 32) | t
@@ -221,10 +222,11 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
       sp = (pp + r.ul) + r.pl;
       sn = (pn + r.ul) + r.nl;
     }
-    const float h = sn - sp + 1.0f;
-    const float act = (live && h >= 0.f) ? 1.f : 0.f;
+    float lval, dneg;
+    trs_pair_loss(a.loss, sp, sn, lval, dneg);
+    const float act = live ? dneg : 0.f;
     float gp = -act * a.inv_B, gn = act * a.inv_B;
-    if (live && lig == 0) loss_acc += fmaxf(h, 0.f);
+    if (live && lig == 0) loss_acc += lval;
     if (NET == TRS_NET_FM) {
       gp = gp * ((1.0f - sp) * sp);
       gn = gn * ((1.0f - sn) * sn);
@@ -972,10 +974,11 @@ __global__ __launch_bounds__(TRS_BLOCK) void meta_stage_kernel(const ScoreArgs a
     pn = trs_group_sum<G>(pn);
     const float sp = NET == TRS_NET_FM ? sigmoidf_(lin_p + 0.5f * pp) : (pp + r.ul) + r.pl;
     const float sn = NET == TRS_NET_FM ? sigmoidf_(lin_n + 0.5f * pn) : (pn + r.ul) + r.nl;
-    const float h = sn - sp + 1.0f;
-    const float act = (live && h >= 0.f) ? 1.f : 0.f;
+    float lval, dneg;
+    trs_pair_loss(a.loss, sp, sn, lval, dneg);
+    const float act = live ? dneg : 0.f;
     float gp = -act * a.inv_B, gn = act * a.inv_B;
-    if (live && lig == 0) loss_acc += fmaxf(h, 0.f);
+    if (live && lig == 0) loss_acc += lval;
     if (NET == TRS_NET_FM) {
       gp = gp * ((1.0f - sp) * sp);
       gn = gn * ((1.0f - sn) * sn);
@@ -1432,6 +1435,8 @@ extern "C" int trs_train_steps_sgd(const trs_train_args* args, void* stream) {
   a.du = du_buf_dev;
   a.inv_B = 1.0f / (float)batch;
   a.lr = lr;
+  a.loss = args->loss;
+  TRS_REQUIRE(args->loss == TRS_LOSS_HINGE || args->loss == TRS_LOSS_BPR, "trs_train_steps_sgd: bad loss kind");
   if (scratch_dev) {
     a.uown = (uint64_t*)scratch_dev;
     a.iown = a.uown + tables->n_users;
@@ -1488,6 +1493,7 @@ extern "C" int trs_train_steps_sgd(const trs_train_args* args, void* stream) {
         sa.Bt.neg_meta = (void*)(meta->neg_meta_ids + (int64_t)st * batch * tables->M);
       }
       sa.inv_B = a.inv_B;
+      sa.loss = a.loss;
       sa.loss_sum = a.loss_sum;
       const bool meta_sorted = meta->sorted_keys[0] != nullptr;
       sa.grad_rows = meta_sorted ? nullptr : meta->grad_rows;

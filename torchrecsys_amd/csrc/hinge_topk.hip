@@ -6,13 +6,15 @@ namespace {
 
 __global__ __launch_bounds__(TRS_BLOCK) void hinge_auc_kernel(const float* __restrict__ pos,
                                                              const float* __restrict__ neg, int64_t B,
-                                                             float* loss_sum, int32_t* auc_count) {
+                                                             float* loss_sum, int32_t* auc_count, int loss) {
   float L = 0.f;
   int A = 0;
   const int64_t stride = (int64_t)gridDim.x * TRS_BLOCK;
   for (int64_t t = (int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x; t < B; t += stride) {
     const float p = pos[t], n = neg[t];
-    L += fmaxf(n - p + 1.0f, 0.f);
+    float lval, dneg;
+    trs_pair_loss(loss, p, n, lval, dneg);
+    L += lval;
     A += (p > n) ? 1 : 0;
   }
   __shared__ float s_l[TRS_BLOCK / TRS_WAVE];
@@ -40,7 +42,7 @@ __global__ __launch_bounds__(TRS_BLOCK) void hinge_auc_kernel(const float* __res
 __global__ __launch_bounds__(TRS_BLOCK) void hinge_auc_batches_kernel(const float* __restrict__ pos,
                                                                      const float* __restrict__ neg, int64_t n_total,
                                                                      int64_t batch, float* loss_sums,
-                                                                     int32_t* auc_counts) {
+                                                                     int32_t* auc_counts, int loss) {
   const int64_t b = blockIdx.y;
   const int64_t t0 = b * batch, t1 = t0 + batch < n_total ? t0 + batch : n_total;
   float L = 0.f;
@@ -48,7 +50,9 @@ __global__ __launch_bounds__(TRS_BLOCK) void hinge_auc_batches_kernel(const floa
   const int64_t stride = (int64_t)gridDim.x * TRS_BLOCK;
   for (int64_t t = t0 + (int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x; t < t1; t += stride) {
     const float p = pos[t], n = neg[t];
-    L += fmaxf(n - p + 1.0f, 0.f);
+    float lval, dneg;
+    trs_pair_loss(loss, p, n, lval, dneg);
+    L += lval;
     A += (p > n) ? 1 : 0;
   }
   __shared__ float s_l[TRS_BLOCK / TRS_WAVE];
@@ -75,10 +79,12 @@ __global__ __launch_bounds__(TRS_BLOCK) void hinge_auc_batches_kernel(const floa
 __global__ __launch_bounds__(TRS_BLOCK) void hinge_backward_kernel(const float* __restrict__ pos,
                                                                   const float* __restrict__ neg, int64_t B,
                                                                   float inv_B, float* __restrict__ gpos,
-                                                                  float* __restrict__ gneg) {
+                                                                  float* __restrict__ gneg, int loss) {
   const int64_t stride = (int64_t)gridDim.x * TRS_BLOCK;
   for (int64_t t = (int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x; t < B; t += stride) {
-    const float act = (neg[t] - pos[t] + 1.0f >= 0.f) ? inv_B : 0.f;
+    float lval, dneg;
+    trs_pair_loss(loss, pos[t], neg[t], lval, dneg);
+    const float act = dneg * inv_B;
     gpos[t] = -act;
     gneg[t] = act;
   }
@@ -209,36 +215,39 @@ static int64_t pow2_at_least(int64_t n, int64_t lo) {
 }  // namespace
 
 extern "C" int trs_hinge_auc(const float* pos_dev, const float* neg_dev, int64_t B, float* loss_sum_dev,
-                             int32_t* auc_count_dev, void* stream) {
+                             int32_t* auc_count_dev, int32_t loss, void* stream) {
+  TRS_REQUIRE(loss == TRS_LOSS_HINGE || loss == TRS_LOSS_BPR, "trs_hinge_auc: bad loss kind");
   TRS_REQUIRE(B >= 0, "trs_hinge_auc: negative B");
   if (B == 0) return TRS_OK;
   TRS_REQUIRE(pos_dev && neg_dev, "trs_hinge_auc: scores are NULL");
   hipLaunchKernelGGL(hinge_auc_kernel, dim3(trs_grid(B, TRS_BLOCK * 4)), dim3(TRS_BLOCK), 0, (hipStream_t)stream,
-                     pos_dev, neg_dev, B, loss_sum_dev, auc_count_dev);
+                     pos_dev, neg_dev, B, loss_sum_dev, auc_count_dev, (int)loss);
   TRS_CHECK_LAUNCH("hinge_auc_kernel");
   return TRS_OK;
 }
 
 extern "C" int trs_hinge_auc_batches(const float* pos_dev, const float* neg_dev, int64_t n_total, int64_t batch,
-                                     float* loss_sums_dev, int32_t* auc_counts_dev, void* stream) {
+                                     float* loss_sums_dev, int32_t* auc_counts_dev, int32_t loss, void* stream) {
+  TRS_REQUIRE(loss == TRS_LOSS_HINGE || loss == TRS_LOSS_BPR, "trs_hinge_auc_batches: bad loss kind");
   TRS_REQUIRE(n_total >= 0 && batch > 0, "trs_hinge_auc_batches: bad sizes");
   if (n_total == 0) return TRS_OK;
   TRS_REQUIRE(pos_dev && neg_dev, "trs_hinge_auc_batches: scores are NULL");
   const int64_t nb = (n_total + batch - 1) / batch;
   TRS_REQUIRE(nb <= 65535, "trs_hinge_auc_batches: more than 65535 batches in one call");
   hipLaunchKernelGGL(hinge_auc_batches_kernel, dim3(trs_grid(batch, TRS_BLOCK * 4), (unsigned)nb), dim3(TRS_BLOCK), 0,
-                     (hipStream_t)stream, pos_dev, neg_dev, n_total, batch, loss_sums_dev, auc_counts_dev);
+                     (hipStream_t)stream, pos_dev, neg_dev, n_total, batch, loss_sums_dev, auc_counts_dev, (int)loss);
   TRS_CHECK_LAUNCH("hinge_auc_batches_kernel");
   return TRS_OK;
 }
 
 extern "C" int trs_hinge_backward(const float* pos_dev, const float* neg_dev, int64_t B, float inv_B,
-                                  float* gpos_dev, float* gneg_dev, void* stream) {
+                                  float* gpos_dev, float* gneg_dev, int32_t loss, void* stream) {
+  TRS_REQUIRE(loss == TRS_LOSS_HINGE || loss == TRS_LOSS_BPR, "trs_hinge_backward: bad loss kind");
   TRS_REQUIRE(B >= 0, "trs_hinge_backward: negative B");
   if (B == 0) return TRS_OK;
   TRS_REQUIRE(pos_dev && neg_dev && gpos_dev && gneg_dev, "trs_hinge_backward: NULL argument");
   hipLaunchKernelGGL(hinge_backward_kernel, dim3(trs_grid(B, TRS_BLOCK)), dim3(TRS_BLOCK), 0, (hipStream_t)stream,
-                     pos_dev, neg_dev, B, inv_B, gpos_dev, gneg_dev);
+                     pos_dev, neg_dev, B, inv_B, gpos_dev, gneg_dev, (int)loss);
   TRS_CHECK_LAUNCH("hinge_backward_kernel");
   return TRS_OK;
 }

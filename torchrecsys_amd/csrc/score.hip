@@ -63,7 +63,9 @@ extern "C" int trs_score_forward(int net, const trs_tables* tables, const trs_ba
 
 extern "C" int trs_score_fwd_bwd(int net, const trs_tables* tables, const trs_batch* batch, float inv_B,
                                  float* pos_score_dev, float* neg_score_dev, float* loss_sum_dev,
-                                 int32_t* auc_count_dev, float* grad_rows_dev, float* grad_lin_dev, void* stream) {
+                                 int32_t* auc_count_dev, float* grad_rows_dev, float* grad_lin_dev, int32_t loss,
+                                 void* stream) {
+  TRS_REQUIRE(loss == TRS_LOSS_HINGE || loss == TRS_LOSS_BPR, "trs_score_fwd_bwd: bad loss kind");
   int rc = check_tables(net, tables, "trs_score_fwd_bwd");
   if (rc) return rc;
   rc = check_batch(tables, batch, true, "trs_score_fwd_bwd");
@@ -74,6 +76,7 @@ extern "C" int trs_score_fwd_bwd(int net, const trs_tables* tables, const trs_ba
   a.T = *tables;
   a.Bt = *batch;
   a.inv_B = inv_B;
+  a.loss = loss;
   a.pos_score = pos_score_dev;
   a.neg_score = neg_score_dev;
   a.loss_sum = loss_sum_dev;

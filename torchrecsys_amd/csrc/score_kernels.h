@@ -81,6 +81,7 @@ struct ScoreArgs {
   trs_tables T;
   trs_batch Bt;
   float inv_B;
+  int loss;  // TRS_LOSS_HINGE | TRS_LOSS_BPR (MODE 1 without upstream gradients, MODE 2, meta_stage_kernel)
   float* pos_score;
   float* neg_score;
   float* loss_sum;
@@ -230,12 +231,13 @@ __global__ __launch_bounds__(TRS_BLOCK) void score_kernel(const ScoreArgs a) {
         gp = live ? a.gpos[t] : 0.f;
         gn = live ? a.gneg[t] : 0.f;
       } else {
-        const float h = sn - sp + 1.0f;  // helper/loss.py:7
-        const float act = (live && h >= 0.f) ? 1.f : 0.f;  // clamp(min=0) passes the gradient at h == 0
+        float lval, dneg;  // helper/loss.py:7 (hinge: clamp(min=0) passes the gradient at h == 0) or BPR
+        trs_pair_loss(a.loss, sp, sn, lval, dneg);
+        const float act = live ? dneg : 0.f;
         gp = -act * a.inv_B;
         gn = act * a.inv_B;
         if (live && lig == 0) {
-          loss_acc += fmaxf(h, 0.f);
+          loss_acc += lval;
           auc_acc += (sp > sn) ? 1 : 0;
         }
       }
@@ -313,10 +315,11 @@ __global__ __launch_bounds__(TRS_BLOCK) void score_kernel(const ScoreArgs a) {
       }
     }
     if (MODE == 2) {
-      const float h = sn - sp + 1.0f;
-      const float act = (live && h >= 0.f) ? 1.f : 0.f;
+      float lval, dneg;
+      trs_pair_loss(a.loss, sp, sn, lval, dneg);
+      const float act = live ? dneg : 0.f;
       float gp = -act * a.inv_B, gn = act * a.inv_B;
-      if (live && lig == 0) loss_acc += fmaxf(h, 0.f);
+      if (live && lig == 0) loss_acc += lval;
       if (NET == TRS_NET_FM) {
         gp = gp * ((1.0f - sp) * sp);
         gn = gn * ((1.0f - sn) * sn);

@@ -95,6 +95,21 @@ __host__ __device__ __forceinline__ int64_t trs_sample_one_neg(uint64_t seed, ui
   return v + (v >= pos ? 1 : 0);
 }
 
+// Pairwise loss of one triple from its two scores: its value and d/d(neg) (d/d(pos) = -d/d(neg)), before the 1/B of the
+// mean.  TRS_LOSS_HINGE: the reference's clamp(neg - pos + 1, min=0) (helper/loss.py:5-9; torch's clamp passes the
+// gradient at 0).  TRS_LOSS_BPR (BASELINE.json north_star; not in the reference): -log sigmoid(pos - neg) = softplus(neg - pos).
+__device__ __forceinline__ void trs_pair_loss(int kind, float sp, float sn, float& value, float& dneg) {
+  if (kind == TRS_LOSS_BPR) {
+    const float x = sn - sp;
+    value = fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
+    dneg = 1.0f / (1.0f + expf(-x));
+  } else {
+    const float h = sn - sp + 1.0f;
+    value = fmaxf(h, 0.f);
+    dneg = h >= 0.f ? 1.f : 0.f;
+  }
+}
+
 // Sampler with the options of trs_sampler (include/trs.h); S.max_tries == 0 means "no options" (plain sampler).
 struct TrsSampler {  // trs_sampler by value, for kernel arguments
   int k_neg, popularity, max_tries;

@@ -108,6 +108,7 @@ class SparseScorerTrainer:
         self.grad_lin = torch.empty((self.R, batch_capacity), dtype=torch.float32, device=dev)
         self.err = torch.zeros(1, dtype=torch.int32, device=dev)
         self.kernel_events = None  # bench.py: {"kernel name": [(start_event, end_event), ...]} on the launch stream
+        self.loss_id = 0  # _lib.LOSS_ID: hinge (the reference) | bpr; set by fit(loss=...)
         # specialised exact 3-kernel SGD step (csrc/fast_step.hip): no metadata, plain SGD with one learning rate
         self.fast_lr = None
         self.fast_kind = None  # "sgd": C step loop on every path; "sparse_adam" / "adagrad": on the presorted path only
@@ -198,7 +199,7 @@ class SparseScorerTrainer:
             st["ui"] = ops.interleave_stream(st["user"], st["pos"])
         ops.train_steps_sgd(self.net.NET, self.net.tables(), st["ui"], st["neg"], shuffle_key,
                             sample_seed, first_pos, batch, n_steps, self.fast_lr, *self.id_bufs, self.gz, self.du,
-                            loss_sums, self.err, self.scratch, self._stamps(n_steps), evs)
+                            loss_sums, self.err, self.scratch, self._stamps(n_steps), evs, loss=self.loss_id)
         if te is not None:
             self._collect_events(te, ns)
 
@@ -331,7 +332,7 @@ class SparseScorerTrainer:
             ids, udup, idup = ps.step_args(b_in_slice)
             ops.train_steps_sgd(self.net.NET, self.net.tables(), None, None, 0, 0, 0, batch, n_steps, self.fast_lr, *ids,
                                 self.gz, self.du, loss_sums, self.err, self.scratch, self._stamps(n_steps), evs,
-                                user_dup=udup, item_dup=idup, ustage=self.ustage)
+                                user_dup=udup, item_dup=idup, ustage=self.ustage, loss=self.loss_id)
             if te is not None:
                 self._collect_events(te, ns, ("fwd_stage_kernel", "flagged_update_kernel", "event_overhead"))
             return
@@ -344,7 +345,7 @@ class SparseScorerTrainer:
                 if self.M > 0 else None)
         ops.train_steps_sgd(self.net.NET, self.net.tables(), None, None, 0, 0, 0, batch, n_steps, self.fast_lr, *ids,
                             self.gz, self.du, loss_sums, self.err, self.scratch, self._stamps(n_steps), evs, sk, sv,
-                            ps.key_bytes, udup, self.ustage, usorted, opt, meta, idup)
+                            ps.key_bytes, udup, self.ustage, usorted, opt, meta, idup, loss=self.loss_id)
         if te is not None:
             # 32-bit keys: item and duplicated-user updates are ONE launch, and the last two events are recorded back to
             # back — that interval is the cost of an event record itself
@@ -409,7 +410,7 @@ class SparseScorerTrainer:
         e = first + n_steps * batch
         ops.train_steps_sgd(self.net.NET, self.net.tables(), None, None, 0, 0, 0, batch, n_steps, self.fast_lr,
                             ep["user"][first:e], ep["pos"][first:e], ep["neg"][first:e], self.gz, self.du, loss_sums,
-                            self.err, self.scratch, self._stamps(n_steps), evs)
+                            self.err, self.scratch, self._stamps(n_steps), evs, loss=self.loss_id)
         if te is not None:
             self._collect_events(te, ns)
 
@@ -422,7 +423,7 @@ class SparseScorerTrainer:
             te, evs, ns = self._make_events(1) if self.kernel_events is not None else (None, None, 0)
             ops.train_steps_sgd(net.NET, net.tables(), None, None, 0, 0, 0, B, 1, self.fast_lr, ids["user"],
                                 ids["pos"], ids["neg"], self.gz, self.du, loss_slot, self.err, self.scratch,
-                                self._stamps(1), evs)
+                                self._stamps(1), evs, loss=self.loss_id)
             if te is not None:
                 self._collect_events(te, ns)
             return
@@ -435,7 +436,7 @@ class SparseScorerTrainer:
             e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
             e0.record()
         ops.score_fwd_bwd(net.NET, T, Bt, B, self.D, self.M, self.dev, loss_slot, auc_slot, want_scores=False,
-                          grad_rows=gr, grad_lin=gl)
+                          grad_rows=gr, grad_lin=gl, loss=self.loss_id)
         if ev is not None:
             e1.record()
         if self.kind == "sgd":

@@ -306,6 +306,7 @@ class MLPTrainer:
         self.err = net._err_flag()
         self.row_state = {id(p): RowState(p) for p in self.emb_params} if self.kind in ("sparse_adam", "adagrad") else {}
         self.kernel_events = None
+        self.loss_id = 0  # _lib.LOSS_ID: hinge (the reference) | bpr; set by fit(loss=...)
 
     def step(self, ids, loss_slot, auc_slot=None):
         net, opt = self.net, self.opt
@@ -313,8 +314,8 @@ class MLPTrainer:
         D, M = net.n_factors, net.n_meta_tables()
         scores, ctx = net.compute.forward(ids, 2, True)
         pos, neg = scores[:B], scores[B:]
-        ops.hinge_auc(pos, neg, loss_slot, auc_slot)
-        gp, gn = ops.hinge_backward(pos, neg)
+        ops.hinge_auc(pos, neg, loss_slot, auc_slot, loss=self.loss_id)
+        gp, gn = ops.hinge_backward(pos, neg, loss=self.loss_id)
         g = torch.cat([gp, gn])
         # ---- dense parameters under data parallelism: RCCL all-reduce per layer, started as the backward produces the
         # layer's gradients (it runs on the collective stream beside the remaining backward GEMMs and the embedding-row

@@ -315,7 +315,7 @@ class TorchRecSys(torch.nn.Module):
 
     @_host_side
     def fit(self, optimizer, epochs=10, batch_size=512, profile_epochs: int = 0, sync_tables_every: int = 1,
-            sync_bn: bool = False):
+            sync_bn: bool = False, loss: str = 'hinge'):
         """Fits the model (reference model.py:203-288).  Per step: [shuffle slice + negative sampling] -> fused
         gather + scoring + hinge + backward -> sparse-row optimiser update; the loss stays on the device and is
         read back once per epoch (the reference syncs every step, model.py:200).
@@ -334,7 +334,14 @@ class TorchRecSys(torch.nn.Module):
         The printed loss is the mean over ranks."""
         if self.net_type == 'mlp':
             self.net.compute.sync_bn = bool(sync_bn)
+        # loss: 'hinge' = the reference's only loss (helper/loss.py:5-9, model.py:282); 'bpr' = -log sigmoid(pos - neg),
+        # the alternative BASELINE.json's north_star names (evaluate() then reports that loss too)
+        from ._lib import LOSS_ID
+        if loss not in LOSS_ID:
+            raise ValueError(f"loss must be one of {sorted(LOSS_ID)}")
+        self.loss = loss
         runner = self.make_runner(optimizer, batch_size)
+        runner.trainer.loss_id = LOSS_ID[loss]
         for epoch in range(epochs):
             self.net = self.net.train()
             prof = None
@@ -419,7 +426,9 @@ class TorchRecSys(torch.nn.Module):
                 ids = ops.batch_prepare(st['user'], st['pos'], st['neg'], 0, s, e - s, self.n_items, sample_seed, s,
                                         st['item_meta'], sampler=self._eval_sampler())
             pos, neg = self.net.score_ids(ids)
-            ops.hinge_auc_batches(pos, neg, batch_size, loss_sums[b0:b1], auc_counts[b0:b1])
+            from ._lib import LOSS_ID
+            ops.hinge_auc_batches(pos, neg, batch_size, loss_sums[b0:b1], auc_counts[b0:b1],
+                                  loss=LOSS_ID[getattr(self, "loss", "hinge")])
         ls, ac = loss_sums.cpu().numpy(), auc_counts.cpu().numpy()
         sizes = [min((b + 1) * batch_size, n_test) - b * batch_size for b in range(nb)]
         results = {}

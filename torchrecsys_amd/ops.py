@@ -93,7 +93,7 @@ def score_forward(net, T, Bt, B, device, want_neg=True):
 
 
 def score_fwd_bwd(net, T, Bt, B, D, M, device, loss_sum, auc_count=None, want_scores=True, grad_rows=None,
-                  grad_lin=None):
+                  grad_lin=None, loss=0):
     """Returns (pos, neg, grad_rows (R,B,D), grad_lin (R,B)); loss_sum/auc_count are accumulated in place."""
     lib = _lib.load()
     R = 3 + 2 * M
@@ -105,7 +105,8 @@ def score_fwd_bwd(net, T, Bt, B, D, M, device, loss_sum, auc_count=None, want_sc
         grad_lin = torch.empty((R, B), dtype=torch.float32, device=device)
     inv_B = 1.0 / B if B > 0 else 0.0
     check(lib.trs_score_fwd_bwd(NET_ID[net], C.byref(T), C.byref(Bt), inv_B, ptr(pos), ptr(neg), ptr(loss_sum),
-                                ptr(auc_count), ptr(grad_rows), ptr(grad_lin), _stream()), "trs_score_fwd_bwd")
+                                ptr(auc_count), ptr(grad_rows), ptr(grad_lin), int(loss), _stream()),
+          "trs_score_fwd_bwd")
     return pos, neg, grad_rows, grad_lin
 
 
@@ -326,7 +327,7 @@ class EpochFlags:
 def train_steps_sgd(net, T, stream_ui, neg_static, shuffle_key, sample_seed, first_pos, batch, n_steps,
                     lr, user_buf, pos_buf, neg_buf, gz_buf, du_buf, loss_sums, err_flag, scratch=None, first_stamp=1,
                     events=None, sorted_keys=None, sorted_vals=None, key_bytes=0, user_dup=None, ustage=None,
-                    user_sorted=None, opt=None, meta=None, item_dup=None):
+                    user_sorted=None, opt=None, meta=None, item_dup=None, loss=0):
     """n_steps fused steps driven from C (trs_train_steps_sgd).  stream_ui None: the steps' ids are already in
     user/pos/neg_buf.  events: optional flat list of 4*n_steps raw hipEvent_t handles.  opt: None (SGD with lr) or a
     _lib.TrsOpt (SparseAdam / Adagrad on the presorted path; keep the tensors it points to alive).  item_dup: the
@@ -335,6 +336,7 @@ def train_steps_sgd(net, T, stream_ui, neg_static, shuffle_key, sample_seed, fir
     a = _lib.TrsTrainArgs()
     a.net, a.n_steps, a.tables, a.batch, a.lr = NET_ID[net], int(n_steps), C.pointer(T), int(batch), float(lr)
     a.first_stamp = int(first_stamp)
+    a.loss = int(loss)
     a.stream_ui_dev, a.neg_static_dev = ptr(stream_ui), ptr(neg_static)
     a.N = 0 if stream_ui is None else stream_ui.shape[0]
     a.shuffle_key, a.sample_seed, a.first_pos = int(shuffle_key), int(sample_seed), int(first_pos)
@@ -380,22 +382,23 @@ def rows_apply_adagrad(table, acc, state_sum, stamp, idx, step_id, clr, eps):
                                              float(clr), float(eps), _stream()), "trs_rows_apply_adagrad")
 
 
-def hinge_auc(pos, neg, loss_sum, auc_count):
-    check(_lib.load().trs_hinge_auc(ptr(pos), ptr(neg), pos.numel(), ptr(loss_sum), ptr(auc_count), _stream()),
-          "trs_hinge_auc")
+def hinge_auc(pos, neg, loss_sum, auc_count, loss=0):
+    """loss: 0 = hinge (the reference), 1 = BPR (_lib.LOSS_ID)."""
+    check(_lib.load().trs_hinge_auc(ptr(pos), ptr(neg), pos.numel(), ptr(loss_sum), ptr(auc_count), int(loss),
+                                    _stream()), "trs_hinge_auc")
 
 
-def hinge_auc_batches(pos, neg, batch, loss_sums, auc_counts):
+def hinge_auc_batches(pos, neg, batch, loss_sums, auc_counts, loss=0):
     """Per-batch hinge sums / AUC counts of consecutive `batch`-row pieces of pos / neg into loss_sums[b], auc_counts[b]."""
     check(_lib.load().trs_hinge_auc_batches(ptr(pos), ptr(neg), pos.numel(), batch, ptr(loss_sums), ptr(auc_counts),
-                                            _stream()), "trs_hinge_auc_batches")
+                                            int(loss), _stream()), "trs_hinge_auc_batches")
 
 
-def hinge_backward(pos, neg):
+def hinge_backward(pos, neg, loss=0):
     B = pos.numel()
     gp, gn = torch.empty_like(pos), torch.empty_like(neg)
-    check(_lib.load().trs_hinge_backward(ptr(pos), ptr(neg), B, 1.0 / B if B else 0.0, ptr(gp), ptr(gn), _stream()),
-          "trs_hinge_backward")
+    check(_lib.load().trs_hinge_backward(ptr(pos), ptr(neg), B, 1.0 / B if B else 0.0, ptr(gp), ptr(gn), int(loss),
+                                         _stream()), "trs_hinge_backward")
     return gp, gn
 
 
