@@ -196,12 +196,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU fallback)"
+    # (rehearsal on a one-GPU box: TRS_BENCH_SHARE_DEVICE=1 puts every rank on the devices that exist and
+    # TRS_DIST_BACKEND=gloo moves the few collectives through the host; a real node runs one rank per GPU over RCCL)
+    if os.environ.get("TRS_BENCH_SHARE_DEVICE") == "1":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        backend = os.environ.get("TRS_DIST_BACKEND", "nccl")  # "nccl" IS RCCL over xGMI on ROCm
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     from torchrecsys_amd import _lib
     from torchrecsys_amd.model import TorchRecSys

@@ -153,3 +153,28 @@ def test_two_rank_sync_batchnorm_equals_one_process():
     ret = mgr.dict()
     mp.spawn(_sync_bn_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """The driver's multi-GPU command line (torch.distributed.run, one rank per GPU, bench.py --gpus N) rehearsed with two
+    ranks sharing this box's GPU and gloo carrying the collectives: rank 0 prints ONE JSON line for the default (c4)
+    workload with n_gpus = 2, the whole-job value, weak scaling, and the replica-synchronisation costs fit() adds."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TRS_BENCH_SHARE_DEVICE="1", TRS_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "24",
+           "--warmup", "8"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 24 and d["scaling"] == "weak" and "c4" in d["config"]["workload"]
+    assert d["config"]["global_batch"] == 2 * d["config"]["per_gpu_batch"] == 65_536
+    assert d["value"] == pytest.approx(2 * 65_536 * 24 / (d["ms_per_step"] * 24 * 1e-3), rel=1e-6)
+    rs = d["replica_sync"]
+    assert rs["averaged_bytes"] == 4 * (1_000_000 * 128 + 1_000_000) and rs["per_epoch_average_ms"] > 0
+    assert "cpu_baseline" not in d  # rank 0 at N = 1 only
