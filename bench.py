@@ -130,13 +130,20 @@ def time_pass(model, runner, B, D, R, dev):
     per = 16 + R * (4 * D + 4) + 8  # ids, R rows + 1-wide terms, two scores out
     res = {"kernel": "pair_scores_kernel", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "algorithmic_bytes_per_triple": per, "shapes": {}}
-    groups, per_group = 8, 10
     g = torch.Generator(device=dev)
     g.manual_seed(99)
-    for Bp in sorted({B, 262_144}):
+    # (triples per launch, label, event groups, launches per group): the per-GPU batch as ONE launch, BASELINE's global
+    # batch, and the per-GPU batch the way evaluate() issues the pass — up to 64 batches per launch (model.py::evaluate)
+    ev_group = max(1, min(64, (1 << 22) // B))
+    shapes = [(B, f"B={B}", 8, 10), (262_144, "B=262144", 8, 10)]
+    if ev_group > 1 and B * ev_group != 262_144:
+        shapes.append((B * ev_group, f"B={B} x {ev_group} batches per launch (evaluate)", 4, 3))
+    seen_bp = set()
+    for Bp, label, groups, per_group in shapes:
         need = (groups * per_group + 3) * Bp
-        if need > st["user"].shape[0]:
+        if need > st["user"].shape[0] or Bp in seen_bp:
             continue
+        seen_bp.add(Bp)
         neg = torch.randint(0, n_items, (need,), device=dev, dtype=torch.int32, generator=g)
         import ctypes as C
         from torchrecsys_amd import _lib, ops
@@ -164,7 +171,7 @@ def time_pass(model, runner, B, D, R, dev):
         us = [1e3 * e0.elapsed_time(e1) / per_group for e0, e1 in evs]
         mean_us = sum(us) / len(us)
         ach = per * Bp / (mean_us * 1e-6) / 1e9
-        res["shapes"][f"B={Bp}"] = {"mean_launch_us": mean_us, "min_group_us": min(us), "max_group_us": max(us),
+        res["shapes"][label] = {"mean_launch_us": mean_us, "triples_per_launch": Bp, "min_group_us": min(us), "max_group_us": max(us),
                                     "achieved": ach, "frac": ach / HBM_PEAK_GBS, "samples": groups,
                                     "launches": groups * per_group}
         assert int(err.item()) == 0, "an id outside its table in the pass measurement"

@@ -852,18 +852,25 @@ def test_presorted_adaptive_rules_match_the_oracle(net, D, skew, kind):
 
 @pytest.mark.parametrize("net,D,M,skew", [("fm", 64, 1, False), ("fm", 16, 3, True), ("linear", 32, 1, True),
                                           ("linear", 8, 2, False), ("fm", 10, 1, True)])
-@pytest.mark.parametrize("meta_sorted,B", [(False, 512), (True, 512), (True, 509), (True, 3)])
+@pytest.mark.parametrize("meta_sorted,B", [(False, 512), (True, 512), (True, 509), (True, 3), ("hot", 2048)])
 def test_presorted_step_with_metadata_matches_oracle(net, D, M, skew, meta_sorted, B):
     """Metadata scorers on the presorted step (SGD): K1 = the scorer's staging mode (ids from the item -> metadata
     table, user update in place, FM: per-pass field sums staged), user / item rows through the sorted runs (FM: w +=
-    sum(c*S) - sum(c)*w), metadata tables through the atomic scatter of the staged fields: 3 batches == oracle steps."""
+    sum(c*S) - sum(c)*w), metadata tables through the atomic scatter of the staged fields: 3 batches == oracle steps.
+    "hot": 90 % of the items carry category 0 of the first column, batch 2048, a ten times larger step — that row's run
+    is ~3 700 references long and is cut into ~58 pieces of 64; FM's pieces subtract sum(c)*w with the w they loaded,
+    which other pieces may already have touched (second order in the step size): held to the same 1e-5."""
     from torchrecsys_amd import _lib
     ops = _ops()
     rs = np.random.RandomState(D + M + skew)
     NU, NI, nb, lr = 300, 57, 3, 0.05
+    hot = meta_sorted == "hot"
     p, _, _ = make_case(net, D, M, 8, NU=NU, NI=NI, seed=2)
     sizes = [p[f"metadata.{m}.weight"].shape[0] for m in range(M)]
     item_meta = np.stack([rs.randint(0, sizes[m], NI) for m in range(M)], axis=1).astype(np.int32)
+    if hot:
+        item_meta[rs.rand(NI) < 0.9, 0] = 0
+        lr = 0.5
     u, i, j = rs.randint(0, NU, nb * B), rs.randint(0, NI, nb * B), rs.randint(0, NI, nb * B)
     if skew:
         i[rs.rand(nb * B) < 0.4] = 7
