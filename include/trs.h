@@ -328,6 +328,11 @@ int trs_epoch_flags(const int32_t* stream_ui_dev, const int32_t* neg_static_dev,
                     int64_t n_items, int32_t* user_dev, int32_t* pos_dev, int32_t* neg_dev,
                     uint8_t* user_dup_flags_out_dev, uint8_t* item_dup_flags_out_dev, int32_t* err_flag_dev,
                     const trs_sampler* sampler, void* stream);
+/* User-duplicate flags alone, by the same LDS bitmap (no sort; conservative for n_users > 2^20).  Plain SGD without
+ * metadata needs nothing else about the users: pass the flags to trs_train_steps_sgd with sorted_ukeys_dev = NULL and the
+ * flagged users add their staged gradient rows with float atomics in the sorted-run launch. */
+int trs_epoch_user_flags(const int32_t* user_dev, int64_t n_batches, int64_t batch, int64_t n_users,
+                         uint8_t* flags_out_dev, void* stream);
 int trs_epoch_user_dups_sizes(int64_t n_batches, int64_t batch, int64_t n_users, int64_t* ukeys_bytes_out,
                               int64_t* uvals_bytes_out, int64_t* temp_bytes_out);
 int trs_epoch_user_dups(const int32_t* user_dev, int64_t n_batches, int64_t batch, int64_t n_users, void* ukeys_dev,

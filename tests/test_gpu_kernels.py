@@ -720,12 +720,14 @@ def test_flag_mode_matches_oracle(net, D, skew, n_users):
 
 @pytest.mark.parametrize("net,D,skew", [("fm", 64, False), ("fm", 64, True), ("fm", 16, True), ("linear", 32, True),
                                         ("fm", 80, False), ("fm", 10, True)])
-@pytest.mark.parametrize("inline_user", [False, True, "items"])
+@pytest.mark.parametrize("inline_user", [False, True, "items", "userflags"])
 def test_presorted_item_update_matches_oracle(net, D, skew, inline_user):
     """trs_epoch_presort + the atomic-free per-run item update: 3 batches in one C call == oracle SGD steps.
     `skew`: one hot item takes 40 % of the references (runs cut at 64, pieces added atomically).
     inline_user "items": K1 also updates the item rows referenced once in the batch (item-duplicate flags) and the
-    sorted runs only walk rows with several references."""
+    sorted runs only walk rows with several references.  "userflags": no user sort — user duplicates as flags of the
+    LDS-bitmap kernel, the flagged users' gradients added with float atomics in the sorted-run launch (the dense regime's
+    plain-SGD step)."""
     ops = _ops()
     rs = np.random.RandomState(D + skew)
     NU, NI, B, nb, lr = 300, 57, 512, 3, 0.05
@@ -740,10 +742,11 @@ def test_presorted_item_update_matches_oracle(net, D, skew, inline_user):
     t = {k: torch.from_numpy(v.copy()).to(DEV) for k, v in p.items()}
     T, keep = ops.make_tables(t["user.weight"], t["item.weight"], t[lin[0]], t[lin[1]])
     err = torch.zeros(1, dtype=torch.int32, device=DEV)
-    ps = ops.EpochPresort(nb, B, NU, NI, DEV)
+    ps = ops.EpochPresort(nb, B, NU, NI, DEV, user_sort=inline_user != "userflags")
     given = [torch.from_numpy(a.astype(np.int32)).to(DEV) for a in (u, i, j)]
     ps.run(None, None, 0, 0, 0, err, given_ids=given)
     ids, sk, sv, udup, usorted, idup = ps.step_args(0)
+    assert (usorted[0] is None) == (inline_user == "userflags")
     gz, du = torch.empty((2, B), device=DEV), torch.empty((B, D), device=DEV)
     losses = torch.zeros(nb, device=DEV)
     # user-duplicate flags of the slice == "another triple of the same batch has this user"

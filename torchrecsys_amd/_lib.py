@@ -129,6 +129,7 @@ PROTOTYPES = {
                                          C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp, _vp, _vp]),
     "trs_epoch_flags": (C.c_int, [_vp, _vp, _i64, _u64, _u64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
                                   C.POINTER(TrsSampler), _vp]),
+    "trs_epoch_user_flags": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "trs_epoch_user_dups_sizes": (C.c_int, [_i64, _i64, _i64, c_int64_p, c_int64_p, c_int64_p]),
     "trs_epoch_user_dups": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, C.POINTER(C.c_void_p),
                                       C.POINTER(C.c_void_p), c_int32_p, _vp]),

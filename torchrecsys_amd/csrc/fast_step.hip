@@ -1266,7 +1266,7 @@ int trs_launch_sorted_updates_fused(const trs_tables* tables, const void* keys_s
                                     int64_t batch, int64_t item_bits, const float* gz, float lr, const float* ustage,
                                     const void* ukeys_step, const void* uvals_step, int64_t q0, const float* du,
                                     const OptArgs* opt, int parity, int64_t xpass, int fmsub, int skip_single,
-                                    hipStream_t s);
+                                    const uint8_t* uflags_step, const int32_t* user_ids_step, hipStream_t s);
 int trs_launch_sorted_meta_update(const trs_tables* tables, int m, float* lin_or_scratch, const void* keys_step,
                                   const void* vals_step, int64_t batch, const float* gz, float lr, const float* xstage,
                                   int64_t xpass, int fmsub, const OptArgs* opt, int parity, hipStream_t s);
@@ -1358,8 +1358,10 @@ extern "C" int trs_train_steps_sgd(const trs_train_args* args, void* stream) {
   if (sorted) {
     TRS_REQUIRE(!from_stream && scratch_dev && sorted_vals_dev && (key_bytes == 4 || key_bytes == 8),
                 "trs_train_steps_sgd: the presorted mode needs the epoch's id arrays, scratch and sorted references");
-    TRS_REQUIRE(!inl || (ustage_buf_dev && sorted_ukeys_dev && sorted_uvals_dev && (ukey_bytes == 4 || ukey_bytes == 8)),
-                "trs_train_steps_sgd: user-duplicate flags need the staging buffer and the slice's sorted (batch,user) pairs");
+    TRS_REQUIRE(!inl || (ustage_buf_dev && ((sorted_ukeys_dev && sorted_uvals_dev && (ukey_bytes == 4 || ukey_bytes == 8)) ||
+                                            (!sorted_ukeys_dev && !(opt && opt->kind != TRS_OPT_SGD) && !meta && key_bytes == 4))),
+                "trs_train_steps_sgd: user-duplicate flags need the staging buffer and the slice's sorted (batch,user) "
+                "pairs (plain SGD without metadata may omit the pairs: flagged users then take float atomics)");
   }
   const bool adaptive = opt && opt->kind != TRS_OPT_SGD;
   // K1 takes the item references that are alone on their row: plain SGD without metadata on the fused two-launch step
@@ -1370,7 +1372,8 @@ extern "C" int trs_train_steps_sgd(const trs_train_args* args, void* stream) {
     TRS_REQUIRE(!from_stream && !adaptive && !meta && ustage_buf_dev,
                 "trs_train_steps_sgd: the flag mode takes given ids, both flag arrays and the (batch,D) staging buffer "
                 "(plain SGD, no metadata, no sorted references)");
-  const bool item_inl = args->item_dup_flags_dev && inl && !adaptive && !meta && key_bytes == 4 && ukey_bytes == 4;
+  const bool item_inl = args->item_dup_flags_dev && inl && !adaptive && !meta && key_bytes == 4 &&
+                        (ukey_bytes == 4 || !sorted_ukeys_dev);
   TRS_REQUIRE(!args->item_dup_flags_dev || item_inl || flgm,
               "trs_train_steps_sgd: item-duplicate flags need the presorted plain-SGD step without metadata");
   if (meta) {
@@ -1529,15 +1532,15 @@ extern "C" int trs_train_steps_sgd(const trs_train_args* args, void* stream) {
     if (sorted) {  // K2: per-run owner update from the presorted references, then K3
       const char* ks = (const char*)sorted_keys_dev + (int64_t)st * 2 * batch * key_bytes;
       const char* vs = (const char*)sorted_vals_dev + (int64_t)st * 2 * batch * 4;
-      if (inl && key_bytes == 4 && ukey_bytes == 4) {  // item + duplicated-user updates in one launch
-        const char* uk = (const char*)sorted_ukeys_dev + (int64_t)st * batch * 4;
-        const char* uv = (const char*)sorted_uvals_dev + (int64_t)st * batch * 4;
+      if (inl && key_bytes == 4 && (ukey_bytes == 4 || !sorted_ukeys_dev)) {  // item + duplicated-user updates in one launch
+        const char* uk = sorted_ukeys_dev ? (const char*)sorted_ukeys_dev + (int64_t)st * batch * 4 : nullptr;
+        const char* uv = sorted_ukeys_dev ? (const char*)sorted_uvals_dev + (int64_t)st * batch * 4 : nullptr;
         const bool fm_meta = meta && net == TRS_NET_FM;
         rc = trs_launch_sorted_updates_fused(tables, ks, vs, batch, item_bits, a.gz, a.lr,
                                              meta ? meta->xstage : a.ustage, uk, uv,
                                              slice_pos0 + (int64_t)st * batch, a.du, adaptive ? &a.o : nullptr,
                                              (int)(a.stamp & 1u), fm_meta ? batch : 0, fm_meta ? 1 : 0,
-                                             item_inl ? 1 : 0, s);
+                                             item_inl ? 1 : 0, a.udup_pos, a.user, s);
         if (rc) return rc;
         if (meta && meta->sorted_keys[0]) {  // one sorted-run launch per metadata column
           for (int m = 0; m < tables->M; ++m) {

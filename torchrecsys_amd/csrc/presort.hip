@@ -147,6 +147,7 @@ struct FlagArgs {
   int32_t* err;
   int log2_bits;              // bitmap size
   int item_hash, user_hash;   // 0: row id = bit (table fits the bitmap), 1: hashed
+  int what_first, what_end;   // tables flagged: [0, 2) items then users; [1, 2) users only (the dense regime sorts its items)
 };
 
 constexpr int FLAG_THREADS = 1024;
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(FLAG_THREADS) void batch_flags_kernel(const FlagArg
     }
   }
   // ---- item references, then users: phases A / B / C over the same LDS bitmap
-  for (int what = 0; what < 2; ++what) {
+  for (int what = a.what_first; what < a.what_end; ++what) {
     const int hashed = what == 0 ? a.item_hash : a.user_hash;
     const int32_t* ida = what == 0 ? a.pos : a.user;
     uint64_t lat0 = 0, lat1 = 0;  // bit rd * FLAG_U + k: the first / second id of triple (round rd, k) came later
@@ -630,7 +631,40 @@ struct UserDupArgs {
   const float* gz;        // (2,B)
   float lr;
   OptArgs o;              // update rule (OPT_SGD: lr above)
+  // ukeys == NULL (plain SGD): no sorted user runs — the flagged users (conservative flags of the LDS-bitmap kernel) add
+  // their staged gradient rows into the table with float atomics (flagged_user_update_body)
+  const uint8_t* uflags;    // this step's B user-duplicate flags
+  const int32_t* user_ids;  // this step's B user ids
 };
+
+// Plain SGD without a user sort: one lane per position of the batch finds the flagged users; the wave then adds their
+// staged gradient rows, user[u] += -lr * du[t] (+ the 1-wide term), a row = adjacent dwords per atomic instruction.  Every
+// read of the step happened in K1, so this is exact up to the order of the sums on shared rows.  c2: 6 % of the users.
+__device__ __forceinline__ void flagged_user_update_body(const UserDupArgs& a, int block_id, int n_blocks) {
+  const trs_tables& T = a.T;
+  const int D = T.D;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)block_id * TRS_BLOCK + threadIdx.x) >> 6;
+  const int64_t nwave = ((int64_t)n_blocks * TRS_BLOCK) >> 6;
+  for (int64_t base = wave * TRS_WAVE; base < a.B; base += nwave * TRS_WAVE) {
+    const int64_t t = base + lane;
+    const bool valid = t < a.B;
+    const int64_t tc = valid ? t : a.B - 1;
+    const int32_t u = a.user_ids[tc];
+    const float clin = -a.lr * (a.gz[tc] + a.gz[a.B + tc]);
+    uint64_t mask = __ballot(valid && a.uflags[tc] != 0);
+    while (mask) {
+      const int l = __ffsll((unsigned long long)mask) - 1;
+      mask &= mask - 1;
+      const int64_t tk = base + l, uk = __shfl(u, l, 64);
+      const float cl = __shfl(clin, l, 64);
+      const float* src = a.du + tk * (int64_t)D;
+      float* dst = T.user + uk * (int64_t)D;
+      for (int e = lane; e < D; e += TRS_WAVE) atomicAdd(dst + e, -a.lr * src[e]);
+      if (lane == 0) atomicAdd(T.user_lin + uk, cl);
+    }
+  }
+}
 
 template <typename KeyT, int VEC, int G, int K, bool FULL, int OPT = OPT_SGD>
 __device__ __forceinline__ void sorted_user_dup_update_body(const UserDupArgs& a, int block_id, int n_blocks) {
@@ -803,9 +837,10 @@ __global__ __launch_bounds__(TRS_BLOCK)
 __attribute__((amdgpu_waves_per_eu(OPT == OPT_SGD && VEC == 4 && K == 1 && FULL ? K2_WAVES : 1)))
 void sorted_updates_fused_kernel(const SortedArgs ia, const UserDupArgs ua,
                                                                         int n_user_blocks) {
-  if ((int)blockIdx.x < n_user_blocks)
-    sorted_user_dup_update_body<uint32_t, VEC, G, K, FULL, OPT>(ua, blockIdx.x, n_user_blocks);
-  else
+  if ((int)blockIdx.x < n_user_blocks) {
+    if (OPT == OPT_SGD && ua.ukeys == nullptr) flagged_user_update_body(ua, blockIdx.x, n_user_blocks);
+    else sorted_user_dup_update_body<uint32_t, VEC, G, K, FULL, OPT>(ua, blockIdx.x, n_user_blocks);
+  } else
     sorted_item_update_staged_body<uint32_t, VEC, G, K, FULL, OPT>(ia, (int)blockIdx.x - n_user_blocks,
                                                                    (int)gridDim.x - n_user_blocks);
 }
@@ -961,6 +996,8 @@ extern "C" int trs_epoch_flags(const int32_t* stream_ui_dev, const int32_t* neg_
   a.log2_bits = lb;
   a.item_hash = n_items > ((int64_t)1 << lb) ? 1 : 0;
   a.user_hash = n_users > ((int64_t)1 << lb) ? 1 : 0;
+  a.what_first = 0;
+  a.what_end = 2;
   const size_t lds = ((size_t)1 << lb) / 8;
   int src = !stream_ui_dev ? 0 : (neg_static_dev ? 2 : 1);
   hipStream_t s = (hipStream_t)stream;
@@ -995,6 +1032,39 @@ extern "C" int trs_epoch_flags(const int32_t* stream_ui_dev, const int32_t* neg_
   }
   if (src == 0) TRS_FL(0) else if (src == 1) TRS_FL(1) else TRS_FL(2)
 #undef TRS_FL
+  TRS_CHECK_LAUNCH("batch_flags_kernel");
+  return TRS_OK;
+}
+
+// User-duplicate flags alone (conservative when n_users exceeds the bitmap): the dense regime's plain-SGD step needs no
+// sorted user runs (flagged users add their staged gradient with float atomics), so the second segmented sort of the
+// slice is replaced by the bitmap kernel restricted to the user ids.
+extern "C" int trs_epoch_user_flags(const int32_t* user_dev, int64_t n_batches, int64_t batch, int64_t n_users,
+                                    uint8_t* flags_out_dev, void* stream) {
+  TRS_REQUIRE(user_dev && flags_out_dev && n_batches > 0 && batch > 0 && n_users > 0 && n_users < ((int64_t)1 << 31),
+              "trs_epoch_user_flags: bad arguments");
+  TRS_REQUIRE(batch <= (int64_t)FLAG_THREADS * FLAG_U * FLAG_MAX_ROUNDS, "trs_epoch_user_flags: batch %lld exceeds %d",
+              (long long)batch, FLAG_THREADS * FLAG_U * FLAG_MAX_ROUNDS);
+  FlagArgs a = {};
+  a.batch = batch;
+  a.n_users = n_users;
+  a.n_items = n_users;  // (pos / neg alias the user ids below: they must pass the id check, nothing is written back)
+  a.user = const_cast<int32_t*>(user_dev);  // SRC 0 with valid ids: read only
+  a.pos = a.neg = a.user;
+  a.uflags = flags_out_dev;
+  int lb = 10;
+  while (lb < 20 && ((int64_t)1 << lb) < n_users) ++lb;
+  a.log2_bits = lb;
+  a.user_hash = n_users > ((int64_t)1 << lb) ? 1 : 0;
+  a.what_first = 1;
+  a.what_end = 2;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)batch_flags_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((batch_flags_kernel<0>), dim3((unsigned)n_batches), dim3(FLAG_THREADS), ((size_t)1 << lb) / 8,
+                     (hipStream_t)stream, a);
   TRS_CHECK_LAUNCH("batch_flags_kernel");
   return TRS_OK;
 }
@@ -1260,7 +1330,7 @@ int trs_launch_sorted_updates_fused(const trs_tables* tables, const void* keys_s
                                     int64_t batch, int64_t item_bits, const float* gz, float lr, const float* ustage,
                                     const void* ukeys_step, const void* uvals_step, int64_t q0, const float* du,
                                     const OptArgs* opt, int parity, int64_t xpass, int fmsub, int skip_single,
-                                    hipStream_t s) {
+                                    const uint8_t* uflags_step, const int32_t* user_ids_step, hipStream_t s) {
   SortedArgs ia = {};
   ia.skip_single = skip_single;
   ia.T = *tables;
@@ -1281,6 +1351,8 @@ int trs_launch_sorted_updates_fused(const trs_tables* tables, const void* keys_s
   ua.du = du;
   ua.gz = gz;
   ua.lr = lr;
+  ua.uflags = uflags_step;
+  ua.user_ids = user_ids_step;
   const int kind = opt ? opt->kind : OPT_SGD;
   if (opt) {
     ia.o = *opt;

@@ -248,8 +248,13 @@ class SparseScorerTrainer:
             meta_kw = {}
             if self.M > 0 and os.environ.get("TRS_META_SORTED", "1") != "0":  # knob: 0 = atomic scatter of staged fields
                 meta_kw = dict(item_meta=self.item_meta, n_meta=[p.shape[0] for p in self.params[4:4 + self.M]])
+            # plain SGD without metadata needs the users' duplicate FLAGS only (flagged users add their gradient with float
+            # atomics); the adaptive rules and the metadata scorers coalesce duplicated users through sorted runs
+            user_sort = not (self.fast_kind == "sgd" and self.M == 0) or os.environ.get("TRS_USER_SORT") == "1"
             ps = sets[i] = ops.EpochPresort(max(n_batches, min(self.SLICE_BATCHES, n_batches)), batch,
-                                            self.params[0].shape[0], self.params[1].shape[0], self.dev, **meta_kw)
+                                            self.params[0].shape[0], self.params[1].shape[0], self.dev,
+                                            user_sort=user_sort,
+                                            item_flags=os.environ.get("TRS_ITEM_INLINE", "0") == "1", **meta_kw)
         if ps.n_batches != n_batches:  # a shorter tail slice: same buffers, fewer batches
             full = ps
             ps = type(full).__new__(type(full))
@@ -349,7 +354,7 @@ class SparseScorerTrainer:
         if te is not None:
             # 32-bit keys: item and duplicated-user updates are ONE launch, and the last two events are recorded back to
             # back — that interval is the cost of an event record itself
-            fused = ps.key_bytes == 4 and ps.ukey_bytes == 4
+            fused = ps.key_bytes == 4 and ps.ukey_bytes in (0, 4)
             self._collect_events(te, ns, ("fwd_stage_kernel", "sorted_updates_fused_kernel", "event_overhead") if fused
                                  else ("fwd_stage_kernel", "sorted_item_update_kernel", "sorted_user_dup_update_kernel"))
 

@@ -195,9 +195,14 @@ class EpochPresort:
     """Buffers + result of trs_epoch_presort for n_batches whole batches: id arrays and the item references of every
     batch sorted by row.  `step_args(b)` gives what trs_train_steps_sgd needs to start at batch b of the slice."""
 
-    def __init__(self, n_batches, batch, n_users, n_items, device, item_meta=None, n_meta=()):
-        """item_meta (n_items, M) int32 + n_meta (categories per column): also sort every metadata column's references."""
+    def __init__(self, n_batches, batch, n_users, n_items, device, item_meta=None, n_meta=(), user_sort=True,
+                 item_flags=True):
+        """item_meta (n_items, M) int32 + n_meta (categories per column): also sort every metadata column's references.
+        user_sort=False (plain SGD without metadata): user duplicates as FLAGS only (trs_epoch_user_flags: the LDS-bitmap
+        kernel, no second segmented sort); the step then adds the flagged users' gradients with float atomics."""
         lib = _lib.load()
+        self.user_sort = bool(user_sort) or batch > EpochFlags.MAX_BATCH
+        self.item_flags = bool(item_flags)  # False: skip the item-duplicate flag pass (only K1's INL 2 mode reads them)
         kb, ktot, vtot, tmp = (C.c_int64() for _ in range(4))
         check(lib.trs_epoch_presort_sizes(n_batches, batch, n_items, C.byref(kb), C.byref(ktot), C.byref(vtot),
                                           C.byref(tmp)), "trs_epoch_presort_sizes")
@@ -210,8 +215,8 @@ class EpochPresort:
         uk, uv, ut = (C.c_int64() for _ in range(3))
         check(lib.trs_epoch_user_dups_sizes(n_batches, batch, n_users, C.byref(uk), C.byref(uv), C.byref(ut)),
               "trs_epoch_user_dups_sizes")
-        self.ukeys = torch.empty(uk.value, dtype=torch.uint8, device=device)
-        self.uvals = torch.empty(uv.value, dtype=torch.uint8, device=device)
+        self.ukeys = torch.empty(uk.value if self.user_sort else 8, dtype=torch.uint8, device=device)
+        self.uvals = torch.empty(uv.value if self.user_sort else 8, dtype=torch.uint8, device=device)
         self.temp_bytes = max(tmp.value, ut.value)
         self.temp = torch.empty(self.temp_bytes, dtype=torch.uint8, device=device)
         self.user_dup = torch.empty(n_pos, dtype=torch.uint8, device=device)  # 1: user has another reference in its batch
@@ -247,15 +252,21 @@ class EpochPresort:
                                             int(first_pos), self.n_batches, self.batch, self.n_users, self.n_items,
                                             ptr(self.ids[0]), ptr(self.ids[1]), ptr(self.ids[2]), ptr(self.keys),
                                             ptr(self.vals), ptr(self.temp), self.temp_bytes, ptr(err_flag),
-                                            C.byref(sk), C.byref(sv), ptr(self.item_dup), _samp(sampler), _stream()),
-              "trs_epoch_presort")
+                                            C.byref(sk), C.byref(sv), ptr(self.item_dup) if self.item_flags else None,
+                                            _samp(sampler), _stream()), "trs_epoch_presort")
         self.sorted_keys, self.sorted_vals = sk.value, sv.value
-        uk, uv, ukb = C.c_void_p(), C.c_void_p(), C.c_int32()
-        check(_lib.load().trs_epoch_user_dups(ptr(self.ids[0]), self.n_batches, self.batch, self.n_users,
-                                              ptr(self.ukeys), ptr(self.uvals), ptr(self.temp), self.temp_bytes,
-                                              ptr(self.user_dup), C.byref(uk), C.byref(uv), C.byref(ukb), _stream()),
-              "trs_epoch_user_dups")
-        self.sorted_ukeys, self.sorted_uvals, self.ukey_bytes = uk.value, uv.value, ukb.value
+        if self.user_sort:
+            uk, uv, ukb = C.c_void_p(), C.c_void_p(), C.c_int32()
+            check(_lib.load().trs_epoch_user_dups(ptr(self.ids[0]), self.n_batches, self.batch, self.n_users,
+                                                  ptr(self.ukeys), ptr(self.uvals), ptr(self.temp), self.temp_bytes,
+                                                  ptr(self.user_dup), C.byref(uk), C.byref(uv), C.byref(ukb), _stream()),
+                  "trs_epoch_user_dups")
+            self.sorted_ukeys, self.sorted_uvals, self.ukey_bytes = uk.value, uv.value, ukb.value
+        else:
+            check(_lib.load().trs_epoch_user_flags(ptr(self.ids[0]), self.n_batches, self.batch, self.n_users,
+                                                   ptr(self.user_dup), _stream()), "trs_epoch_user_flags")
+            self.sorted_ukeys = self.sorted_uvals = None
+            self.ukey_bytes = 0
         self.meta_sorted = []
         for m, n_cat in enumerate(self.n_meta):  # metadata columns: the same grouping by row, per column
             mk, mv = C.c_void_p(), C.c_void_p()
@@ -283,9 +294,10 @@ class EpochPresort:
         """(user, pos, neg id views, sorted keys address, sorted vals address, user-duplicate flags view, sorted user
         runs, item-duplicate flags view) for the steps starting at batch b."""
         o = b * self.batch
+        usorted = ((self.sorted_ukeys + o * self.ukey_bytes, self.sorted_uvals + o * 4, self.ukey_bytes, o)
+                   if self.sorted_ukeys is not None else (None, None, 0, o))
         return ([t[o:] for t in self.ids], self.sorted_keys + 2 * o * self.key_bytes, self.sorted_vals + 2 * o * 4,
-                self.user_dup[o:], (self.sorted_ukeys + o * self.ukey_bytes, self.sorted_uvals + o * 4,
-                                    self.ukey_bytes, o), self.item_dup[o:])
+                self.user_dup[o:], usorted, self.item_dup[o:])
 
 
 class EpochFlags:
