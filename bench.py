@@ -94,7 +94,8 @@ def slice_fractions(runner):
     n = ps.n_batches * ps.batch
     return {"k1_takes_lone_items": ps.key_bytes == 0,  # EpochFlags (accumulate mode); the sorted runs take every item reference
             "users_alone": 1.0 - float(ps.user_dup[:n].float().mean()),
-            "item_refs_alone": 1.0 - float(ps.item_dup[:n].float().mean()),
+            # (the sorted-run presort computes item flags only when K1 reads them: None = not computed)
+            "item_refs_alone": (1.0 - float(ps.item_dup[:n].float().mean())) if getattr(ps, "item_flags", True) else None,
             "note": "shares of the references whose row no other reference of the batch names (flags of the presort)"}
 
 

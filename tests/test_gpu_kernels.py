@@ -294,6 +294,44 @@ def test_hinge_auc():
         assert ac.item() == int((pos > neg).sum())
 
 
+@pytest.mark.parametrize("NI,B,nb,skew", [(1, 5, 2, False), (91, 256, 4, False), (16_384, 1000, 3, False),
+                                          (16_385, 4096, 2, True), (100_000, 65_536, 3, False),
+                                          (100_000, 65_536, 2, True), (100_000, 8192, 5, True),
+                                          (131_072, 3001, 2, False), (131_073, 512, 2, False),
+                                          (50_000, 131_072, 1, True), (50_000, 131_073, 1, False)])
+def test_item_references_grouped_by_row(NI, B, nb, skew):
+    """trs_epoch_presort's grouping of every batch's 2B item references — the hand-written counting sort in LDS (tables up
+    to 8 chunks of 16 384 rows and batches up to 131 072; beyond either: the segmented radix sort) — sizes either side
+    of the chunk and hand-over boundaries, ragged batches, hot rows longer than the staging buffer (zipf: a quarter of a
+    65 536-batch on one row): per batch the keys are the batch's pos / neg rows in ascending order, the payloads a
+    permutation of 0..2B-1 with ids[payload] == key.  Bit-exact (index work)."""
+    ops = _ops()
+    rs = np.random.RandomState(NI % 997 + B)
+    n = nb * B
+    draw = (lambda: (rs.zipf(1.3, n) % NI)) if skew else (lambda: rs.randint(0, NI, n))
+    user = rs.randint(0, 50, n).astype(np.int32)
+    pos, neg = draw().astype(np.int32), draw().astype(np.int32)
+    if NI > 1:
+        pos[:3], neg[:3] = NI - 1, 0  # first / last row of the table
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ps = ops.EpochPresort(nb, B, 50, NI, DEV, user_sort=False, item_flags=True)
+    ps.run(None, None, 0, 0, 0, err, given_ids=(d(user), d(pos), d(neg)))
+    torch.cuda.synchronize()
+    assert err.item() == 0
+    keys = ps.keys.view(torch.uint32)[2 * n:4 * n].cpu().numpy().astype(np.int64)
+    vals = ps.vals.view(torch.uint32)[2 * n:4 * n].cpu().numpy().astype(np.int64)
+    idup = ps.item_dup.cpu().numpy()
+    for b in range(nb):
+        k_, v_ = keys[2 * b * B:2 * (b + 1) * B], vals[2 * b * B:2 * (b + 1) * B]
+        both = np.stack([pos[b * B:(b + 1) * B], neg[b * B:(b + 1) * B]], 1).reshape(-1).astype(np.int64)  # [2t + w]
+        assert np.array_equal(k_, np.sort(both)), b
+        assert np.array_equal(np.sort(v_), np.arange(2 * B)), b
+        assert np.array_equal(both[v_], k_), b
+        cnt = np.bincount(both, minlength=NI)
+        assert np.array_equal(idup[b * B:(b + 1) * B].reshape(-1), (cnt[both] > 1).astype(np.uint8)), b
+
+
 @pytest.mark.parametrize("n,batch", [(1, 1), (1000, 7), (70_001, 512), (300, 1000), (65_536, 1024)])
 def test_hinge_auc_batches(n, batch):
     """Per-batch hinge sums / AUC counts of consecutive batches in one launch (evaluate()): each slot equals the oracle's

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(TRS_BLOCK) void epoch_refs_kernel(const EpochArgs a
 // ---------------------------------------------------------------------------------------------- duplicate flags only
 // The sparse regime (c4: 65 536 item references over 1M rows, 32 768 users over 10M per step) needs no grouping at all:
 // 94 % of the item references and 99.7 % of the users are alone on their row in the batch, K1 updates those rows in
-// place, and the few shared rows meet in a gradient accumulator (fast_step.hip, INL 3).  All K1 needs from the epoch is
+// place, and the few shared rows are updated by K2's float atomics (fast_step.hip, INL 2).  All K1 needs from the epoch is
 // one flag per reference: "another reference of this batch names the same row".  One 1024-thread workgroup per batch
 // finds them with a bitmap in LDS (2^20 bits = 128 KB of the CU's 160 KB):
 //   A  every reference sets its row's bit (ds_or returning the old word): a bit already set = a LATER arrival;
@@ -278,6 +278,147 @@ __global__ __launch_bounds__(FLAG_THREADS) void batch_flags_kernel(const FlagArg
       }
     }
     __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- grouping by item row
+// The dense regime's sorted runs need every batch's 2B item references grouped by row.  A segmented radix sort moves
+// keys AND payloads through global memory twice (two 9-bit passes: 32 B per reference); a counting sort reads the ids
+// (L2-resident: one batch = 8 B per triple) and writes each (row, payload) pair once.  One 1024-thread workgroup per
+// batch walks the key space in chunks of GRP_BINS rows; per chunk, in LDS, GRP_BINS cursors (64 KB) and a staging buffer
+// of GRP_CAP packed words (88 KB):
+//   count    every reference whose row falls in the chunk: ds_add on its counter (ids read straight from pos / neg);
+//   scan     counters -> first output slot of every row (each wave scans a contiguous segment 64 rows at a time, wave
+//            totals combined through LDS); the same sweep finds the rows at which the output crosses a multiple of
+//            GRP_CAP = the windows of rows whose output fits the staging buffer (one window unless rows are hot);
+//   scatter  per window, every reference again: slot = ds_add_rtn on its row's cursor; (row in chunk, payload) packed
+//            into one word of the staging buffer at slot - window start — NOT stored to global memory: scattered 4-byte
+//            stores cost 1.8 ms per 512 batches of 65 536 (L2 request rate; tools/micro/group_bench.hip), the staged
+//            ones 0.15 ms;
+//   write    the staging buffer leaves as coalesced stores of keys and payloads.
+// A row with more references than the buffer holds (hot rows of skewed data) spills its tail as direct stores.
+// Output = the batch's references in ascending row order (inside a row: arrival order — it only permutes the fp32
+// summation order of the run).  Measured at c2 (100 K rows = 7 chunks, 14 sweeps): 0.64 ms per 512 batches against
+// 0.88 ms for rocprim's segmented radix sort on the same keys; 20 K rows: 0.19 against 0.41 ms.
+constexpr int GRP_THREADS = 1024, GRP_BINS = 16384, GRP_BIN_BITS = 14, GRP_CAP = 22528, GRP_U = 8, GRP_MAX_CHUNKS = 8;
+constexpr int GRP_WMAX = 16;  // windows per chunk: 2B / GRP_CAP + 2 <= 14 for 2B <= 2^18
+
+__global__ __launch_bounds__(GRP_THREADS) void batch_group_items_kernel(const int32_t* __restrict__ pos_all,
+                                                                       const int32_t* __restrict__ neg_all,
+                                                                       int64_t batch, int64_t n_items, int pb,
+                                                                       uint32_t* __restrict__ keys_all,
+                                                                       RefPayload* __restrict__ vals_all) {
+  extern __shared__ uint32_t grp_lds[];
+  uint32_t* cur = grp_lds;               // GRP_BINS counters, then cursors
+  uint32_t* stage = grp_lds + GRP_BINS;  // GRP_CAP packed (row in chunk << pb) | payload
+  __shared__ uint32_t wave_tot[GRP_THREADS / TRS_WAVE];
+  __shared__ uint32_t win_row[GRP_WMAX + 2], win_slot[GRP_WMAX + 2];  // first row / first slot of every window
+  __shared__ uint32_t tot_s;
+  const int32_t* pos = pos_all + (int64_t)blockIdx.x * batch;
+  const int32_t* neg = neg_all + (int64_t)blockIdx.x * batch;
+  uint32_t* keys = keys_all + 2 * (int64_t)blockIdx.x * batch;
+  RefPayload* vals = vals_all + 2 * (int64_t)blockIdx.x * batch;
+  const int B = (int)batch;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  constexpr int NW = GRP_THREADS / TRS_WAVE, SEG = GRP_BINS / NW;  // rows per wave in the scan
+  constexpr int STEP = GRP_THREADS * GRP_U;
+  const uint32_t pmask = (1u << pb) - 1u;
+  uint32_t base = 0;  // output slot of the chunk's first reference
+  for (int64_t c0l = 0; c0l < n_items; c0l += GRP_BINS) {
+    const uint32_t c0 = (uint32_t)c0l;
+    for (int w = threadIdx.x; w < GRP_BINS; w += GRP_THREADS) cur[w] = 0u;
+    __syncthreads();
+    for (int t0 = threadIdx.x; t0 < B; t0 += STEP) {  // count
+      uint32_t kp[GRP_U], kn[GRP_U];
+#pragma unroll
+      for (int k = 0; k < GRP_U; ++k) {
+        const int t = t0 + k * GRP_THREADS;
+        kp[k] = (uint32_t)pos[t < B ? t : 0] - c0;
+        kn[k] = (uint32_t)neg[t < B ? t : 0] - c0;
+      }
+#pragma unroll
+      for (int k = 0; k < GRP_U; ++k) {
+        if (t0 + k * GRP_THREADS < B) {
+          if (kp[k] < (uint32_t)GRP_BINS) atomicAdd(&cur[kp[k]], 1u);
+          if (kn[k] < (uint32_t)GRP_BINS) atomicAdd(&cur[kn[k]], 1u);
+        }
+      }
+    }
+    __syncthreads();
+    // exclusive scan (slots relative to the chunk's first): wave wv owns rows [wv * SEG, (wv + 1) * SEG)
+    uint32_t tot = 0;
+    for (int i = lane; i < SEG; i += TRS_WAVE) tot += cur[wv * SEG + i];
+    tot = (uint32_t)trs_wave_sum_i((int)tot);
+    if (lane == 0) wave_tot[wv] = tot;
+    __syncthreads();
+    uint32_t carry = 0;
+    for (int w = 0; w < wv; ++w) carry += wave_tot[w];
+    for (int i0 = 0; i0 < SEG; i0 += TRS_WAVE) {
+      const uint32_t r = (uint32_t)(wv * SEG + i0 + lane);
+      const uint32_t v = cur[r];
+      uint32_t inc = v;  // inclusive scan over the 64 lanes
+#pragma unroll
+      for (int o = 1; o < TRS_WAVE; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)inc, o, 64);
+        if (lane >= o) inc += up;
+      }
+      const uint32_t f = carry + inc - v, e = f + v;  // this row's slots [f, e)
+      cur[r] = f;
+      // the row at which the output crosses w * GRP_CAP closes window w - 1 (a hot row may close several)
+      for (uint32_t w = f / GRP_CAP + 1; w * GRP_CAP <= e; ++w) {
+        win_row[w] = r + 1;
+        win_slot[w] = e;
+      }
+      carry += (uint32_t)__shfl((int)inc, 63, 64);
+    }
+    if (threadIdx.x == GRP_THREADS - 1) {  // (last wave: carry = the chunk's references)
+      const uint32_t nw = carry / GRP_CAP + 1;
+      tot_s = carry;
+      win_row[0] = 0u;
+      win_slot[0] = 0u;
+      win_row[nw] = (uint32_t)GRP_BINS;
+      win_slot[nw] = carry;
+    }
+    __syncthreads();
+    const uint32_t totc = tot_s, nwin = totc / GRP_CAP + 1;
+    for (uint32_t w = 0; w < nwin; ++w) {
+      const uint32_t r0 = win_row[w], nr = win_row[w + 1] - r0, wb = win_slot[w], wn = win_slot[w + 1] - wb;
+      if (nr == 0u || wn == 0u) continue;  // (uniform: LDS values)
+      for (int t0 = threadIdx.x; t0 < B; t0 += STEP) {  // scatter into the staging buffer
+        uint32_t kp[GRP_U], kn[GRP_U];
+#pragma unroll
+        for (int k = 0; k < GRP_U; ++k) {
+          const int t = t0 + k * GRP_THREADS;
+          kp[k] = (uint32_t)pos[t < B ? t : 0] - c0;
+          kn[k] = (uint32_t)neg[t < B ? t : 0] - c0;
+        }
+#pragma unroll
+        for (int k = 0; k < GRP_U; ++k) {
+          const int t = t0 + k * GRP_THREADS;
+          if (t < B) {
+            if (kp[k] - r0 < nr) {
+              const uint32_t slot = atomicAdd(&cur[kp[k]], 1u), o = slot - wb;
+              if (o < (uint32_t)GRP_CAP) stage[o] = (kp[k] << pb) | (2u * (uint32_t)t);
+              else { keys[base + slot] = kp[k] + c0; vals[base + slot].tw = 2u * (uint32_t)t; }
+            }
+            if (kn[k] - r0 < nr) {
+              const uint32_t slot = atomicAdd(&cur[kn[k]], 1u), o = slot - wb;
+              if (o < (uint32_t)GRP_CAP) stage[o] = (kn[k] << pb) | (2u * (uint32_t)t + 1u);
+              else { keys[base + slot] = kn[k] + c0; vals[base + slot].tw = 2u * (uint32_t)t + 1u; }
+            }
+          }
+        }
+      }
+      __syncthreads();
+      const uint32_t nst = wn < (uint32_t)GRP_CAP ? wn : (uint32_t)GRP_CAP;
+      for (uint32_t o = threadIdx.x; o < nst; o += GRP_THREADS) {  // coalesced write-out
+        const uint32_t word = stage[o];
+        keys[base + wb + o] = (word >> pb) + c0;
+        vals[base + wb + o].tw = word & pmask;
+      }
+      __syncthreads();
+    }
+    base += totc;
   }
 }
 
@@ -924,6 +1065,10 @@ extern "C" int trs_epoch_presort(const int32_t* stream_ui_dev, const int32_t* ne
   const int src = !stream_ui_dev ? 0 : (neg_static_dev ? 2 : 1);
   hipStream_t s = (hipStream_t)stream;
   const dim3 gr(trs_grid(n_pos, TRS_BLOCK)), bl(TRS_BLOCK);
+  static const bool vendor_sort = getenv("TRS_VENDOR_SORT") && atoi(getenv("TRS_VENDOR_SORT")) != 0;  // A/B knob
+  const int pay_bits = bits_for(2 * batch);  // a staged word = (row in chunk, payload): GRP_BIN_BITS + pay_bits <= 32
+  const bool hand = !vendor_sort && n_items <= (int64_t)GRP_BINS * GRP_MAX_CHUNKS && GRP_BIN_BITS + pay_bits <= 32;
+  if (hand) a.keys = nullptr;  // the grouping kernel reads pos / neg themselves
   if (src == 0) hipLaunchKernelGGL((epoch_refs_kernel<uint32_t, 0>), gr, bl, 0, s, a);
   else if (src == 1) hipLaunchKernelGGL((epoch_refs_kernel<uint32_t, 1>), gr, bl, 0, s, a);
   else hipLaunchKernelGGL((epoch_refs_kernel<uint32_t, 2>), gr, bl, 0, s, a);
@@ -933,6 +1078,28 @@ extern "C" int trs_epoch_presort(const int32_t* stream_ui_dev, const int32_t* ne
   RefPayload* vin = (RefPayload*)vals_dev;
   RefPayload* vout = vin + n;
   uint32_t* kin = (uint32_t*)keys_dev;
+  if (hand) {
+    // hand-written grouping (counting sort in LDS, one workgroup per batch): no key array, no vendor library
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute((const void*)batch_group_items_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (GRP_BINS + GRP_CAP) * 4);
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(batch_group_items_kernel, dim3((unsigned)n_batches), dim3(GRP_THREADS),
+                       (size_t)(GRP_BINS + GRP_CAP) * 4, s, (const int32_t*)pos_dev, (const int32_t*)neg_dev, batch,
+                       n_items, pay_bits, kin + n, vout);
+    TRS_CHECK_LAUNCH("batch_group_items_kernel");
+    *sorted_keys_out = (void*)(kin + n);
+    *sorted_vals_out = (void*)vout;
+    if (item_dup_flags_out_dev) {
+      (void)hipMemsetAsync(item_dup_flags_out_dev, 0, n, s);
+      hipLaunchKernelGGL(item_flags_kernel, dim3(trs_grid((int64_t)n, TRS_BLOCK)), bl, 0, s, kin + n, vout, (int64_t)n,
+                         2 * batch, item_dup_flags_out_dev);
+      TRS_CHECK_LAUNCH("item_flags_kernel");
+    }
+    return TRS_OK;
+  }
   hipError_t e = rocprim::segmented_radix_sort_pairs<ItemSortCfg>(
       temp_dev, temp, kin, kin + n,
       ref_val_it(batch), vout, n,
