@@ -436,13 +436,15 @@ def test_gemm_split_k_wgrad_shape_and_strided_views():
     assert rel_err(out_f.cpu().numpy(), dy.astype(np.float64).T @ x.astype(np.float64)) < 3e-6
 
 
-@pytest.mark.parametrize("tile", ["128", "256", "512"])
-@pytest.mark.parametrize("B,K,H", [(256, 128, 256), (512, 256, 512)])
+@pytest.mark.parametrize("tile", ["128", "256", "512", "512-regstage"])
+@pytest.mark.parametrize("B,K,H", [(256, 128, 256), (512, 256, 512), (384, 1280, 768)])
 def test_gemm_bf16_resident_tiles_and_fused_bn_statistics(tile, B, K, H, monkeypatch):
-    """The three workgroup tiles of the bf16-resident kernel (128x128, 256x128, 256x256; forced through
-    TRS_GEMM16_TILE) give the same product, bf16 output and per-128-row BatchNorm partials."""
+    """The workgroup tiles of the bf16-resident kernels (128x128, 256x128, 256x256 filled by the LDS-DMA [NT form] and
+    256x256 staged through registers; forced through TRS_GEMM16_TILE / TRS_GEMM16_NO_GLDS) give the same product, bf16
+    output and per-128-row BatchNorm partials."""
     ops = _ops()
-    monkeypatch.setenv("TRS_GEMM16_TILE", tile)
+    monkeypatch.setenv("TRS_GEMM16_TILE", tile.split("-")[0])
+    monkeypatch.setenv("TRS_GEMM16_NO_GLDS", "1" if tile.endswith("regstage") else "0")
     rs = np.random.RandomState(B + K)
     rows = 2 * B
     x = torch.from_numpy(rs.normal(0, 1, (rows, K)).astype(np.float32)).to(DEV).to(torch.bfloat16)

@@ -1,0 +1,216 @@
+// Scratch: NT bf16 GEMM C(M,N) = A(M,K) B(N,K)^T at the c5 MLP shapes — 256 x 256 x 64 workgroup tiles filled by
+// global_load_lds (16 B per lane, XOR swizzle applied to the per-lane SOURCE address, LDS image lane-linear), wave grids
+// 2 x 4 (wave tile 128 x 64) and 2 x 2 (128 x 128), one barrier per k-tile.
+//   hipcc -O3 --offload-arch=gfx950 tools/micro/gemm16_bench.hip -o /tmp/gemm16_bench && /tmp/gemm16_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using u16 = unsigned short;
+
+constexpr int BMT = 256, BNT = 256, BKT = 64;
+constexpr int TILE_BYTES = BMT * BKT * 2;  // 32 KB per operand tile
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// one operand tile (256 rows x 64 k): 32 wave-instructions of 8 rows; wave w issues 32 / NWAVES of them
+template <int NWAVES, int SWZ>
+__device__ __forceinline__ void stage_tile(const u16* __restrict__ P, int64_t ld, int64_t row0, int64_t k0, char* lds_tile,
+                                           int wave, int lane) {
+  constexpr int PER = 32 / NWAVES;
+  const int r8 = lane >> 3, slot = lane & 7;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int inst = wave * PER + q;
+    const int row = inst * 8 + r8;
+    const u16* src = P + (row0 + row) * ld + k0 + ((slot ^ (SWZ ? ((row >> 1) & 7) : r8)) << 3);
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_tile + inst * 1024), 16, 0, 0);
+  }
+}
+
+template <int WM, int WN, bool OUT16, int SWZ, bool M16>
+__global__ __launch_bounds__(WM* WN * 64) void gemm16_nt_kernel(const u16* __restrict__ A, const u16* __restrict__ B,
+                                                                 float* __restrict__ C, u16* __restrict__ C16, int64_t M,
+                                                                 int64_t N, int64_t K, int gx) {
+  constexpr int NWAVES = WM * WN, TM = BMT / WM, TN = BNT / WN, MI = TM / 32, NI = TN / 32;
+  __shared__ __attribute__((aligned(1024))) char lds[4 * TILE_BYTES];  // [buf][A | B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  int64_t lid = blockIdx.x;
+  const int64_t nwg = gridDim.x;
+  if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);
+  const int bx = (int)(lid % gx), by = (int)(lid / gx);
+  const int64_t m0 = (int64_t)by * BMT, n0 = (int64_t)bx * BNT;
+  const int nk = (int)(K / BKT);
+  if constexpr (!M16) {
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int lr = lane & 31, lk = lane >> 5;
+  stage_tile<NWAVES, SWZ>(A, K, m0, 0, lds, wave, lane);
+  stage_tile<NWAVES, SWZ>(B, K, n0, 0, lds + TILE_BYTES, wave, lane);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      stage_tile<NWAVES, SWZ>(A, K, m0, (int64_t)(kt + 1) * BKT, lds + (cur ^ 1) * 2 * TILE_BYTES, wave, lane);
+      stage_tile<NWAVES, SWZ>(B, K, n0, (int64_t)(kt + 1) * BKT, lds + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES, wave, lane);
+    }
+    const char* ta = lds + cur * 2 * TILE_BYTES + (wm * TM + lr) * 128;
+    const char* tb = lds + cur * 2 * TILE_BYTES + TILE_BYTES + (wn * TN + lr) * 128;
+    const int f = SWZ ? ((lr >> 1) & 7) : (lr & 7);
+#pragma unroll
+    for (int ks = 0; ks < BKT / 16; ++ks) {
+      const int sw = ((ks * 2 + lk) ^ f) << 4;
+      bf16x8 a[MI], b[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(ta + i * 32 * 128 + sw);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 128 + sw);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int64_t col = n0 + wn * TN + j * 32 + lr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (OUT16) C16[row * N + col] = __builtin_bit_cast(u16, (__bf16)acc[i][j][r]);
+        else C[row * N + col] = acc[i][j][r];
+      }
+    }
+  } else {
+  // 16 x 16 x 32 MFMA: fragment = row fr = lane & 15, k-chunk fq = lane >> 4 (8 bf16) of a 32-deep step
+  constexpr int MI2 = TM / 16, NI2 = TN / 16;
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  f32x4 acc[MI2][NI2];
+#pragma unroll
+  for (int i = 0; i < MI2; ++i)
+#pragma unroll
+    for (int j = 0; j < NI2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+  const int fr = lane & 15, fq = lane >> 4;
+  stage_tile<NWAVES, SWZ>(A, K, m0, 0, lds, wave, lane);
+  stage_tile<NWAVES, SWZ>(B, K, n0, 0, lds + TILE_BYTES, wave, lane);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      stage_tile<NWAVES, SWZ>(A, K, m0, (int64_t)(kt + 1) * BKT, lds + (cur ^ 1) * 2 * TILE_BYTES, wave, lane);
+      stage_tile<NWAVES, SWZ>(B, K, n0, (int64_t)(kt + 1) * BKT, lds + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES, wave, lane);
+    }
+    const char* ta = lds + cur * 2 * TILE_BYTES + (wm * TM + fr) * 128;
+    const char* tb = lds + cur * 2 * TILE_BYTES + TILE_BYTES + (wn * TN + fr) * 128;
+    const int f = SWZ ? ((fr >> 1) & 7) : (fr & 7);
+#pragma unroll
+    for (int ks = 0; ks < BKT / 32; ++ks) {
+      const int sw = ((ks * 4 + fq) ^ f) << 4;
+      bf16x8 a[MI2], b[NI2];
+#pragma unroll
+      for (int i = 0; i < MI2; ++i) a[i] = *reinterpret_cast<const bf16x8*>(ta + i * 16 * 128 + sw);
+#pragma unroll
+      for (int j = 0; j < NI2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(tb + j * 16 * 128 + sw);
+#pragma unroll
+      for (int i = 0; i < MI2; ++i)
+#pragma unroll
+        for (int j = 0; j < NI2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MI2; ++i)
+#pragma unroll
+    for (int j = 0; j < NI2; ++j) {
+      const int64_t col = n0 + wn * TN + j * 16 + fr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = m0 + wm * TM + i * 16 + fq * 4 + r;
+        if (OUT16) C16[row * N + col] = __builtin_bit_cast(u16, (__bf16)acc[i][j][r]);
+        else C[row * N + col] = acc[i][j][r];
+      }
+    }
+  }
+}
+
+static u16 f2bf(float f) {
+  unsigned u; memcpy(&u, &f, 4);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (u16)(u >> 16);
+}
+static float bf2f(u16 h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
+int main(int argc, char** argv) {
+  const int64_t M = argc > 1 ? atoll(argv[1]) : 65536;
+  struct Shape { int64_t N, K; const char* name; } shapes[] = {{1024, 1280, "fwd L1"}, {512, 1024, "fwd L2"},
+                                                               {256, 512, "fwd L3"}, {1280, 1024, "dgrad L1"},
+                                                               {1024, 512, "dgrad L2"}, {512, 256, "dgrad L3"}};
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (auto& sh : shapes) {
+    const int64_t N = sh.N, K = sh.K;
+    std::vector<u16> hA((size_t)M * K), hB((size_t)N * K);
+    unsigned long long s = 88172645463325252ull;
+    auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (float)((s >> 40) & 0xFFFF) / 32768.f - 1.f; };
+    for (auto& v : hA) v = f2bf(rnd());
+    for (auto& v : hB) v = f2bf(rnd());
+    u16 *dA, *dB, *dC16; float* dC;
+    hipMalloc(&dA, hA.size() * 2); hipMalloc(&dB, hB.size() * 2); hipMalloc(&dC, (size_t)M * N * 4); hipMalloc(&dC16, (size_t)M * N * 2);
+    hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(dB, hB.data(), hB.size() * 2, hipMemcpyHostToDevice);
+    const int gx = (int)(N / BNT), gy = (int)(M / BMT);
+    auto check = [&](bool out16) {
+      std::vector<float> hC(out16 ? 0 : (size_t)M * N); std::vector<u16> hC16(out16 ? (size_t)M * N : 0);
+      if (out16) hipMemcpy(hC16.data(), dC16, hC16.size() * 2, hipMemcpyDeviceToHost);
+      else hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost);
+      double worst = 0;
+      unsigned long long t = 12345;
+      for (int q = 0; q < 400; ++q) {
+        t = t * 6364136223846793005ull + 1442695040888963407ull;
+        const int64_t r = (int64_t)((t >> 33) % (unsigned long long)M), c = (int64_t)((t >> 13) % (unsigned long long)N);
+        double ref = 0;
+        for (int64_t k = 0; k < K; ++k) ref += (double)bf2f(hA[r * K + k]) * (double)bf2f(hB[c * K + k]);
+        const double got = out16 ? bf2f(hC16[r * N + c]) : hC[r * N + c];
+        const double err = fabs(got - ref) / (out16 ? fmax(1.0, fabs(ref)) * 4e-3 : fmax(1.0, fabs(ref)) * 1e-4);
+        if (err > worst) worst = err;
+      }
+      return worst;
+    };
+#define RUN(NAME, WM_, WN_, O16, SWZ_, M16_)                                                                              \
+    {                                                                                                         \
+      float ms = 0;                                                                                           \
+      hipMemset(dC, 0, (size_t)M * N * 4); hipMemset(dC16, 0, (size_t)M * N * 2);                             \
+      for (int rep = 0; rep < 6; ++rep) {                                                                     \
+        if (rep == 1) hipEventRecord(e0);                                                                     \
+        hipLaunchKernelGGL((gemm16_nt_kernel<WM_, WN_, O16, SWZ_, M16_>), dim3(gx * gy), dim3(WM_ * WN_ * 64), 0, 0, dA, dB, dC, dC16, M, N, K, gx); \
+      }                                                                                                       \
+      hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); ms /= 5;                 \
+      const double w = check(O16);                                                                            \
+      printf("%-9s N=%4lld K=%4lld %-22s %8.1f us %7.1f TF   worst err/tol %.3f %s (%s)\n", sh.name, (long long)N, \
+             (long long)K, NAME, ms * 1e3, 2.0 * M * N * K / ms / 1e9, w, w <= 1.0 ? "ok" : "WRONG",           \
+             hipGetErrorString(hipGetLastError()));                                                           \
+    }
+    RUN("8w 128x64 32x32 swz0", 2, 4, true, 0, false)
+    RUN("8w 128x64 32x32 swz1", 2, 4, true, 1, false)
+    RUN("8w 128x64 16x16 swz1", 2, 4, true, 1, true)
+    RUN("8w 128x64 16x16 swz1 f32", 2, 4, false, 1, true)
+    RUN("4w 128x128 32x32 swz1", 2, 2, true, 1, false)
+    RUN("4w 128x128 16x16 swz1", 2, 2, true, 1, true)
+    hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dC16);
+  }
+  return 0;
+}

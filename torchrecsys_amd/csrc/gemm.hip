@@ -563,6 +563,153 @@ __global__ __launch_bounds__(BMT * BNT / 64) void gemm_bf16in_kernel(const Gemm1
     gemm_tile_bn_stats(e, acc, reinterpret_cast<float*>(&As[0][0]), m0, n0, wm, wn, lr, lk, by, BMT / BM, WN);
 }
 
+// ---- NT form at 256 x 256 x 64 tiles filled by the LDS-DMA (global_load_lds_dwordx4): forward and input-gradient GEMMs
+// of the bf16-resident MLP step.  8 waves as 2 (M) x 4 (N), wave tile 128 x 64 = 4 x 2 MFMA 32x32x16 accumulators: a
+// k-step of 16 reads 6 fragments for 8 MFMAs (the 16-wave kernel above: 4 for 4 — at 1 KB of LDS reads per MFMA the LDS
+// array, not the matrix cores, set its pace).  No staging registers, no ds_write pass: each wave-instruction moves
+// 8 rows x 128 B (64 k of bf16) straight into LDS, lane-linear; the bank-conflict swizzle (16-B slot ^= (row >> 1) & 7,
+// which spreads every 16-lane group of a ds_read_b128 over the 16 slots of the 256-B bank row) is applied to the per-lane
+// SOURCE address and again on the fragment reads.  One barrier per k-tile: the loads of tile t+1 are issued right after
+// the barrier that publishes tile t and are awaited (vmcnt(0)) at the next one.  Measured against the 16-wave kernel at
+// the c5 shapes (65 536 rows): 1280 -> 1024: 182 us (944 TFLOP/s) against 221; 1024 -> 512: 73 against 96;
+// 512 -> 256: 24 against 37 (tools/micro/gemm16_bench.hip).
+// Epilogue: alpha * acc + bias -> fp32 or bf16 C; BatchNorm partial statistics per 128-row chunk = per wave row (every
+// column's 128 rows live in ONE wave: 4 accumulators x 16 registers x 2 lane halves — no LDS, no barrier).
+constexpr int G3_TILE = 256 * BK2 * 2;  // bytes of one operand tile
+typedef const __attribute__((address_space(1))) void* g3_gptr;
+typedef __attribute__((address_space(3))) void* g3_lptr;
+
+__device__ __forceinline__ void g3_stage(const unsigned short* __restrict__ P, int64_t ld, int64_t row0, int64_t k0,
+                                         char* lds_tile, int wave, int lane) {
+  const int r8 = lane >> 3, slot = lane & 7;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {  // 32 pieces of 8 rows per tile, 4 per wave
+    const int piece = wave * 4 + q;
+    const int row = piece * 8 + r8;
+    const unsigned short* src = P + (row0 + row) * ld + k0 + ((slot ^ ((row >> 1) & 7)) << 3);
+    __builtin_amdgcn_global_load_lds((g3_gptr)src, (g3_lptr)(lds_tile + piece * 1024), 16, 0, 0);
+  }
+}
+
+template <bool OUT16>
+__global__ __launch_bounds__(512) void gemm16_nt_glds_kernel(const Gemm16Args g) {
+  __shared__ __attribute__((aligned(1024))) char lds[4 * G3_TILE];  // [buffer][A | B], the only LDS object
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  int64_t lid = blockIdx.x;
+  const int64_t nwg = gridDim.x;
+  if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);  // XCD-aware tile order (see gemm_f32_kernel)
+  const int bx = (int)(lid % g.gx), by = (int)(lid / g.gx);
+  const int64_t m0 = (int64_t)by * 256, n0 = (int64_t)bx * 256;
+  const int nk = (int)(g.K / BK2);
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int lr = lane & 31, lk = lane >> 5;
+  g3_stage(g.A, g.lda, m0, 0, lds, wave, lane);
+  g3_stage(g.B, g.ldb, n0, 0, lds + G3_TILE, wave, lane);
+  const int f = (lr >> 1) & 7;
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();  // (drains this wave's LDS-DMA: vmcnt(0)) tile kt is in LDS, tile kt - 1 has been read by everyone
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      g3_stage(g.A, g.lda, m0, (int64_t)(kt + 1) * BK2, lds + (cur ^ 1) * 2 * G3_TILE, wave, lane);
+      g3_stage(g.B, g.ldb, n0, (int64_t)(kt + 1) * BK2, lds + (cur ^ 1) * 2 * G3_TILE + G3_TILE, wave, lane);
+    }
+    const char* ta = lds + cur * 2 * G3_TILE + (wm * 128 + lr) * 128;
+    const char* tb = lds + cur * 2 * G3_TILE + G3_TILE + (wn * 64 + lr) * 128;
+#pragma unroll
+    for (int ks = 0; ks < BK2 / 16; ++ks) {
+      const int sw = ((ks * 2 + lk) ^ f) << 4;
+      bf16x8 a[4], b[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(ta + i * 32 * 128 + sw);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 128 + sw);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // Epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) — a lane holds
+  // ONE column of 16 rows, so storing from the accumulators would issue 128 stores of 64-byte row pieces per wave.  The
+  // operand buffers are dead: each wave transposes its tile through its own 16 KB of LDS, 64 rows at a time, and leaves
+  // through 16-byte stores of whole 128-byte (bf16) / 256-byte (fp32) row segments.
+  float bv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bv[j] = g.bias ? g.bias[n0 + wn * 64 + j * 32 + lr] : 0.f;
+  __syncthreads();  // every wave has read the last k-tile
+  float* stage = reinterpret_cast<float*>(lds + wave * 16384);  // [64 rows][64 columns] fp32, private to the wave
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = g.alpha * acc[2 * h + ii][j][r] + bv[j];
+          acc[2 * h + ii][j][r] = v;
+          stage[(ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * 64 + j * 32 + lr] = v;
+        }
+    const int64_t row_h = m0 + wm * 128 + h * 64, col_w = n0 + wn * 64;
+    if (OUT16) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {  // 8 rows per wave-instruction: 8 lanes x 8 columns each
+        const int row = q * 8 + (lane >> 3), cg = lane & 7;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * 64 + cg * 8);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row * 64 + cg * 8 + 4);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = (__bf16)lo[e];
+          o[4 + e] = (__bf16)hi[e];
+        }
+        *reinterpret_cast<bf16x8*>(g.C16 + (row_h + row) * g.ldc + col_w + cg * 8) = o;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {  // 4 rows per wave-instruction: 16 lanes x 4 columns each
+        const int row = q * 4 + (lane >> 4), cg = lane & 15;
+        const f32x4 v4 = *reinterpret_cast<const f32x4*>(stage + row * 64 + cg * 4);
+        *reinterpret_cast<f32x4*>(g.C + (row_h + row) * g.ldc + col_w + cg * 4) = v4;
+      }
+    }
+  }
+  if (g.bn_part) {  // mean and sum of squared deviations of the stored values over this wave's 128 rows, per column
+    float* o = g.bn_part + (int64_t)(by * 2 + wm) * 2 * g.N;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+      s += __shfl_xor(s, 32, 64);
+      const float mean = s * (1.0f / 128.0f);
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float d = acc[i][j][r] - mean;
+          q += d * d;
+        }
+      q += __shfl_xor(q, 32, 64);
+      if (lk == 0) {
+        const int64_t col = n0 + wn * 64 + j * 32 + lr;
+        o[col] = mean;
+        o[g.N + col] = q;
+      }
+    }
+  }
+}
+
 // fp32 (rows, cols) -> bf16 copy (same layout) and, optionally, the transposed bf16 copy (cols, rows): the per-step
 // refresh of the MLP's weight images (tiny: the weights, not the activations).
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, int64_t rows, int64_t cols,
@@ -749,6 +896,17 @@ extern "C" int trs_gemm_bf16in(int tn, int64_t M, int64_t N, int64_t K, float al
   g.gx = (int)gx; g.gy = (int)gy; g.splits = splits;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)(gx * gy * splits));
+  const char* ng_env = getenv("TRS_GEMM16_NO_GLDS");  // A/B knob (tests, tuning): the register-staged 256 x 256 kernel
+  const bool no_glds = ng_env && atoi(ng_env) != 0;
+  const bool c_vec = (((uintptr_t)(C_bf16_dev ? C_bf16_dev : (void*)C_dev)) & 15) == 0 && ldc % 8 == 0;  // 16-byte stores
+  if (wide && !tn && splits == 1 && beta == 0.f && !no_glds && c_vec) {
+    g.gx = (int)(N / 256); g.gy = (int)(M / 256);
+    const dim3 grid3((unsigned)((int64_t)g.gx * g.gy));
+    if (g.C16) hipLaunchKernelGGL((gemm16_nt_glds_kernel<true>), grid3, dim3(512), 0, s, g);
+    else hipLaunchKernelGGL((gemm16_nt_glds_kernel<false>), grid3, dim3(512), 0, s, g);
+    TRS_CHECK_LAUNCH("gemm16_nt_glds_kernel");
+    return TRS_OK;
+  }
   if (wide && tn) hipLaunchKernelGGL((gemm_bf16in_kernel<true, 256, 256>), grid, dim3(1024), 0, s, g);
   else if (wide) hipLaunchKernelGGL((gemm_bf16in_kernel<false, 256, 256>), grid, dim3(1024), 0, s, g);
   else if (tn && big) hipLaunchKernelGGL((gemm_bf16in_kernel<true, 256>), grid, dim3(512), 0, s, g);
