@@ -413,6 +413,20 @@ int trs_topk(const float* scores_dev, int64_t n, int32_t k, int64_t* idx_out_dev
 int trs_mlp_gather_concat(const trs_tables* tables, const trs_batch* batch, int32_t passes, float* x_dev,
                           void* x_bf16_dev, int64_t ld, void* stream);
 
+/* SGD on every embedding table of an MLP step, straight from d x0 = the input gradient of the first layer ((2B, ld);
+ * rows [0,B) positive pass, [B,2B) negative pass; column block f = field f of x0; fp32 OR bf16 — exactly one of
+ * dx0_dev / dx0_bf16_dev): W[row] -= lr * (sum of the d x0 segments of the row's references).  Replaces the sparse COO
+ * gradients of the embedding tables + optimizer.step() (model.py:197-198) for the MLP scorer.  Two launches: user / item
+ * rows (the user's two passes added in registers; references flagged alone in their batch — user_dup_flags_dev (B),
+ * item_dup_flags_dev (B,2) from trs_epoch_flags / trs_epoch_presort, both optional — are plain read-modify-writes, the
+ * rest float atomics) and the metadata tables (every workgroup owns a range of categories, sums their references in LDS
+ * and applies each row once).  Needs D % 4 == 0, ld % 4 == 0 and metadata tables small enough for the owner-computes
+ * form: trs_mlp_embed_sgd_update_supported(tables) != 0. */
+int trs_mlp_embed_sgd_update_supported(const trs_tables* tables);
+int trs_mlp_embed_sgd_update(const trs_tables* tables, const trs_batch* batch, const float* dx0_dev,
+                             const void* dx0_bf16_dev, int64_t ld, float lr, const uint8_t* user_dup_flags_dev,
+                             const uint8_t* item_dup_flags_dev, void* stream);
+
 /* C(M,N) = alpha * op(A)(M,K) * op(B)(K,N) + beta * C [+ bias(N) on every row], fp32 in / fp32 accumulate on
  * v_mfma_f32_32x32x2_f32 (an exact fp32 FMA chain).  Row-major; transA: 0 = A stored (M,K), 1 = stored (K,M);
  * transB: 0 = B stored (K,N), 1 = stored (N,K).  Replaces aten::addmm / mm under nn.Linear and its autograd

@@ -495,6 +495,76 @@ def test_gemm_bf16_resident_split_k_wgrad_shape():
     assert rel_err(out.cpu().numpy(), dy.double().cpu().numpy().T @ x.double().cpu().numpy()) < 3e-6
 
 
+@pytest.mark.parametrize("D,M,B,n_cat", [(8, 0, 300, 0), (64, 1, 1000, 37), (256, 3, 4096, 1000), (128, 2, 777, 5000),
+                                          (256, 3, 2000, 10_000)])
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("flags", [False, True])
+def test_mlp_embed_sgd_update(D, M, B, n_cat, dt, flags):
+    """trs_mlp_embed_sgd_update: every embedding table of an MLP step from d x0 in two launches — W[row] -= lr * (sum of
+    the row's d x0 segments), the user's two passes merged, duplicate-free references (flags) as plain read-modify-writes,
+    metadata tables by owner-computes LDS sums — against the float64 scatter-add of the same (bf16-rounded) d x0."""
+    ops = _ops()
+    rs = np.random.RandomState(D + M + B)
+    NU, NI, lr = 500, 300, 0.37
+    F = 2 + M
+    user = rs.randint(0, NU, B).astype(np.int64)
+    pos = (rs.zipf(1.5, B) % NI).astype(np.int64)   # hot items: duplicates inside the batch
+    neg = rs.randint(0, NI, B).astype(np.int64)
+    user[:5] = user[5:10]                            # duplicated users too
+    pm = rs.randint(0, max(n_cat, 1), (B, M)).astype(np.int64)
+    nm = rs.randint(0, max(n_cat, 1), (B, M)).astype(np.int64)
+    if M:
+        pm[:, 0] = np.minimum(pm[:, 0], n_cat - 1)
+        pm[:3, 0], nm[:3, 0] = n_cat - 1, 0          # first / last category
+    tabs = [rs.normal(0, 1, (n, D)).astype(np.float32) for n in [NU, NI] + [n_cat] * M]
+    dx = rs.normal(0, 1, (2 * B, F * D + 8)).astype(np.float32)   # row stride wider than the F blocks
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    tdx = d(dx)
+    if dt == "bf16":
+        tdx = tdx.to(torch.bfloat16)
+        dx = tdx.float().cpu().numpy()
+    want = [t.astype(np.float64) for t in tabs]
+    np.add.at(want[0], user, -lr * (dx[:B, :D].astype(np.float64) + dx[B:, :D]))
+    np.add.at(want[1], pos, -lr * dx[:B, D:2 * D].astype(np.float64))
+    np.add.at(want[1], neg, -lr * dx[B:, D:2 * D].astype(np.float64))
+    for m in range(M):
+        np.add.at(want[2 + m], pm[:, m], -lr * dx[:B, (2 + m) * D:(3 + m) * D].astype(np.float64))
+        np.add.at(want[2 + m], nm[:, m], -lr * dx[B:, (2 + m) * D:(3 + m) * D].astype(np.float64))
+    ttabs = [d(t.copy()) for t in tabs]
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    T, keep = ops.make_tables(ttabs[0], ttabs[1], None, None, ttabs[2:], [])
+    ids = [d(user), d(pos), d(neg)] + ([d(pm), d(nm)] if M else [None, None])
+    Bt, keep2 = ops.make_batch(*ids, err)
+    assert ops.mlp_embed_sgd_supported(T)
+    ud = idp = None
+    if flags:
+        ud = d((np.bincount(user, minlength=NU)[user] > 1).astype(np.uint8))
+        cnt = np.bincount(np.concatenate([pos, neg]), minlength=NI)
+        idp = d(np.stack([cnt[pos] > 1, cnt[neg] > 1], 1).astype(np.uint8))
+    ops.mlp_embed_sgd_update(T, Bt, tdx, lr, ud, idp)
+    torch.cuda.synchronize()
+    assert err.item() == 0
+    for k, (got, w) in enumerate(zip(ttabs, want)):
+        assert np.abs(got.cpu().numpy() - w).max() < 1e-5 * max(1.0, np.abs(w).max()) * 8, k
+    # an id outside its table: skipped and flagged
+    bad = d(np.full(B, NU + 3, dtype=np.int64))
+    Bt2, keep3 = ops.make_batch(bad, ids[1], ids[2], ids[3], ids[4], err)
+    before = ttabs[0].clone()
+    ops.mlp_embed_sgd_update(T, Bt2, tdx, lr)
+    torch.cuda.synchronize()
+    assert err.item() == 1 and torch.equal(ttabs[0], before)
+
+
+def test_mlp_embed_sgd_update_refuses_what_it_cannot_do():
+    ops = _ops()
+    big = torch.zeros((300_000, 256), device=DEV)
+    small = torch.zeros((10, 256), device=DEV)
+    T, keep = ops.make_tables(small, small, None, None, [big, big, big], [])
+    assert not ops.mlp_embed_sgd_supported(T)       # 300 K categories x 3 columns: the per-table scatter's job
+    T2, keep2 = ops.make_tables(torch.zeros((10, 6), device=DEV), torch.zeros((10, 6), device=DEV))
+    assert not ops.mlp_embed_sgd_supported(T2)      # D % 4 != 0
+
+
 @pytest.mark.parametrize("B,H", [(64, 32), (1000, 130), (5000, 7), (256, 512)])
 @pytest.mark.parametrize("passes", [1, 2])
 def test_bn_stats_forward_backward(B, H, passes):

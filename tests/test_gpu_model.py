@@ -247,8 +247,11 @@ def test_g4_end_to_end_fit_evaluate_predict(net_type, dyn, fixture):
     is_mlp = net_type == "mlp"
     # printed with 4 decimals.  The MLP trajectory (BatchNorm, 156 steps) amplifies summation-order differences — the
     # reference itself differs between 1 and 8 BLAS threads, and the numpy oracle deviates from the
-    # golden run by the same 1% (tests/test_oracle_golden.py::test_g4_oracle_end_to_end) — so it is held to 3e-4 (losses) / 0.2 (weights, max-norm; oracle-vs-golden is 0.1).
-    assert losses == pytest.approx(list(g["epoch_losses"]), abs=3e-4 if is_mlp else 1.01e-4)
+    # golden run by the same 1% (tests/test_oracle_golden.py::test_g4_oracle_end_to_end).  The float atomics of the
+    # embedding update make the trajectory differ from run to run as well: six runs of the g4m dynamic case (two update
+    # kernels x three repeats) printed second-epoch losses 0.9890 .. 0.9896 around the golden 0.9892 — so the MLP is held
+    # to 6e-4 (losses) / 0.2 (weights, max-norm; oracle-vs-golden is 0.1).
+    assert losses == pytest.approx(list(g["epoch_losses"]), abs=6e-4 if is_mlp else 1.01e-4)
     for k, v in sub(g, "final").items():
         if v.dtype != np.float32:
             assert int(final[k]) == int(v), k  # BatchNorm num_batches_tracked: two per step

@@ -724,6 +724,203 @@ __global__ __launch_bounds__(TRS_BLOCK) void colsum_partial_v4_kernel(const floa
 
 static int n_chunks_of(int64_t rows) { return (int)((rows + CHUNK_ROWS - 1) / CHUNK_ROWS); }
 
+// ------------------------------------------------------------------------------------------- embedding update
+// SGD on the embedding rows of an MLP step straight from d x0 (rows [0,B): positive pass, [B,2B): negative pass; column
+// block f = field f).  Two launches instead of one float-atomic scatter per table:
+//   user / item   one wave turn per (triple, user | positive item | negative item): the user's two passes are added
+//                 in registers (one row update instead of two); rows the duplicate flags call alone in the batch get a
+//                 plain read-modify-write, the others float atomics.
+//   metadata      few rows, many references each (10 K categories for 65 536 references per column at c5): every
+//                 workgroup OWNS a range of categories of every column, scans the batch's metadata ids once (L2), adds
+//                 the d x0 segments of the references that name its categories in LDS and applies each owned row once,
+//                 atomic-free — the table rows are read and written once per step instead of once per reference.
+struct EmbUpdArgs {
+  trs_tables T;
+  trs_batch Bt;
+  const float* dx;            // fp32 d x0 or NULL
+  const unsigned short* dx16; // bf16 d x0 or NULL
+  int64_t ld;
+  float lr;
+  const uint8_t* udup;  // per triple: 1 = the user has another reference in the batch (NULL: atomics everywhere)
+  const uint8_t* idup;  // per triple x {pos, neg}
+  int cats_per_wg;
+};
+
+template <bool DX16>
+__device__ __forceinline__ float4 ld_dx4(const EmbUpdArgs& a, int64_t off) {
+  if (DX16) {
+    const uint2 v = *reinterpret_cast<const uint2*>(a.dx16 + off);
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xFFFF0000u), __uint_as_float(v.y << 16),
+                       __uint_as_float(v.y & 0xFFFF0000u));
+  }
+  return *reinterpret_cast<const float4*>(a.dx + off);
+}
+template <bool DX16>
+__device__ __forceinline__ float ld_dx1(const EmbUpdArgs& a, int64_t off) {
+  return DX16 ? __uint_as_float((uint32_t)a.dx16[off] << 16) : a.dx[off];
+}
+
+// one wave per (triple, user | positive item | negative item) turn: a row of D floats, lane = element (stride 64) —
+// float atomics want consecutive lanes on consecutive addresses (one 256-byte request per instruction; four 16-byte-strided
+// atomics per lane measured 2.7x slower), and so does the plain read-modify-write of a row that is alone in the batch
+template <typename IdT, bool DX16>
+__global__ __launch_bounds__(TRS_BLOCK) void mlp_embed_user_item_kernel(const EmbUpdArgs a) {
+  const trs_tables& T = a.T;
+  const int D = T.D;
+  const int64_t B = a.Bt.B;
+  const IdT* uid = (const IdT*)a.Bt.user;
+  const IdT* pid = (const IdT*)a.Bt.pos;
+  const IdT* nid = (const IdT*)a.Bt.neg;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x) >> 6;
+  const int64_t nwave = ((int64_t)gridDim.x * TRS_BLOCK) >> 6;
+  for (int64_t seg = wave; seg < 3 * B; seg += nwave) {
+    const int64_t t = seg / 3;
+    const int w = (int)(seg - t * 3);  // 0 user, 1 positive item, 2 negative item
+    const IdT* ids = w == 0 ? uid : (w == 1 ? pid : nid);
+    const int64_t id = (int64_t)ids[t];
+    float* tab = w == 0 ? T.user : T.item;
+    const int64_t n_rows = w == 0 ? T.n_users : T.n_items;
+    if ((uint64_t)id >= (uint64_t)n_rows) {
+      if (lane == 0 && a.Bt.err_flag_dev) atomicOr(a.Bt.err_flag_dev, 1);
+      continue;
+    }
+    const bool alone = w == 0 ? (a.udup && a.udup[t] == 0) : (a.idup && a.idup[2 * t + (w - 1)] == 0);
+    const int64_t r1 = (w == 2 ? B + t : t) * a.ld + (w == 0 ? 0 : D);  // first (only) d x0 segment
+    const int64_t r2 = (B + t) * a.ld;                                   // the user's negative-pass segment
+    float* dst = tab + id * (int64_t)D;
+    for (int d = lane; d < D; d += TRS_WAVE) {
+      float g = ld_dx1<DX16>(a, r1 + d);
+      if (w == 0) g += ld_dx1<DX16>(a, r2 + d);
+      if (alone) dst[d] -= a.lr * g;
+      else atomicAdd(dst + d, -a.lr * g);
+    }
+  }
+}
+
+constexpr int EMB_META_THREADS = 1024, EMB_U = 16, EMB_LIST = 256;
+constexpr int EMB_ACC_BYTES = 124 * 1024;  // LDS for the gradient sums (+ 32 KB of per-wave reference lists)
+template <typename IdT, bool DX16>
+__global__ __launch_bounds__(EMB_META_THREADS) void mlp_embed_meta_kernel(const EmbUpdArgs a) {
+  // LDS: [M][C][D] gradient sums | [M][C] touched | per wave: EMB_LIST x {d x0 row, (column << 24) | owned row} | counters.
+  // LDS float atomics run at ~2 cycles per LANE on gfx950 (measured here: 214 of 500 us), so the sums are plain
+  // read-modify-writes: every owned row belongs to ONE wave (row % 16) and references are routed to their row's wave
+  // through per-wave lists (integer LDS atomics, one per matching reference).
+  extern __shared__ float emb_acc[];
+  const trs_tables& T = a.T;
+  const int D = T.D, M = T.M, C = a.cats_per_wg;
+  const int B = (int)a.Bt.B;
+  constexpr int NW = EMB_META_THREADS / TRS_WAVE;
+  int* touched = reinterpret_cast<int*>(emb_acc + (int64_t)M * C * D);
+  int* lists = touched + M * C;            // [NW][2][EMB_LIST]
+  int* counts = lists + NW * 2 * EMB_LIST;  // [NW] entries appended in this window, [NW] = overflow flag
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < M * C * D; i += EMB_META_THREADS) emb_acc[i] = 0.f;
+  for (int i = threadIdx.x; i < M * C; i += EMB_META_THREADS) touched[i] = 0;
+  if (threadIdx.x <= NW) counts[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t c0 = (int64_t)blockIdx.x * C;  // first owned category (of every column)
+  const int chunks = D >> 2;
+  const IdT* pm_ids = (const IdT*)a.Bt.pos_meta;
+  const IdT* nm_ids = (const IdT*)a.Bt.neg_meta;
+  const uint32_t half = (uint32_t)B * (uint32_t)M, total = 2u * half;  // the two (B, M) id matrices, flat
+  const uint32_t magic = (uint32_t)(0x100000000ull / (uint32_t)M) + 1u;  // q / M = umulhi(q, magic) for q < 2^32 / M (M > 1)
+  uint32_t start = 0, span = EMB_META_THREADS * EMB_U;
+  while (start < total) {  // (workgroup-uniform) windows of flat id positions
+    // ---- scan: every workgroup reads ALL metadata ids of the batch (coalesced, EMB_U loads in flight per lane, none
+    // inside a conditional block: a block that holds a load ends in s_waitcnt vmcnt(0)) and routes its own
+    const uint32_t end = start + span < total ? start + span : total;
+    int64_t cat[EMB_U];
+#pragma unroll
+    for (int k = 0; k < EMB_U; ++k) {
+      uint32_t q = start + k * EMB_META_THREADS + threadIdx.x;
+      q = q < total ? q : total - 1;
+      const IdT* src = q < half ? pm_ids + q : nm_ids + (q - half);
+      cat[k] = (int64_t)*src;
+    }
+#pragma unroll
+    for (int k = 0; k < EMB_U; ++k) {
+      const uint32_t q = start + k * EMB_META_THREADS + threadIdx.x;
+      if (q < end) {
+        const uint32_t qq = q < half ? q : q - half;
+        const uint32_t r = M == 1 ? qq : __umulhi(qq, magic);
+        const int m = (int)(qq - r * (uint32_t)M);
+        if ((uint64_t)cat[k] >= (uint64_t)T.n_meta[m]) {
+          if (blockIdx.x == 0 && a.Bt.err_flag_dev) atomicOr(a.Bt.err_flag_dev, 1);
+        } else if (cat[k] >= c0 && cat[k] < c0 + C) {
+          const int own = m * C + (int)(cat[k] - c0);
+          const int ow = own % NW;
+          const int at = atomicAdd(&counts[ow], 1);
+          if (at < EMB_LIST) {
+            lists[(ow * 2 + 0) * EMB_LIST + at] = (int)((q < half ? 0u : (uint32_t)B) + r);
+            lists[(ow * 2 + 1) * EMB_LIST + at] = (m << 24) | own;
+          } else {
+            counts[NW] = 1;  // a list is full: the window is scanned again at half the span (nothing was added yet)
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const bool overflow = counts[NW] != 0;
+    const int n_list = overflow ? 0 : counts[wave];
+    // ---- add: each wave sums the d x0 segments of ITS rows' references, four row loads in flight, plain LDS adds
+    const int* list_row = lists + (wave * 2 + 0) * EMB_LIST;
+    const int* list_own = lists + (wave * 2 + 1) * EMB_LIST;
+    for (int i = 0; i < n_list; i += 4) {
+      float4 g[4];
+      int own[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = i + k < n_list ? i + k : n_list - 1;
+        const int packed = list_own[e];
+        own[k] = packed & 0xFFFFFF;
+        const int c = lane < chunks ? lane : 0;
+        g[k] = ld_dx4<DX16>(a, (int64_t)list_row[e] * a.ld + (int64_t)(2 + (packed >> 24)) * D + 4 * c);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (i + k < n_list && lane < chunks) {
+          float4* acc = reinterpret_cast<float4*>(emb_acc + (int64_t)own[k] * D) + lane;
+          float4 v = *acc;
+          v.x += g[k].x; v.y += g[k].y; v.z += g[k].z; v.w += g[k].w;
+          *acc = v;
+        }
+      }
+      for (int c = lane + TRS_WAVE; c < chunks; c += TRS_WAVE)  // (D > 256: the rest of the row, one entry at a time)
+        for (int k = 0; k < 4 && i + k < n_list; ++k) {
+          const int packed = list_own[i + k];
+          const float4 gg = ld_dx4<DX16>(a, (int64_t)list_row[i + k] * a.ld + (int64_t)(2 + (packed >> 24)) * D + 4 * c);
+          float4* acc = reinterpret_cast<float4*>(emb_acc + (int64_t)own[k] * D) + c;
+          float4 v = *acc;
+          v.x += gg.x; v.y += gg.y; v.z += gg.z; v.w += gg.w;
+          *acc = v;
+        }
+    }
+    for (int e = lane; e < n_list; e += TRS_WAVE) touched[list_own[e] & 0xFFFFFF] = 1;
+    __syncthreads();  // lists and counters are free again
+    if (threadIdx.x <= NW) counts[threadIdx.x] = 0;
+    if (overflow) {
+      span = span > 2 * EMB_LIST ? span / 2 : EMB_LIST;  // <= EMB_LIST positions always fit
+    } else {
+      start = end;
+      if (span < EMB_META_THREADS * EMB_U) span *= 2;
+    }
+    __syncthreads();
+  }
+  for (int row = wave; row < M * C; row += NW) {  // one owned row per wave turn: a plain read-modify-write
+    if (!touched[row]) continue;
+    const int m = row / C, lc = row - m * C;
+    float* dst = T.meta[m] + (c0 + lc) * (int64_t)D;
+    const float* acc = emb_acc + (int64_t)row * D;
+    for (int c = lane; c < chunks; c += TRS_WAVE) {
+      float4 v = *reinterpret_cast<float4*>(dst + 4 * c);
+      const float4 g = *reinterpret_cast<const float4*>(acc + 4 * c);
+      v.x -= a.lr * g.x; v.y -= a.lr * g.y; v.z -= a.lr * g.z; v.w -= a.lr * g.w;
+      *reinterpret_cast<float4*>(dst + 4 * c) = v;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int trs_mlp_gather_concat(const trs_tables* tables, const trs_batch* batch, int32_t passes, float* x_dev,
@@ -949,5 +1146,94 @@ extern "C" int trs_outer(const float* g_dev, const float* w_dev, int64_t rows, i
   hipLaunchKernelGGL(outer_kernel, dim3(trs_grid(rows * H, TRS_BLOCK)), dim3(TRS_BLOCK), 0, (hipStream_t)stream, g_dev,
                      w_dev, rows, H, dx_dev, ld);
   TRS_CHECK_LAUNCH("outer_kernel");
+  return TRS_OK;
+}
+
+// owned categories per workgroup of mlp_embed_meta_kernel: as many as 128 KB of LDS accumulators hold, but no fewer
+// workgroups than CUs; every workgroup scans all metadata ids of the batch, so the form stops paying beyond ~1000 of them
+static bool embed_meta_plan(const trs_tables* tables, int64_t* cats_per_wg, int64_t* wgs) {
+  const int D = tables->D, M = tables->M;
+  int64_t max_cat = 0;
+  for (int m = 0; m < M; ++m) max_cat = tables->n_meta[m] > max_cat ? tables->n_meta[m] : max_cat;
+  if (M == 0 || max_cat <= 0) return false;
+  const int64_t c_lds = EMB_ACC_BYTES / ((int64_t)M * (D * 4 + 4));
+  int64_t c = (max_cat + 255) / 256;
+  if (c > c_lds) c = c_lds;
+  if (c < 1) return false;
+  *cats_per_wg = c;
+  *wgs = (max_cat + c - 1) / c;
+  return *wgs <= 1024;
+}
+
+extern "C" int trs_mlp_embed_sgd_update_supported(const trs_tables* tables) {
+  if (!tables || tables->D <= 0 || tables->D % 4 != 0 || tables->M < 0 || tables->M > TRS_MAX_META) return 0;
+  int64_t c, w;
+  return tables->M == 0 || embed_meta_plan(tables, &c, &w) ? 1 : 0;
+}
+
+// SGD update of every embedding table of an MLP step from d x0 (fp32 or bf16; (2B, ld), column block f = field f):
+// see mlp_embed_user_item_kernel / mlp_embed_meta_kernel.  user_dup_flags (B) / item_dup_flags (B, 2) are optional
+// (trs_epoch_flags / trs_epoch_presort produce them): NULL = float atomics for every user / item reference.
+extern "C" int trs_mlp_embed_sgd_update(const trs_tables* tables, const trs_batch* batch, const float* dx0_dev,
+                                        const void* dx0_bf16_dev, int64_t ld, float lr,
+                                        const uint8_t* user_dup_flags_dev, const uint8_t* item_dup_flags_dev,
+                                        void* stream) {
+  TRS_REQUIRE(tables && batch && ((dx0_dev != nullptr) != (dx0_bf16_dev != nullptr)),
+              "trs_mlp_embed_sgd_update: NULL argument (exactly one of dx0_dev / dx0_bf16_dev)");
+  TRS_REQUIRE(tables->M >= 0 && tables->M <= TRS_MAX_META && tables->user && tables->item,
+              "trs_mlp_embed_sgd_update: bad tables");
+  TRS_REQUIRE(tables->D > 0 && tables->D % 4 == 0 && ld % 4 == 0 && ld >= (int64_t)(2 + tables->M) * tables->D,
+              "trs_mlp_embed_sgd_update: needs D and ld multiples of 4, ld >= (2 + M) * D");
+  TRS_REQUIRE(((uintptr_t)(dx0_dev ? (const void*)dx0_dev : dx0_bf16_dev) & 15) == 0,
+              "trs_mlp_embed_sgd_update: d x0 must be 16-byte aligned");
+  TRS_REQUIRE(batch->idx_bytes == 4 || batch->idx_bytes == 8, "trs_mlp_embed_sgd_update: idx_bytes must be 4 or 8");
+  if (batch->B == 0) return TRS_OK;
+  TRS_REQUIRE(batch->B < ((int64_t)1 << 30) && 2 * batch->B * tables->M * tables->M < ((int64_t)1 << 32),
+              "trs_mlp_embed_sgd_update: batch too large");
+  TRS_REQUIRE(batch->user && batch->pos && batch->neg, "trs_mlp_embed_sgd_update: ids are NULL");
+  TRS_REQUIRE(tables->M == 0 || (batch->pos_meta && batch->neg_meta), "trs_mlp_embed_sgd_update: metadata ids NULL");
+  for (int m = 0; m < tables->M; ++m) TRS_REQUIRE(tables->meta[m], "trs_mlp_embed_sgd_update: metadata table %d NULL", m);
+  EmbUpdArgs a = {};
+  a.T = *tables;
+  a.Bt = *batch;
+  a.dx = dx0_dev;
+  a.dx16 = (const unsigned short*)dx0_bf16_dev;
+  a.ld = ld;
+  a.lr = lr;
+  a.udup = user_dup_flags_dev;
+  a.idup = item_dup_flags_dev;
+  hipStream_t s = (hipStream_t)stream;
+  const int D = tables->D, M = tables->M;
+  const dim3 grid_ui(trs_grid(batch->B * 3, TRS_BLOCK / TRS_WAVE));
+  const bool i64 = batch->idx_bytes == 8, b16 = dx0_bf16_dev != nullptr;
+#define TRS_EMB(KERNEL, GRID, BLOCK, LDS)                                                            \
+  {                                                                                                  \
+    if (i64 && b16) hipLaunchKernelGGL((KERNEL<int64_t, true>), GRID, BLOCK, LDS, s, a);             \
+    else if (i64) hipLaunchKernelGGL((KERNEL<int64_t, false>), GRID, BLOCK, LDS, s, a);              \
+    else if (b16) hipLaunchKernelGGL((KERNEL<int32_t, true>), GRID, BLOCK, LDS, s, a);               \
+    else hipLaunchKernelGGL((KERNEL<int32_t, false>), GRID, BLOCK, LDS, s, a);                       \
+  }
+  TRS_EMB(mlp_embed_user_item_kernel, grid_ui, dim3(TRS_BLOCK), 0)
+  TRS_CHECK_LAUNCH("mlp_embed_user_item_kernel");
+  if (M == 0) return TRS_OK;
+  int64_t c, wgs;
+  TRS_REQUIRE(embed_meta_plan(tables, &c, &wgs),
+              "trs_mlp_embed_sgd_update: metadata tables too large for the owner-computes update (ask "
+              "trs_mlp_embed_sgd_update_supported first and scatter per table with trs_rows_scatter_add)");
+  a.cats_per_wg = (int)c;
+  const size_t lds = (size_t)M * c * (D * 4 + 4) + (size_t)(EMB_META_THREADS / TRS_WAVE) * 2 * EMB_LIST * 4 +
+                     (size_t)(EMB_META_THREADS / TRS_WAVE + 1) * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    const int cap = 160 * 1024 - 1024;
+    (void)hipFuncSetAttribute((const void*)mlp_embed_meta_kernel<int64_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute((const void*)mlp_embed_meta_kernel<int64_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute((const void*)mlp_embed_meta_kernel<int32_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute((const void*)mlp_embed_meta_kernel<int32_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    attr_done = true;
+  }
+  TRS_EMB(mlp_embed_meta_kernel, dim3((unsigned)wgs), dim3(EMB_META_THREADS), lds)
+#undef TRS_EMB
+  TRS_CHECK_LAUNCH("mlp_embed_meta_kernel");
   return TRS_OK;
 }

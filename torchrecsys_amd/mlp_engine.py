@@ -109,7 +109,7 @@ class MLPCompute:
             x = torch.empty((rows, net.input_shape), dtype=torch.float32, device=dev)
             ops.mlp_gather_concat(net.tables(), Bt, passes, x)
         ctx = {"ids": ids, "B": B, "passes": passes, "x": [x], "y": [], "mean": [], "var": [], "training": training,
-               "resident": res}
+               "resident": res, "Bt": (Bt, keep)}
         for l in range(L):
             fc = net.fcs[l]
             # train-mode BN: the batch statistics come out of the GEMM epilogue (one partial per 128-row tile) when no
@@ -325,12 +325,15 @@ class MLPTrainer:
         grads, dx0 = net.compute.backward(ctx, g, grad_of=self.bucket.grad_of,
                                           on_group_done=(lambda i: works.append(
                                               self.bucket.allreduce_segment_async(self.segs[i]))) if dp else None)
-        idx_user = torch.cat([ids["user"], ids["user"]])
-        idx_item = torch.cat([ids["pos"], ids["neg"]])
-        tables = [(net.user.weight, idx_user, 0), (net.item.weight, idx_item, 1)]
-        for m in range(M):
-            tables.append((net.metadata_embeddings[m].weight,
-                           torch.cat([ids["pos_meta"][:, m], ids["neg_meta"][:, m]]).contiguous(), 2 + m))
+        fused_lr = self._fused_embed_lr() if self.kind == "sgd" else None
+        tables = []
+        if fused_lr is None:  # per-table paths: one index vector per table over the 2B rows of d x0
+            idx_user = torch.cat([ids["user"], ids["user"]])
+            idx_item = torch.cat([ids["pos"], ids["neg"]])
+            tables = [(net.user.weight, idx_user, 0), (net.item.weight, idx_item, 1)]
+            for m in range(M):
+                tables.append((net.metadata_embeddings[m].weight,
+                               torch.cat([ids["pos_meta"][:, m], ids["neg_meta"][:, m]]).contiguous(), 2 + m))
         ld = dx0.stride(0)
         if self.kind == "generic":
             opt.zero_grad()
@@ -343,7 +346,11 @@ class MLPTrainer:
             p.grad = self.bucket.grad_of(p)
         # ---- embedding tables: fused sparse-row updates from the column blocks of d x0 (independent of the dense
         # gradients still being reduced)
-        if self.kind == "sgd":
+        if fused_lr is not None:
+            # all tables in two launches: user / item rows (the user's two passes summed in registers; references the
+            # epoch's duplicate flags call alone are plain read-modify-writes) + the owner-computes metadata update
+            ops.mlp_embed_sgd_update(net.tables(), ctx["Bt"][0], dx0, fused_lr, ids.get("user_dup"), ids.get("item_dup"))
+        elif self.kind == "sgd":
             for p, idx, f in tables:
                 ops.rows_scatter_add(p.data, idx, dx0[:, f * D:], -_group_of(opt, p)["lr"], ld=ld, err_flag=self.err)
         elif self.kind in ("sparse_adam", "adagrad"):
@@ -351,6 +358,20 @@ class MLPTrainer:
                 self._rows(p, idx, dx0[:, f * D:], ld)
         self.bucket.finish_segments(works)
         opt.step()
+
+    def _fused_embed_lr(self):
+        """The one learning rate of the fused embedding update, or None when it does not apply (tables in parameter
+        groups with different rates, n_factors not a multiple of 4, metadata tables too large for the owner-computes
+        kernel, or TRS_MLP_FUSED_EMBED=0)."""
+        import os
+        if os.environ.get("TRS_MLP_FUSED_EMBED", "1") == "0":
+            return None
+        lrs = {float(_group_of(self.opt, p)["lr"]) for p in self.emb_params}
+        if len(lrs) != 1 or self.net.n_factors % 4 != 0:
+            return None
+        if getattr(self, "_fused_ok", None) is None:
+            self._fused_ok = ops.mlp_embed_sgd_supported(self.net.tables())
+        return lrs.pop() if self._fused_ok else None
 
     def _rows(self, p, idx, vals, ld):
         apply_rows(self.kind, self.opt, p, self.row_state[id(p)], idx, vals, ld)

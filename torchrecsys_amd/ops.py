@@ -467,6 +467,21 @@ def mlp_gather_concat(T, Bt, passes, x=None, x16=None):
           "trs_mlp_gather_concat")
 
 
+def mlp_embed_sgd_supported(T):
+    return bool(_lib.load().trs_mlp_embed_sgd_update_supported(C.byref(T)))
+
+
+def mlp_embed_sgd_update(T, Bt, dx0, lr, user_dup=None, item_dup=None):
+    """Embedding-row SGD of an MLP step from d x0 ((2B, ld) fp32 or bfloat16): user / item rows (+ optional duplicate
+    flags: unflagged references are plain read-modify-writes) and the owner-computes metadata update."""
+    f32 = dx0 if dx0.dtype == torch.float32 else None
+    b16 = dx0 if dx0.dtype == torch.bfloat16 else None
+    if f32 is None and b16 is None:
+        raise TypeError(f"mlp_embed_sgd_update: d x0 must be float32 or bfloat16, got {dx0.dtype}")
+    check(_lib.load().trs_mlp_embed_sgd_update(C.byref(T), C.byref(Bt), ptr(f32), ptr(b16), dx0.stride(0), float(lr),
+                                               ptr(user_dup), ptr(item_dup), _stream()), "trs_mlp_embed_sgd_update")
+
+
 _gemm_ws = {}
 
 
