@@ -357,7 +357,8 @@ def main():
         fl = sum(f for _, _, f in gemm_events)
         ach = fl / (ms * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[dtype]
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16in_kernel" if cfg["amp"] else "gemm_f32_kernel",
+        out["roofline"] = {"bound": "mfma", "kernel": ("gemm16_nt_glds_kernel (forward / input-gradient GEMMs) + gemm_bf16in_kernel (weight-gradient GEMMs)"
+                                      if cfg["amp"] else "gemm_f32_kernel"),
                            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                            "gemm_launches_per_step": len(gemm_events) / timed_steps,
                            "gemm_ms_per_step": ms / timed_steps,

@@ -148,6 +148,86 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm16_nt_kernel(const u16* __res
   }
 }
 
+// Ping-pong variant: the two wave rows (wm = 0 / 1: one wave of each per SIMD) run half a phase apart — while one row's
+// 16 MFMAs of a 32-deep half tile run, the other row reads its fragments (and issues the LDS-DMA of the next tile).
+// Raw s_barrier + explicit waitcnt (a __syncthreads() would drain the LDS-DMA at every barrier).
+template <bool PRIO>
+__global__ __launch_bounds__(512) void gemm16_nt_pp_kernel(const u16* __restrict__ A, const u16* __restrict__ B,
+                                                           float* __restrict__ C, u16* __restrict__ C16, int64_t M,
+                                                           int64_t N, int64_t K, int gx) {
+  constexpr int NWAVES = 8, TM = 128, TN = 64, MI = 4, NI = 2;
+  __shared__ __attribute__((aligned(1024))) char lds[4 * TILE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  int64_t lid = blockIdx.x;
+  const int64_t nwg = gridDim.x;
+  if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);
+  const int bx = (int)(lid % gx), by = (int)(lid / gx);
+  const int64_t m0 = (int64_t)by * BMT, n0 = (int64_t)bx * BNT;
+  const int nk = (int)(K / BKT);
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int lr = lane & 31, lk = lane >> 5;
+  const int f = (lr >> 1) & 7;
+#define BAR() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+  stage_tile<NWAVES, 1>(A, K, m0, 0, lds, wave, lane);
+  stage_tile<NWAVES, 1>(B, K, n0, 0, lds + TILE_BYTES, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  BAR();
+  if (wm == 1) BAR();  // stagger: row 1 runs half a phase behind row 0
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const char* ta = lds + cur * 2 * TILE_BYTES + (wm * TM + lr) * 128;
+    const char* tb = lds + cur * 2 * TILE_BYTES + TILE_BYTES + (wn * TN + lr) * 128;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      bf16x8 a[2][MI], b[2][NI];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int sw = (((2 * h + q) * 2 + lk) ^ f) << 4;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[q][i] = *reinterpret_cast<const bf16x8*>(ta + i * 32 * 128 + sw);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) b[q][j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 128 + sw);
+      }
+      if (h == 0 && kt + 1 < nk) {
+        stage_tile<NWAVES, 1>(A, K, m0, (int64_t)(kt + 1) * BKT, lds + (cur ^ 1) * 2 * TILE_BYTES, wave, lane);
+        stage_tile<NWAVES, 1>(B, K, n0, (int64_t)(kt + 1) * BKT, lds + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES, wave, lane);
+      }
+      if (h == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      BAR();
+      if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q][i], b[q][j], acc[i][j], 0, 0, 0);
+      if (PRIO) __builtin_amdgcn_s_setprio(0);
+      BAR();
+    }
+  }
+  if (wm == 0) BAR();
+#undef BAR
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int64_t col = n0 + wn * TN + j * 32 + lr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        C16[row * N + col] = __builtin_bit_cast(u16, (__bf16)acc[i][j][r]);
+      }
+    }
+}
+
 static u16 f2bf(float f) {
   unsigned u; memcpy(&u, &f, 4);
   u += 0x7FFFu + ((u >> 16) & 1u);
@@ -204,12 +284,24 @@ int main(int argc, char** argv) {
              (long long)K, NAME, ms * 1e3, 2.0 * M * N * K / ms / 1e9, w, w <= 1.0 ? "ok" : "WRONG",           \
              hipGetErrorString(hipGetLastError()));                                                           \
     }
-    RUN("8w 128x64 32x32 swz0", 2, 4, true, 0, false)
     RUN("8w 128x64 32x32 swz1", 2, 4, true, 1, false)
     RUN("8w 128x64 16x16 swz1", 2, 4, true, 1, true)
-    RUN("8w 128x64 16x16 swz1 f32", 2, 4, false, 1, true)
-    RUN("4w 128x128 32x32 swz1", 2, 2, true, 1, false)
-    RUN("4w 128x128 16x16 swz1", 2, 2, true, 1, true)
+#define RUNP(NAME, PRIO_)                                                                                      \
+    {                                                                                                         \
+      float ms = 0;                                                                                           \
+      hipMemset(dC16, 0, (size_t)M * N * 2);                                                                  \
+      for (int rep = 0; rep < 6; ++rep) {                                                                     \
+        if (rep == 1) hipEventRecord(e0);                                                                     \
+        hipLaunchKernelGGL((gemm16_nt_pp_kernel<PRIO_>), dim3(gx * gy), dim3(512), 0, 0, dA, dB, dC, dC16, M, N, K, gx); \
+      }                                                                                                       \
+      hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); ms /= 5;                 \
+      const double w = check(true);                                                                           \
+      printf("%-9s N=%4lld K=%4lld %-22s %8.1f us %7.1f TF   worst err/tol %.3f %s (%s)\n", sh.name, (long long)N, \
+             (long long)K, NAME, ms * 1e3, 2.0 * M * N * K / ms / 1e9, w, w <= 1.0 ? "ok" : "WRONG",           \
+             hipGetErrorString(hipGetLastError()));                                                           \
+    }
+    RUNP("ping-pong", false)
+    RUNP("ping-pong + setprio", true)
     hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dC16);
   }
   return 0;

@@ -1,6 +1,6 @@
 """Scratch: what the vendor library (torch.matmul -> hipBLASLt) reaches on the c5 / c3 GEMM shapes, beside trs_gemm_bf16in."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 dev = "cuda:0"
 def bench(f, n=20):

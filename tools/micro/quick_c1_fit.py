@@ -1,6 +1,6 @@
 """Scratch: end-to-end wall time of the reference-style flow at the c1 size (DataFrame in, fit() of 10 epochs)."""
 import os, sys, time, io, contextlib
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, pandas as pd, torch
 from torchrecsys_amd.model import TorchRecSys
 print("threads", torch.get_num_threads(), "cpu_count", os.cpu_count(), "affinity", len(os.sched_getaffinity(0)), flush=True)

@@ -2,7 +2,7 @@
 shape: a full 512-batch slice and short slices.  usage: python tools/quick_flags.py"""
 import os
 import sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from torchrecsys_amd import ops
 

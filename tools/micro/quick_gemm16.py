@@ -1,6 +1,6 @@
 """Scratch: bf16-resident GEMM rates (NT: fwd / dgrad with W^T image; TN: wgrad) at the c5 / c3 MLP shapes."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from torchrecsys_amd import ops
 dev = "cuda:0"

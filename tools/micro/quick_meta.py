@@ -1,6 +1,6 @@
 """Scratch: FM / Linear step time WITH one metadata column at the c2 shape (generic staged path)."""
 import os, sys, time, io, contextlib
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from torchrecsys_amd.model import TorchRecSys

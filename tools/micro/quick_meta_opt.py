@@ -1,7 +1,7 @@
 """Scratch: FM / Linear step time with one metadata column AND an adaptive rule at the c2 shape (presorted step with the
 rule fused in; TRS_META_FAST=0 in the environment gives the generic staged path for comparison)."""
 import os, sys, time, io, contextlib
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from torchrecsys_amd.model import TorchRecSys

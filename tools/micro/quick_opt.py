@@ -1,6 +1,6 @@
 """Scratch: c2 step time per optimiser (SGD fast path vs the generic staged path with SparseAdam / Adagrad)."""
 import os, sys, time, io, contextlib
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from torchrecsys_amd.model import TorchRecSys

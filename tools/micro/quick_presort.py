@@ -1,6 +1,6 @@
 """Scratch: standalone time of one presort slice at the c2 shape (512 batches of 65536 triples from the resident stream)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from torchrecsys_amd import ops
