@@ -228,6 +228,172 @@ __global__ __launch_bounds__(512) void gemm16_nt_pp_kernel(const u16* __restrict
     }
 }
 
+
+// pieces p of the next tile's 8 LDS-DMA instructions of a wave (0-3: A, 4-7: B)
+__device__ __forceinline__ void stage_piece(const u16* __restrict__ A, const u16* __restrict__ B, int64_t ld, int64_t m0,
+                                            int64_t n0, int64_t k0, char* lds_buf, int wave, int lane, int p) {
+  const bool isb = p >= 4;
+  const int piece = wave * 4 + (p & 3);
+  const int row = piece * 8 + (lane >> 3);
+  const u16* P = isb ? B : A;
+  const int64_t r0 = isb ? n0 : m0;
+  const u16* src = P + (r0 + row) * ld + k0 + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+  __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_buf + (isb ? TILE_BYTES : 0) + piece * 1024), 16, 0, 0);
+}
+
+// the one-barrier loop with the DMA issue moved behind / spread between the MFMA groups of the tile
+template <int SPREAD>
+__global__ __launch_bounds__(512) void gemm16_nt_spread_kernel(const u16* __restrict__ A, const u16* __restrict__ B,
+                                                               float* __restrict__ C, u16* __restrict__ C16, int64_t M,
+                                                               int64_t N, int64_t K, int gx) {
+  constexpr int NWAVES = 8, TM = 128, TN = 64, MI = 4, NI = 2;
+  __shared__ __attribute__((aligned(1024))) char lds[4 * TILE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  int64_t lid = blockIdx.x;
+  const int64_t nwg = gridDim.x;
+  if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);
+  const int bx = (int)(lid % gx), by = (int)(lid / gx);
+  const int64_t m0 = (int64_t)by * BMT, n0 = (int64_t)bx * BNT;
+  const int nk = (int)(K / BKT);
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int lr = lane & 31, lk = lane >> 5;
+  const int f = (lr >> 1) & 7;
+  stage_tile<NWAVES, 1>(A, K, m0, 0, lds, wave, lane);
+  stage_tile<NWAVES, 1>(B, K, n0, 0, lds + TILE_BYTES, wave, lane);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk;
+    char* nxt = lds + (cur ^ 1) * 2 * TILE_BYTES;
+    const int64_t kn = (int64_t)(kt + 1) * BKT;
+    const char* ta = lds + cur * 2 * TILE_BYTES + (wm * TM + lr) * 128;
+    const char* tb = lds + cur * 2 * TILE_BYTES + TILE_BYTES + (wn * TN + lr) * 128;
+#pragma unroll
+    for (int ks = 0; ks < BKT / 16; ++ks) {
+      const int sw = ((ks * 2 + lk) ^ f) << 4;
+      bf16x8 a[MI], b[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(ta + i * 32 * 128 + sw);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 128 + sw);
+      if (more) {
+        if (SPREAD == 1 && ks == 0) {
+#pragma unroll
+          for (int p = 0; p < 8; ++p) stage_piece(A, B, K, m0, n0, kn, nxt, wave, lane, p);
+        }
+        if (SPREAD == 2) {
+          stage_piece(A, B, K, m0, n0, kn, nxt, wave, lane, 2 * ks);
+          stage_piece(A, B, K, m0, n0, kn, nxt, wave, lane, 2 * ks + 1);
+        }
+        if (SPREAD == 3 && ks < 2) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p) stage_piece(A, B, K, m0, n0, kn, nxt, wave, lane, 4 * ks + p);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int64_t col = n0 + wn * TN + j * 32 + lr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        C16[row * N + col] = __builtin_bit_cast(u16, (__bf16)acc[i][j][r]);
+      }
+    }
+}
+
+// Ablations of the one-barrier loop (results are wrong by construction; only the time is read):
+//   MODE 1: no LDS-DMA in the loop (every k-tile re-reads tile 0)   MODE 2: DMA + barrier, no ds_read / MFMA
+//   MODE 3: DMA + ds_reads, no MFMA                                  MODE 4: MFMA only (fragments read once)
+template <int MODE>
+__global__ __launch_bounds__(512) void gemm16_nt_abl_kernel(const u16* __restrict__ A, const u16* __restrict__ B,
+                                                            float* __restrict__ C, u16* __restrict__ C16, int64_t M,
+                                                            int64_t N, int64_t K, int gx) {
+  constexpr int NWAVES = 8, TM = 128, TN = 64, MI = 4, NI = 2;
+  __shared__ __attribute__((aligned(1024))) char lds[4 * TILE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  int64_t lid = blockIdx.x;
+  const int64_t nwg = gridDim.x;
+  if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);
+  const int bx = (int)(lid % gx), by = (int)(lid / gx);
+  const int64_t m0 = (int64_t)by * BMT, n0 = (int64_t)bx * BNT;
+  const int nk = (int)(K / BKT);
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int lr = lane & 31, lk = lane >> 5;
+  const int f = (lr >> 1) & 7;
+  stage_tile<NWAVES, 1>(A, K, m0, 0, lds, wave, lane);
+  stage_tile<NWAVES, 1>(B, K, n0, 0, lds + TILE_BYTES, wave, lane);
+  bf16x8 a[MI], b[NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) a[i] = bf16x8{};
+#pragma unroll
+  for (int j = 0; j < NI; ++j) b[j] = bf16x8{};
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    const int cur = MODE == 1 ? 0 : (kt & 1);
+    if (MODE != 1 && MODE != 4 && kt + 1 < nk) {
+      stage_tile<NWAVES, 1>(A, K, m0, (int64_t)(kt + 1) * BKT, lds + (cur ^ 1) * 2 * TILE_BYTES, wave, lane);
+      if (MODE != 5) stage_tile<NWAVES, 1>(B, K, n0, (int64_t)(kt + 1) * BKT, lds + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES, wave, lane);
+      if (MODE == 6) stage_tile<NWAVES, 1>(B, K, n0, (int64_t)(kt + 1) * BKT, lds + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES, wave, lane);
+    }
+    const char* ta = lds + cur * 2 * TILE_BYTES + (wm * TM + lr) * 128;
+    const char* tb = lds + cur * 2 * TILE_BYTES + TILE_BYTES + (wn * TN + lr) * 128;
+#pragma unroll
+    for (int ks = 0; ks < BKT / 16; ++ks) {
+      const int sw = ((ks * 2 + lk) ^ f) << 4;
+      if (MODE != 2 && MODE != 5 && MODE != 6 && MODE != 7 && (MODE != 4 || kt == 0)) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(ta + i * 32 * 128 + sw);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 128 + sw);
+      }
+      if (MODE == 3) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[i][0][0] += (float)a[i][0];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[0][j][1] += (float)b[j][0];
+      } else if (MODE != 2 && MODE != 5 && MODE != 6) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int64_t col = n0 + wn * TN + j * 32 + lr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        C16[row * N + col] = __builtin_bit_cast(u16, (__bf16)acc[i][j][r]);
+      }
+    }
+}
+
 static u16 f2bf(float f) {
   unsigned u; memcpy(&u, &f, 4);
   u += 0x7FFFu + ((u >> 16) & 1u);
@@ -300,6 +466,41 @@ int main(int argc, char** argv) {
              (long long)K, NAME, ms * 1e3, 2.0 * M * N * K / ms / 1e9, w, w <= 1.0 ? "ok" : "WRONG",           \
              hipGetErrorString(hipGetLastError()));                                                           \
     }
+#define RUNA(NAME, MODE_)                                                                                      \
+    {                                                                                                         \
+      float ms = 0;                                                                                           \
+      for (int rep = 0; rep < 6; ++rep) {                                                                     \
+        if (rep == 1) hipEventRecord(e0);                                                                     \
+        hipLaunchKernelGGL((gemm16_nt_abl_kernel<MODE_>), dim3(gx * gy), dim3(512), 0, 0, dA, dB, dC, dC16, M, N, K, gx); \
+      }                                                                                                       \
+      hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); ms /= 5;                 \
+      printf("%-9s N=%4lld K=%4lld %-22s %8.1f us %7.1f TF-equivalent (%s)\n", sh.name, (long long)N,        \
+             (long long)K, NAME, ms * 1e3, 2.0 * M * N * K / ms / 1e9, hipGetErrorString(hipGetLastError())); \
+    }
+    RUNA("abl: no DMA in loop", 1)
+    RUNA("abl: DMA + barrier only", 2)
+    RUNA("abl: DMA + ds_read", 3)
+    RUNA("abl: MFMA only", 4)
+    RUNA("abl: DMA A only + barrier", 5)
+    RUNA("abl: DMA A + 2x B + barrier", 6)
+    RUNA("abl: DMA + MFMA, no ds_read", 7)
+#define RUNS2(NAME, SP_)                                                                                       \
+    {                                                                                                         \
+      float ms = 0;                                                                                           \
+      hipMemset(dC16, 0, (size_t)M * N * 2);                                                                  \
+      for (int rep = 0; rep < 6; ++rep) {                                                                     \
+        if (rep == 1) hipEventRecord(e0);                                                                     \
+        hipLaunchKernelGGL((gemm16_nt_spread_kernel<SP_>), dim3(gx * gy), dim3(512), 0, 0, dA, dB, dC, dC16, M, N, K, gx); \
+      }                                                                                                       \
+      hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); ms /= 5;                 \
+      const double w = check(true);                                                                           \
+      printf("%-9s N=%4lld K=%4lld %-22s %8.1f us %7.1f TF   worst err/tol %.3f %s (%s)\n", sh.name, (long long)N, \
+             (long long)K, NAME, ms * 1e3, 2.0 * M * N * K / ms / 1e9, w, w <= 1.0 ? "ok" : "WRONG",           \
+             hipGetErrorString(hipGetLastError()));                                                           \
+    }
+    RUNS2("DMA after 1st reads", 1)
+    RUNS2("DMA 2 per k-step", 2)
+    RUNS2("DMA 4+4 in k-steps 0,1", 3)
     RUNP("ping-pong", false)
     RUNP("ping-pong + setprio", true)
     hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dC16);

@@ -569,8 +569,8 @@ __global__ __launch_bounds__(BMT * BNT / 64) void gemm_bf16in_kernel(const Gemm1
 // array, not the matrix cores, set its pace).  No staging registers, no ds_write pass: each wave-instruction moves
 // 8 rows x 128 B (64 k of bf16) straight into LDS, lane-linear; the bank-conflict swizzle (16-B slot ^= (row >> 1) & 7,
 // which spreads every 16-lane group of a ds_read_b128 over the 16 slots of the 256-B bank row) is applied to the per-lane
-// SOURCE address and again on the fragment reads.  One barrier per k-tile: the loads of tile t+1 are issued right after
-// the barrier that publishes tile t and are awaited (vmcnt(0)) at the next one.  Measured against the 16-wave kernel at
+// SOURCE address and again on the fragment reads.  One barrier per k-tile: the loads of tile t+1 are issued during tile t's
+// k-steps (two DMA pieces per step) and awaited (vmcnt(0)) at the next barrier.  Measured against the 16-wave kernel at
 // the c5 shapes (65 536 rows): 1280 -> 1024: 182 us (944 TFLOP/s) against 221; 1024 -> 512: 73 against 96;
 // 512 -> 256: 24 against 37 (tools/micro/gemm16_bench.hip).
 // Epilogue: alpha * acc + bias -> fp32 or bf16 C; BatchNorm partial statistics per 128-row chunk = per wave row (every
@@ -589,6 +589,18 @@ __device__ __forceinline__ void g3_stage(const unsigned short* __restrict__ P, i
     const unsigned short* src = P + (row0 + row) * ld + k0 + ((slot ^ ((row >> 1) & 7)) << 3);
     __builtin_amdgcn_global_load_lds((g3_gptr)src, (g3_lptr)(lds_tile + piece * 1024), 16, 0, 0);
   }
+}
+
+// piece p (0-3: A, 4-7: B) of a wave's 8 DMA instructions for one k-tile
+__device__ __forceinline__ void g3_piece(const unsigned short* __restrict__ A, const unsigned short* __restrict__ B,
+                                         int64_t lda, int64_t ldb, int64_t m0, int64_t n0, int64_t k0, char* lds_buf,
+                                         int wave, int lane, int p) {
+  const bool isb = p >= 4;
+  const int piece = wave * 4 + (p & 3);
+  const int row = piece * 8 + (lane >> 3);
+  const unsigned short* src = (isb ? B + (n0 + row) * ldb : A + (m0 + row) * lda) + k0 +
+                              (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+  __builtin_amdgcn_global_load_lds((g3_gptr)src, (g3_lptr)(lds_buf + (isb ? G3_TILE : 0) + piece * 1024), 16, 0, 0);
 }
 
 template <bool OUT16>
@@ -616,10 +628,9 @@ __global__ __launch_bounds__(512) void gemm16_nt_glds_kernel(const Gemm16Args g)
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();  // (drains this wave's LDS-DMA: vmcnt(0)) tile kt is in LDS, tile kt - 1 has been read by everyone
     const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      g3_stage(g.A, g.lda, m0, (int64_t)(kt + 1) * BK2, lds + (cur ^ 1) * 2 * G3_TILE, wave, lane);
-      g3_stage(g.B, g.ldb, n0, (int64_t)(kt + 1) * BK2, lds + (cur ^ 1) * 2 * G3_TILE + G3_TILE, wave, lane);
-    }
+    const bool more = kt + 1 < nk;
+    char* nxt = lds + (cur ^ 1) * 2 * G3_TILE;
+    const int64_t kn = (int64_t)(kt + 1) * BK2;
     const char* ta = lds + cur * 2 * G3_TILE + (wm * 128 + lr) * 128;
     const char* tb = lds + cur * 2 * G3_TILE + G3_TILE + (wn * 64 + lr) * 128;
 #pragma unroll
@@ -630,6 +641,13 @@ __global__ __launch_bounds__(512) void gemm16_nt_glds_kernel(const Gemm16Args g)
       for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(ta + i * 32 * 128 + sw);
 #pragma unroll
       for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 128 + sw);
+      // the next tile's 8 LDS-DMA pieces of this wave go out two per k-step, behind the step's fragment reads: all 8 right
+      // after the barrier keep every wave's first reads and MFMAs waiting behind ~1000 cycles of DMA issue (fwd 1280 ->
+      // 1024: 181 -> 163 us; tools/micro/gemm16_bench.hip)
+      if (more) {
+        g3_piece(g.A, g.B, g.lda, g.ldb, m0, n0, kn, nxt, wave, lane, 2 * ks);
+        g3_piece(g.A, g.B, g.lda, g.ldb, m0, n0, kn, nxt, wave, lane, 2 * ks + 1);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
