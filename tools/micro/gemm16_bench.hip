@@ -316,6 +316,91 @@ __global__ __launch_bounds__(512) void gemm16_nt_spread_kernel(const u16* __rest
     }
 }
 
+// persistent form: 256 workgroups walk the tiles (tile = it * 256 + b after the XCD remap), so the C stores of a tile
+// drain while the next tile's k-loop runs
+template <int SPREAD>
+__global__ __launch_bounds__(512) void gemm16_nt_persist_kernel(const u16* __restrict__ A, const u16* __restrict__ B,
+                                                               float* __restrict__ C, u16* __restrict__ C16, int64_t M,
+                                                               int64_t N, int64_t K, int gx) {
+  constexpr int NWAVES = 8, TM = 128, TN = 64, MI = 4, NI = 2;
+  __shared__ __attribute__((aligned(1024))) char lds[4 * TILE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int lr0 = 0; (void)lr0;
+  const int64_t ntiles = (M / BMT) * gx;
+  for (int64_t t0 = 0; t0 < ntiles; t0 += gridDim.x) {
+  int64_t lid = t0 + blockIdx.x;
+  {
+    // XCD-aware: within this round of gridDim.x tiles, workgroup b (XCD b & 7) takes tile (b & 7) * (G / 8) + (b >> 3)
+    const int64_t G = gridDim.x, b = blockIdx.x;
+    if ((G & 7) == 0) lid = t0 + (b & 7) * (G >> 3) + (b >> 3);
+  }
+  if (lid >= ntiles) break;
+  const int bx = (int)(lid % gx), by = (int)(lid / gx);
+  const int64_t m0 = (int64_t)by * BMT, n0 = (int64_t)bx * BNT;
+  const int nk = (int)(K / BKT);
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  __syncthreads();  // the previous tile's last k-tile has been read by everyone
+  const int lr = lane & 31, lk = lane >> 5;
+  const int f = (lr >> 1) & 7;
+  stage_tile<NWAVES, 1>(A, K, m0, 0, lds, wave, lane);
+  stage_tile<NWAVES, 1>(B, K, n0, 0, lds + TILE_BYTES, wave, lane);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk;
+    char* nxt = lds + (cur ^ 1) * 2 * TILE_BYTES;
+    const int64_t kn = (int64_t)(kt + 1) * BKT;
+    const char* ta = lds + cur * 2 * TILE_BYTES + (wm * TM + lr) * 128;
+    const char* tb = lds + cur * 2 * TILE_BYTES + TILE_BYTES + (wn * TN + lr) * 128;
+#pragma unroll
+    for (int ks = 0; ks < BKT / 16; ++ks) {
+      const int sw = ((ks * 2 + lk) ^ f) << 4;
+      bf16x8 a[MI], b[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(ta + i * 32 * 128 + sw);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 128 + sw);
+      if (more) {
+        if (SPREAD == 1 && ks == 0) {
+#pragma unroll
+          for (int p = 0; p < 8; ++p) stage_piece(A, B, K, m0, n0, kn, nxt, wave, lane, p);
+        }
+        if (SPREAD == 2) {
+          stage_piece(A, B, K, m0, n0, kn, nxt, wave, lane, 2 * ks);
+          stage_piece(A, B, K, m0, n0, kn, nxt, wave, lane, 2 * ks + 1);
+        }
+        if (SPREAD == 3 && ks < 2) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p) stage_piece(A, B, K, m0, n0, kn, nxt, wave, lane, 4 * ks + p);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int64_t col = n0 + wn * TN + j * 32 + lr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        C16[row * N + col] = __builtin_bit_cast(u16, (__bf16)acc[i][j][r]);
+      }
+    }
+  }
+}
+
 // Ablations of the one-barrier loop (results are wrong by construction; only the time is read):
 //   MODE 1: no LDS-DMA in the loop (every k-tile re-reads tile 0)   MODE 2: DMA + barrier, no ds_read / MFMA
 //   MODE 3: DMA + ds_reads, no MFMA                                  MODE 4: MFMA only (fragments read once)
@@ -501,6 +586,21 @@ int main(int argc, char** argv) {
     RUNS2("DMA after 1st reads", 1)
     RUNS2("DMA 2 per k-step", 2)
     RUNS2("DMA 4+4 in k-steps 0,1", 3)
+#define RUNQ(NAME, SP_, GRID_)                                                                                 \
+    {                                                                                                         \
+      float ms = 0;                                                                                           \
+      hipMemset(dC16, 0, (size_t)M * N * 2);                                                                  \
+      for (int rep = 0; rep < 6; ++rep) {                                                                     \
+        if (rep == 1) hipEventRecord(e0);                                                                     \
+        hipLaunchKernelGGL((gemm16_nt_persist_kernel<SP_>), dim3(GRID_), dim3(512), 0, 0, dA, dB, dC, dC16, M, N, K, gx); \
+      }                                                                                                       \
+      hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); ms /= 5;                 \
+      const double w = check(true);                                                                           \
+      printf("%-9s N=%4lld K=%4lld %-22s %8.1f us %7.1f TF   worst err/tol %.3f %s (%s)\n", sh.name, (long long)N, \
+             (long long)K, NAME, ms * 1e3, 2.0 * M * N * K / ms / 1e9, w, w <= 1.0 ? "ok" : "WRONG",           \
+             hipGetErrorString(hipGetLastError()));                                                           \
+    }
+    RUNQ("persistent 256 WGs", 2, 256)
     RUNP("ping-pong", false)
     RUNP("ping-pong + setprio", true)
     hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dC16);

@@ -894,8 +894,29 @@ extern "C" int trs_gemm_bf16(int transA, int transB, int64_t M, int64_t N, int64
 }
 
 // bf16-resident GEMM.  tn = 0: C(M,N) = alpha * A(M,K) B(N,K)^T; tn = 1: C(M,N) = alpha * A(K,M)^T B(K,N).
+// split-K of the weight-gradient (TN) form on 256 x 256 tiles (one workgroup per CU): as many splits as give every CU
+// a workgroup, at least 4 k-tiles each
+static int tn_wide_splits(int64_t M, int64_t N, int64_t K) {
+  const int64_t tiles = (M / 256) * (N / 256), kt = K / BK2;
+  int64_t s = tiles > 0 ? 256 / tiles : 1;
+  if (s > kt / 4) s = kt / 4;
+  return s < 1 ? 1 : (int)s;
+}
+// (measured at the c5 weight-gradient shapes, K = 65 536: 1024 x 1280 281 -> 233 us, 512 x 1024 107 -> 94, but 256 x 512 —
+// two tiles x 128 splits of slabs — 38 -> 44: eight tiles at least.  TRS_GEMM16_TN_WIDE = 0 | 1 overrides: tuning knob)
+static bool tn_wide_wanted(int64_t M, int64_t N) {
+  const char* e = getenv("TRS_GEMM16_TN_WIDE");
+  if (e) return atoi(e) != 0;
+  return (M / 256) * (N / 256) >= 8;
+}
+
 extern "C" int64_t trs_gemm_bf16in_workspace_bytes(int64_t M, int64_t N, int64_t K) {
-  return trs_gemm_f32_workspace_bytes(M, N, K);
+  int64_t b = trs_gemm_f32_workspace_bytes(M, N, K);
+  if (M > 0 && N > 0 && K > 0 && M % 256 == 0 && N % 256 == 0) {
+    const int64_t w = (int64_t)tn_wide_splits(M, N, K) * M * N * 4;
+    if (w > b) b = w;
+  }
+  return b;
 }
 
 extern "C" int trs_gemm_bf16in(int tn, int64_t M, int64_t N, int64_t K, float alpha, const void* A_dev, int64_t lda,
@@ -911,6 +932,9 @@ extern "C" int trs_gemm_bf16in(int tn, int64_t M, int64_t N, int64_t K, float al
   TRS_REQUIRE((((uintptr_t)A_dev | (uintptr_t)B_dev) & 15) == 0 && lda % 8 == 0 && ldb % 8 == 0,
               "trs_gemm_bf16in: operands must be 16-byte aligned with leading dimensions that are multiples of 8");
   int splits = (bn_part_dev || C_bf16_dev) ? 1 : pick_splits(M, N, K);
+  const bool tn_wide = tn && !bn_part_dev && !C_bf16_dev && M % 256 == 0 && N % 256 == 0 && tn_wide_wanted(M, N) &&
+                       (M / 256) * (N / 256) * tn_wide_splits(M, N, K) >= 128;
+  if (tn_wide) splits = tn_wide_splits(M, N, K);
   const int64_t kt = K / BK2;
   if (splits > kt) splits = (int)kt;
   int64_t per = (kt + splits - 1) / splits;
@@ -932,7 +956,7 @@ extern "C" int trs_gemm_bf16in(int tn, int64_t M, int64_t N, int64_t K, float al
   const char* tile_env = getenv("TRS_GEMM16_TILE");
   const int tile = tile_env ? atoi(tile_env) : 0;
   const bool can_big = M % 256 == 0, can_wide = can_big && N % 256 == 0;
-  const bool wide = tile ? (tile == 512 && can_wide) : (can_wide && (M / 256) * (N / 256) * splits >= 256);
+  const bool wide = tn_wide || (tile ? (tile == 512 && can_wide) : (can_wide && (M / 256) * (N / 256) * splits >= 256));
   const bool big = wide || (tile ? (tile == 256 && can_big) : (can_big && (M / 256) * (N / BN) * splits >= 256));
   const int64_t gx = N / (wide ? 256 : BN), gy = M / (big ? 256 : BM);
   TRS_REQUIRE(gx * gy * splits < ((int64_t)1 << 31), "trs_gemm_bf16in: problem too large for the launch grid");
