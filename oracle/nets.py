@@ -214,13 +214,14 @@ def _mm(a, b):
     return (a.astype(np.float64) @ b.astype(np.float64)).astype(F32)
 
 
-def mlp_train_step_bf16(params, batch, rnd=bf16_round, y_bf16=True):
+def mlp_train_step_bf16(params, batch, rnd=bf16_round, y_bf16=True, dx0_bf16=False):
     """use_amp=True on tile-aligned nets (torchrecsys_amd/mlp_engine.py, the bf16-RESIDENT path): the arithmetic of
     mlp_forward / mlp_backward with a rounding to bf16 at exactly the points where the product path keeps a bf16 image
     in HBM — the gathered input x_0, every weight image W_l (forward and input gradient), the pre-BN outputs y_l (when
     their statistics come from the fp32 accumulators of the same launch: y_bf16; statistics are taken BEFORE the
     rounding), the layer inputs x_l (l < L; the last one feeds the fp32 H -> 1 dot), the BN-backward outputs dy_l and
-    the input gradients dx_l (l > 0; dx_0 = the embedding gradient stays fp32).  Bias / gamma / beta gradients and dW
+    the input gradients dx_l (l > 0; dx_0 = the embedding gradient stays fp32 unless dx0_bf16: the fused SGD embedding
+    update of the trainer reads a bf16 d x0 — what autocast's gradient of the half-precision x_0 is).  Bias / gamma / beta gradients and dW
     are fp32 sums.  rnd=identity restates the fp32 path (tests/test_oracle_golden.py pins that against the fp32
     functions above, which the reference's golden vectors pin).  The reference's own AMP is fp16 autocast + GradScaler
     and CUDA-only (model.py:86-88,192-195): there is no reference output to pin the ROUNDED variant to — it is this
@@ -289,7 +290,7 @@ def mlp_train_step_bf16(params, batch, rnd=bf16_round, y_bf16=True):
             dy16 = rnd(dy)
             grads[f"fcs.{l}.weight"] = _mm(dy16.T, c["x"][l])
             dx = _mm(dy16, W[l])
-            if l > 0 and (y_bf16 or not use_bn):  # the layer below keeps a bf16 y: its dx image is bf16 too
+            if (l > 0 and (y_bf16 or not use_bn)) or (l == 0 and dx0_bf16):  # the layer below keeps a bf16 y: its dx image is bf16 too
                 dx = rnd(dx)
         D = params["user.weight"].shape[1]
         np.add.at(grads["user.weight"], u, dx[:, 0:D])

@@ -20,7 +20,7 @@ def mm(a, b):
     return (a.to(WIDE) @ b.to(WIDE)).float()
 
 
-def train_step_bf16(P, ids, y_bf16=True, wide=torch.float64):
+def train_step_bf16(P, ids, y_bf16=True, wide=torch.float64, dx0_bf16=False):
     """wide: accumulation dtype of the reductions (float64 = the judge; float32 = the calibration run).
     P: dict name -> fp32 GPU tensor (state_dict layout; embedding tables may be compacted); ids: dict user/pos/neg
     [/pos_meta/neg_meta] of int64 GPU tensors.  Returns (pos, neg, loss, grads, dx0 rows per pass) — running statistics
@@ -96,7 +96,7 @@ def train_step_bf16(P, ids, y_bf16=True, wide=torch.float64):
             # sum of |products| per element: the scale of the fp32-accumulation error of this reduction over all rows
             gr[f"absbound.fcs.{l}.weight"] = mm(dy16.abs().T, c["x"][l].abs())
             dx = mm(dy16, W[l])
-            if l > 0 and (y_bf16 or not use_bn):
+            if (l > 0 and (y_bf16 or not use_bn)) or (l == 0 and dx0_bf16):
                 dx = rnd(dx)
         return gr, dx
 

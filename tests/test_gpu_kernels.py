@@ -485,12 +485,14 @@ def test_gemm_bf16_resident_nt_and_tn(M, N, K):
     assert torch.equal(d, w.to(torch.bfloat16)) and torch.equal(dt, w.to(torch.bfloat16).t().contiguous())
 
 
-def test_gemm_bf16_resident_split_k_wgrad_shape():
+@pytest.mark.parametrize("H,Kin,rows", [(256, 384, 64 * 300), (512, 1024, 64 * 257), (1024, 768, 8192)])
+def test_gemm_bf16_resident_split_k_wgrad_shape(H, Kin, rows):
+    """dW = dy^T x over many rows (split-K slabs).  (512, 1024) and (1024, 768) take the 256 x 256 tiles with an uneven
+    last split (257 k-tiles); (256, 384) the 128-tile kernel."""
     ops = _ops()
     rs = np.random.RandomState(3)
-    rows = 64 * 300
-    dy = torch.from_numpy(rs.normal(0, 1, (rows, 256)).astype(np.float32)).to(DEV).to(torch.bfloat16)
-    x = torch.from_numpy(rs.normal(0, 1, (rows, 384)).astype(np.float32)).to(DEV).to(torch.bfloat16)
+    dy = torch.from_numpy(rs.normal(0, 1, (rows, H)).astype(np.float32)).to(DEV).to(torch.bfloat16)
+    x = torch.from_numpy(rs.normal(0, 1, (rows, Kin)).astype(np.float32)).to(DEV).to(torch.bfloat16)
     out = ops.gemm_bf16in(True, dy, x)
     assert rel_err(out.cpu().numpy(), dy.double().cpu().numpy().T @ x.double().cpu().numpy()) < 3e-6
 

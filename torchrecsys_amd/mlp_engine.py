@@ -36,6 +36,10 @@ class MLPCompute:
         # 2*H floats each — so N ranks with batch B compute what one process computes with batch N*B.  Off (default):
         # per-replica statistics.  Only read when torch.distributed has more than one rank.
         self.sync_bn = False
+        # the embedding gradient d x0 as a bf16 image on the bf16-resident path (what autocast's gradient of the
+        # half-precision x0 is): set by MLPTrainer when its fused SGD embedding update consumes it; the autograd bridge
+        # and the per-table optimiser paths keep fp32
+        self.dx0_bf16 = False
 
     def _resident(self, rows, training):
         """bf16-resident path: use_amp, training step, every GEMM of the net made of interior tiles."""
@@ -110,6 +114,7 @@ class MLPCompute:
             ops.mlp_gather_concat(net.tables(), Bt, passes, x)
         ctx = {"ids": ids, "B": B, "passes": passes, "x": [x], "y": [], "mean": [], "var": [], "training": training,
                "resident": res, "Bt": (Bt, keep)}
+        tracked = []
         for l in range(L):
             fc = net.fcs[l]
             # train-mode BN: the batch statistics come out of the GEMM epilogue (one partial per 128-row tile) when no
@@ -144,7 +149,7 @@ class MLPCompute:
                         ops.bn_batch_stats(y, B, passes, BN_MOMENTUM, mean, var, rm, rv)
                     if sync:
                         self._sync_stats(mean, var, bn, B)
-                    bn.num_batches_tracked += passes
+                    tracked.append(bn.num_batches_tracked)
                     stat_passes = passes
                 else:
                     mean, var = bn.running_mean, bn.running_var
@@ -158,6 +163,8 @@ class MLPCompute:
                 ops.bn_relu_forward(y, B, passes, use_bn, stat_passes, mean, var, gamma, beta, BN_EPS, xn)
             x = xn
             ctx["x"].append(x)
+        if tracked:  # BatchNorm1d.num_batches_tracked of every layer: + passes, one launch
+            torch._foreach_add_(tracked, passes)
         out = torch.empty(rows, dtype=torch.float32, device=dev)
         ops.rowdot(x, net.output_layer.weight.data.reshape(-1), net.output_layer.bias.data, out)
         return out, ctx
@@ -243,7 +250,8 @@ class MLPCompute:
                 # dx = dy W through the W^T image: bf16 between layers (when the layer below keeps a bf16 y), fp32 for the
                 # embedding gradient d x0
                 dx = self._gemm16(False, dy16, self.w16t[l],
-                                  out_bf16=l > 0 and ctx["y"][l - 1].dtype == torch.bfloat16)
+                                  out_bf16=(l > 0 and ctx["y"][l - 1].dtype == torch.bfloat16)
+                                  or (l == 0 and self.dx0_bf16))
             else:
                 self._gemm(True, False, dy, ctx["x"][l], out=slot(fc.weight), bf16=net.use_bf16)  # dW = dy^T x (split-K)
                 if on_group_done:
@@ -312,6 +320,8 @@ class MLPTrainer:
         net, opt = self.net, self.opt
         B = ids["user"].shape[0]
         D, M = net.n_factors, net.n_meta_tables()
+        fused_lr = self._fused_embed_lr() if self.kind == "sgd" else None
+        net.compute.dx0_bf16 = fused_lr is not None  # (only read on the bf16-resident path)
         scores, ctx = net.compute.forward(ids, 2, True)
         pos, neg = scores[:B], scores[B:]
         ops.hinge_auc(pos, neg, loss_slot, auc_slot, loss=self.loss_id)
@@ -325,7 +335,7 @@ class MLPTrainer:
         grads, dx0 = net.compute.backward(ctx, g, grad_of=self.bucket.grad_of,
                                           on_group_done=(lambda i: works.append(
                                               self.bucket.allreduce_segment_async(self.segs[i]))) if dp else None)
-        fused_lr = self._fused_embed_lr() if self.kind == "sgd" else None
+        net.compute.dx0_bf16 = False
         tables = []
         if fused_lr is None:  # per-table paths: one index vector per table over the 2B rows of d x0
             idx_user = torch.cat([ids["user"], ids["user"]])
