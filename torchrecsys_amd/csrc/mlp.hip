@@ -30,7 +30,8 @@ struct GatherArgs {
   unsigned short* x16;  // bf16 image (use_amp: what the bf16-resident GEMMs read), or NULL; same ld (elements)
 };
 
-// one (row, field) segment of D floats per G-lane group; fields: 0 user, 1 item, 2+m metadata m
+// one (row, field) segment of D floats per lane group (a whole wave at D = 256), lane = 4-float chunk (fields: 0 user,
+// 1 item, 2+m metadata m): the index arithmetic (a 64-bit division) is per segment, not per element
 __global__ __launch_bounds__(TRS_BLOCK) void mlp_gather_kernel(const GatherArgs a) {
   const trs_tables& T = a.T;
   const int D = T.D, F = 2 + T.M;
@@ -38,12 +39,14 @@ __global__ __launch_bounds__(TRS_BLOCK) void mlp_gather_kernel(const GatherArgs 
   const int ib = a.Bt.idx_bytes;
   const int64_t nseg = (int64_t)a.passes * B * F;
   const int chunks = (D + 3) / 4;
-  const bool vec = (D % 4) == 0;
-  const int64_t total = nseg * chunks;
-  const int64_t stride = (int64_t)gridDim.x * TRS_BLOCK;
-  for (int64_t e = (int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x; e < total; e += stride) {
-    const int64_t seg = e / chunks;
-    const int c = (int)(e - seg * chunks);
+  const bool vec = (D % 4) == 0 && (a.ld & 3) == 0;
+  const int lane = threadIdx.x & 63;
+  int gsh = 0;  // lane group of G = 2^gsh lanes per segment (the smallest power of two >= chunks, at most a wave)
+  while (gsh < 6 && (1 << gsh) < chunks) ++gsh;
+  const int G = 1 << gsh, spw = TRS_WAVE >> gsh, lig = lane & (G - 1);
+  const int64_t wave = ((int64_t)blockIdx.x * TRS_BLOCK + threadIdx.x) >> 6;
+  const int64_t nwave = ((int64_t)gridDim.x * TRS_BLOCK) >> 6;
+  for (int64_t seg = wave * spw + (lane >> gsh); seg < nseg; seg += nwave * spw) {
     const int64_t row = seg / F;
     const int f = (int)(seg - row * F);
     const int pass = row >= B;
@@ -58,30 +61,29 @@ __global__ __launch_bounds__(TRS_BLOCK) void mlp_gather_kernel(const GatherArgs 
       id = trs_ld_idx(pass ? a.Bt.neg_meta : a.Bt.pos_meta, ib, t * T.M + m);
       n_rows = T.n_meta[m];
     }
-    const int64_t doff = row * a.ld + (int64_t)f * D + 4 * c;
-    float* dst = a.x + doff;
-    if ((uint64_t)id >= (uint64_t)n_rows) {
-      if (c == 0 && a.Bt.err_flag_dev) atomicOr(a.Bt.err_flag_dev, 1);
-      for (int q = 0; q < 4 && 4 * c + q < D; ++q) {
-        if (a.x) dst[q] = 0.f;
-        if (a.x16) a.x16[doff + q] = 0;
+    const bool bad = (uint64_t)id >= (uint64_t)n_rows;
+    if (bad && lig == 0 && a.Bt.err_flag_dev) atomicOr(a.Bt.err_flag_dev, 1);
+    for (int c = lig; c < chunks; c += G) {
+      const int64_t doff = row * a.ld + (int64_t)f * D + 4 * c;
+      float* dst = a.x + doff;
+      if (bad) {
+        for (int q = 0; q < 4 && 4 * c + q < D; ++q) {
+          if (a.x) dst[q] = 0.f;
+          if (a.x16) a.x16[doff + q] = 0;
+        }
+        continue;
       }
-      continue;
-    }
-    const float* src = tab + id * (int64_t)D + 4 * c;
-    if (a.x16) {
-      if (vec && ((a.ld & 3) == 0)) {
+      const float* src = tab + id * (int64_t)D + 4 * c;
+      if (vec) {
         const float4 v = *reinterpret_cast<const float4*>(src);
-        st_bf16x4(a.x16 + doff, v.x, v.y, v.z, v.w);
+        if (a.x16) st_bf16x4(a.x16 + doff, v.x, v.y, v.z, v.w);
+        if (a.x) *reinterpret_cast<float4*>(dst) = v;
       } else {
-        for (int q = 0; q < 4 && 4 * c + q < D; ++q) a.x16[doff + q] = f2bf(src[q]);
+        for (int q = 0; q < 4 && 4 * c + q < D; ++q) {
+          if (a.x16) a.x16[doff + q] = f2bf(src[q]);
+          if (a.x) dst[q] = src[q];
+        }
       }
-      if (!a.x) continue;
-    }
-    if (vec && ((a.ld & 3) == 0)) {
-      *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
-    } else {
-      for (int q = 0; q < 4 && 4 * c + q < D; ++q) dst[q] = src[q];
     }
   }
 }
@@ -560,7 +562,10 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_reduce_v4_kernel(const BnBwd
   }
 }
 
-// out = relu(bn(y)): thread = 4 fixed columns (scale/shift folded once), rows streamed four at a time.
+// out = relu(bn(y)): thread = 4 fixed columns (scale/shift folded once), eight rows in flight per thread, 32 rows per
+// workgroup — no reduction here, so the rows are cut fine enough to fill the chip (128-row chunks: 512 workgroups with
+// 16 KB in flight per CU ran the 1024-wide bf16 layer at 3.0 TB/s).
+constexpr int FWD_ROWS = 32;
 template <bool Y16>
 __global__ __launch_bounds__(TRS_BLOCK) void bn_relu_fwd_v4_kernel(const BnFwdArgs a, int tpr) {
   const int tc = threadIdx.x % tpr, rl = threadIdx.x / tpr, nrl = TRS_BLOCK / tpr;
@@ -568,8 +573,8 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_relu_fwd_v4_kernel(const BnFwdAr
   if (col >= a.H) return;
   const int chunk = blockIdx.y, pass = blockIdx.z;
   const int sp = a.stat_passes > 1 ? pass : 0;
-  const int64_t r0 = (int64_t)chunk * CHUNK_ROWS;
-  const int64_t r1 = (r0 + CHUNK_ROWS < a.rows_per_pass) ? r0 + CHUNK_ROWS : a.rows_per_pass;
+  const int64_t r0 = (int64_t)chunk * FWD_ROWS;
+  const int64_t r1 = (r0 + FWD_ROWS < a.rows_per_pass) ? r0 + FWD_ROWS : a.rows_per_pass;
   const int64_t base = (int64_t)pass * a.rows_per_pass;
   float mu[4], is[4], ga[4], be[4];
 #pragma unroll
@@ -579,7 +584,7 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_relu_fwd_v4_kernel(const BnFwdAr
     ga[q] = a.use_bn ? a.gamma[col + q] : 1.f;
     be[q] = a.use_bn ? a.beta[col + q] : 0.f;
   }
-  constexpr int U = 4;
+  constexpr int U = 8;
   for (int64_t r = r0 + rl; r < r1; r += (int64_t)nrl * U) {
     float4 yv[U];
 #pragma unroll
@@ -937,8 +942,11 @@ extern "C" int trs_mlp_gather_concat(const trs_tables* tables, const trs_batch* 
   TRS_REQUIRE(tables->M == 0 || (batch->pos_meta && (passes == 1 || batch->neg_meta)),
               "trs_mlp_gather_concat: metadata ids NULL");
   GatherArgs a = {*tables, *batch, x_dev, ld, passes, (unsigned short*)x_bf16_dev};
-  const int64_t total = (int64_t)passes * batch->B * (2 + tables->M) * ((tables->D + 3) / 4);
-  hipLaunchKernelGGL(mlp_gather_kernel, dim3(trs_grid(total, TRS_BLOCK)), dim3(TRS_BLOCK), 0, (hipStream_t)stream, a);
+  const int64_t segs = (int64_t)passes * batch->B * (2 + tables->M);
+  int g_lanes = 1;
+  while (g_lanes < 64 && g_lanes < (tables->D + 3) / 4) g_lanes <<= 1;
+  hipLaunchKernelGGL(mlp_gather_kernel, dim3(trs_grid(segs, TRS_BLOCK / g_lanes)), dim3(TRS_BLOCK), 0,
+                     (hipStream_t)stream, a);
   TRS_CHECK_LAUNCH("mlp_gather_kernel");
   return TRS_OK;
 }
@@ -1011,7 +1019,7 @@ extern "C" int trs_bn_relu_forward(const void* y_dev, int32_t y_bf16, int64_t ro
               "trs_bn_relu_forward: bf16 images need H %% 4 == 0 and aligned rows");
   if (v4) {
     const V4Shape v = v4_shape(H);
-    const dim3 gr(v.gx, n_chunks_of(rows_per_pass), passes);
+    const dim3 gr(v.gx, (unsigned)((rows_per_pass + FWD_ROWS - 1) / FWD_ROWS), passes);
     if (y_bf16) hipLaunchKernelGGL(bn_relu_fwd_v4_kernel<true>, gr, dim3(TRS_BLOCK), 0, (hipStream_t)stream, a, v.tpr);
     else hipLaunchKernelGGL(bn_relu_fwd_v4_kernel<false>, gr, dim3(TRS_BLOCK), 0, (hipStream_t)stream, a, v.tpr);
   } else {
