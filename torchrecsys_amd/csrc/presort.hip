@@ -303,6 +303,9 @@ __global__ __launch_bounds__(FLAG_THREADS) void batch_flags_kernel(const FlagArg
 constexpr int GRP_THREADS = 1024, GRP_BINS = 16384, GRP_BIN_BITS = 14, GRP_CAP = 22528, GRP_U = 8, GRP_MAX_CHUNKS = 8;
 constexpr int GRP_WMAX = 16;  // windows per chunk: 2B / GRP_CAP + 2 <= 14 for 2B <= 2^18
 
+// PAIRED: the references' rows come interleaved, keys[2t] / keys[2t + 1] (the metadata columns: `pos_all` is that array,
+// read 8 bytes per triple); else from the pos / neg id arrays.
+template <bool PAIRED>
 __global__ __launch_bounds__(GRP_THREADS) void batch_group_items_kernel(const int32_t* __restrict__ pos_all,
                                                                        const int32_t* __restrict__ neg_all,
                                                                        int64_t batch, int64_t n_items, int pb,
@@ -314,8 +317,9 @@ __global__ __launch_bounds__(GRP_THREADS) void batch_group_items_kernel(const in
   __shared__ uint32_t wave_tot[GRP_THREADS / TRS_WAVE];
   __shared__ uint32_t win_row[GRP_WMAX + 2], win_slot[GRP_WMAX + 2];  // first row / first slot of every window
   __shared__ uint32_t tot_s;
-  const int32_t* pos = pos_all + (int64_t)blockIdx.x * batch;
-  const int32_t* neg = neg_all + (int64_t)blockIdx.x * batch;
+  const int32_t* pos = pos_all + (PAIRED ? 2 : 1) * (int64_t)blockIdx.x * batch;
+  const int32_t* neg = PAIRED ? nullptr : neg_all + (int64_t)blockIdx.x * batch;
+  const uint2* pair = reinterpret_cast<const uint2*>(pos);
   uint32_t* keys = keys_all + 2 * (int64_t)blockIdx.x * batch;
   RefPayload* vals = vals_all + 2 * (int64_t)blockIdx.x * batch;
   const int B = (int)batch;
@@ -333,8 +337,14 @@ __global__ __launch_bounds__(GRP_THREADS) void batch_group_items_kernel(const in
 #pragma unroll
       for (int k = 0; k < GRP_U; ++k) {
         const int t = t0 + k * GRP_THREADS;
-        kp[k] = (uint32_t)pos[t < B ? t : 0] - c0;
-        kn[k] = (uint32_t)neg[t < B ? t : 0] - c0;
+        if (PAIRED) {
+          const uint2 kk = pair[t < B ? t : 0];
+          kp[k] = kk.x - c0;
+          kn[k] = kk.y - c0;
+        } else {
+          kp[k] = (uint32_t)pos[t < B ? t : 0] - c0;
+          kn[k] = (uint32_t)neg[t < B ? t : 0] - c0;
+        }
       }
 #pragma unroll
       for (int k = 0; k < GRP_U; ++k) {
@@ -389,8 +399,14 @@ __global__ __launch_bounds__(GRP_THREADS) void batch_group_items_kernel(const in
 #pragma unroll
         for (int k = 0; k < GRP_U; ++k) {
           const int t = t0 + k * GRP_THREADS;
-          kp[k] = (uint32_t)pos[t < B ? t : 0] - c0;
-          kn[k] = (uint32_t)neg[t < B ? t : 0] - c0;
+          if (PAIRED) {
+            const uint2 kk = pair[t < B ? t : 0];
+            kp[k] = kk.x - c0;
+            kn[k] = kk.y - c0;
+          } else {
+            kp[k] = (uint32_t)pos[t < B ? t : 0] - c0;
+            kn[k] = (uint32_t)neg[t < B ? t : 0] - c0;
+          }
         }
 #pragma unroll
         for (int k = 0; k < GRP_U; ++k) {
@@ -1100,11 +1116,11 @@ extern "C" int trs_epoch_presort(const int32_t* stream_ui_dev, const int32_t* ne
     // hand-written grouping (counting sort in LDS, one workgroup per batch): no key array, no vendor library
     static bool attr_done = false;
     if (!attr_done) {
-      (void)hipFuncSetAttribute((const void*)batch_group_items_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+      (void)hipFuncSetAttribute((const void*)batch_group_items_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (GRP_BINS + GRP_CAP) * 4);
       attr_done = true;
     }
-    hipLaunchKernelGGL(batch_group_items_kernel, dim3((unsigned)n_batches), dim3(GRP_THREADS),
+    hipLaunchKernelGGL(batch_group_items_kernel<false>, dim3((unsigned)n_batches), dim3(GRP_THREADS),
                        (size_t)(GRP_BINS + GRP_CAP) * 4, s, (const int32_t*)pos_dev, (const int32_t*)neg_dev, batch,
                        n_items, pay_bits, kin + n, vout);
     TRS_CHECK_LAUNCH("batch_group_items_kernel");
@@ -1361,11 +1377,27 @@ extern "C" int trs_epoch_presort_meta(const int32_t* pos_dev, const int32_t* neg
                      batch, item_meta_dev, M, m, n_cat, kin, vin, err_flag_dev, pos_meta_out_dev, neg_meta_out_dev);
   TRS_CHECK_LAUNCH("meta_refs_kernel");
   size_t temp = (size_t)temp_bytes;
+  *sorted_keys_out = (void*)(kin + n);
+  *sorted_vals_out = (void*)(vin + n);
+  const char* vs_env = getenv("TRS_VENDOR_SORT");
+  if (!(vs_env && atoi(vs_env) != 0) && n_cat <= (int64_t)GRP_BINS * GRP_MAX_CHUNKS &&
+      GRP_BIN_BITS + bits_for(2 * batch) <= 32) {
+    // the column's references grouped by the hand-written counting sort (categories = rows; keys interleaved in kin)
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute((const void*)batch_group_items_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (GRP_BINS + GRP_CAP) * 4);
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(batch_group_items_kernel<true>, dim3((unsigned)n_batches), dim3(GRP_THREADS),
+                       (size_t)(GRP_BINS + GRP_CAP) * 4, s, (const int32_t*)kin, (const int32_t*)nullptr, batch, n_cat,
+                       bits_for(2 * batch), kin + n, vin + n);
+    TRS_CHECK_LAUNCH("batch_group_items_kernel");
+    return TRS_OK;
+  }
   hipError_t e = rocprim::segmented_radix_sort_pairs<ItemSortCfg>(
       temp_dev, temp, kin, kin + n, ref_val_it(batch), vin + n, n, (unsigned)n_batches,
       seg_it(0, (uint32_t)(2 * batch)), seg_it(1, (uint32_t)(2 * batch)), 0u, (unsigned)bits_for(n_cat), s);
-  *sorted_keys_out = (void*)(kin + n);
-  *sorted_vals_out = (void*)(vin + n);
   if (e != hipSuccess) {
     trs_set_error("trs_epoch_presort_meta: rocprim::segmented_radix_sort_pairs failed: %s", hipGetErrorString(e));
     return TRS_E_LAUNCH;
