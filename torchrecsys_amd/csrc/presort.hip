@@ -303,9 +303,10 @@ __global__ __launch_bounds__(FLAG_THREADS) void batch_flags_kernel(const FlagArg
 constexpr int GRP_THREADS = 1024, GRP_BINS = 16384, GRP_BIN_BITS = 14, GRP_CAP = 22528, GRP_U = 8, GRP_MAX_CHUNKS = 8;
 constexpr int GRP_WMAX = 16;  // windows per chunk: 2B / GRP_CAP + 2 <= 14 for 2B <= 2^18
 
-// PAIRED: the references' rows come interleaved, keys[2t] / keys[2t + 1] (the metadata columns: `pos_all` is that array,
-// read 8 bytes per triple); else from the pos / neg id arrays.
-template <bool PAIRED>
+// SRC 0: the references' rows are the pos / neg ids (payload 2t + w).  SRC 1: they come interleaved, keys[2t] / keys[2t+1]
+// (the metadata columns: `pos_all` is that array, read 8 bytes per triple).  SRC 2: ONE reference per position — the
+// users of a batch (`pos_all` = user ids): B references per batch, payload = the position in the SLICE, b * batch + t.
+template <int SRC>
 __global__ __launch_bounds__(GRP_THREADS) void batch_group_items_kernel(const int32_t* __restrict__ pos_all,
                                                                        const int32_t* __restrict__ neg_all,
                                                                        int64_t batch, int64_t n_items, int pb,
@@ -317,11 +318,13 @@ __global__ __launch_bounds__(GRP_THREADS) void batch_group_items_kernel(const in
   __shared__ uint32_t wave_tot[GRP_THREADS / TRS_WAVE];
   __shared__ uint32_t win_row[GRP_WMAX + 2], win_slot[GRP_WMAX + 2];  // first row / first slot of every window
   __shared__ uint32_t tot_s;
-  const int32_t* pos = pos_all + (PAIRED ? 2 : 1) * (int64_t)blockIdx.x * batch;
-  const int32_t* neg = PAIRED ? nullptr : neg_all + (int64_t)blockIdx.x * batch;
+  const int32_t* pos = pos_all + (SRC == 1 ? 2 : 1) * (int64_t)blockIdx.x * batch;
+  const int32_t* neg = SRC != 0 ? nullptr : neg_all + (int64_t)blockIdx.x * batch;
   const uint2* pair = reinterpret_cast<const uint2*>(pos);
-  uint32_t* keys = keys_all + 2 * (int64_t)blockIdx.x * batch;
-  RefPayload* vals = vals_all + 2 * (int64_t)blockIdx.x * batch;
+  constexpr int PER = SRC == 2 ? 1 : 2;  // references per position
+  uint32_t* keys = keys_all + PER * (int64_t)blockIdx.x * batch;
+  RefPayload* vals = vals_all + PER * (int64_t)blockIdx.x * batch;
+  const uint32_t pay0 = SRC == 2 ? (uint32_t)((int64_t)blockIdx.x * batch) : 0u;  // added to the payload on the way out
   const int B = (int)batch;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   constexpr int NW = GRP_THREADS / TRS_WAVE, SEG = GRP_BINS / NW;  // rows per wave in the scan
@@ -337,10 +340,13 @@ __global__ __launch_bounds__(GRP_THREADS) void batch_group_items_kernel(const in
 #pragma unroll
       for (int k = 0; k < GRP_U; ++k) {
         const int t = t0 + k * GRP_THREADS;
-        if (PAIRED) {
+        if (SRC == 1) {
           const uint2 kk = pair[t < B ? t : 0];
           kp[k] = kk.x - c0;
           kn[k] = kk.y - c0;
+        } else if (SRC == 2) {
+          kp[k] = (uint32_t)pos[t < B ? t : 0] - c0;
+          kn[k] = 0xFFFFFFFFu;  // (never in a chunk)
         } else {
           kp[k] = (uint32_t)pos[t < B ? t : 0] - c0;
           kn[k] = (uint32_t)neg[t < B ? t : 0] - c0;
@@ -399,10 +405,13 @@ __global__ __launch_bounds__(GRP_THREADS) void batch_group_items_kernel(const in
 #pragma unroll
         for (int k = 0; k < GRP_U; ++k) {
           const int t = t0 + k * GRP_THREADS;
-          if (PAIRED) {
+          if (SRC == 1) {
             const uint2 kk = pair[t < B ? t : 0];
             kp[k] = kk.x - c0;
             kn[k] = kk.y - c0;
+          } else if (SRC == 2) {
+            kp[k] = (uint32_t)pos[t < B ? t : 0] - c0;
+            kn[k] = 0xFFFFFFFFu;  // (never in a chunk)
           } else {
             kp[k] = (uint32_t)pos[t < B ? t : 0] - c0;
             kn[k] = (uint32_t)neg[t < B ? t : 0] - c0;
@@ -414,13 +423,13 @@ __global__ __launch_bounds__(GRP_THREADS) void batch_group_items_kernel(const in
           if (t < B) {
             if (kp[k] - r0 < nr) {
               const uint32_t slot = atomicAdd(&cur[kp[k]], 1u), o = slot - wb;
-              if (o < (uint32_t)GRP_CAP) stage[o] = (kp[k] << pb) | (2u * (uint32_t)t);
-              else { keys[base + slot] = kp[k] + c0; vals[base + slot].tw = 2u * (uint32_t)t; }
+              if (o < (uint32_t)GRP_CAP) stage[o] = (kp[k] << pb) | ((uint32_t)PER * (uint32_t)t);
+              else { keys[base + slot] = kp[k] + c0; vals[base + slot].tw = (uint32_t)PER * (uint32_t)t + pay0; }
             }
             if (kn[k] - r0 < nr) {
               const uint32_t slot = atomicAdd(&cur[kn[k]], 1u), o = slot - wb;
               if (o < (uint32_t)GRP_CAP) stage[o] = (kn[k] << pb) | (2u * (uint32_t)t + 1u);
-              else { keys[base + slot] = kn[k] + c0; vals[base + slot].tw = 2u * (uint32_t)t + 1u; }
+              else { keys[base + slot] = kn[k] + c0; vals[base + slot].tw = 2u * (uint32_t)t + 1u + pay0; }
             }
           }
         }
@@ -430,7 +439,7 @@ __global__ __launch_bounds__(GRP_THREADS) void batch_group_items_kernel(const in
       for (uint32_t o = threadIdx.x; o < nst; o += GRP_THREADS) {  // coalesced write-out
         const uint32_t word = stage[o];
         keys[base + wb + o] = (word >> pb) + c0;
-        vals[base + wb + o].tw = word & pmask;
+        vals[base + wb + o].tw = (word & pmask) + pay0;
       }
       __syncthreads();
     }
@@ -1116,11 +1125,11 @@ extern "C" int trs_epoch_presort(const int32_t* stream_ui_dev, const int32_t* ne
     // hand-written grouping (counting sort in LDS, one workgroup per batch): no key array, no vendor library
     static bool attr_done = false;
     if (!attr_done) {
-      (void)hipFuncSetAttribute((const void*)batch_group_items_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      (void)hipFuncSetAttribute((const void*)batch_group_items_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (GRP_BINS + GRP_CAP) * 4);
       attr_done = true;
     }
-    hipLaunchKernelGGL(batch_group_items_kernel<false>, dim3((unsigned)n_batches), dim3(GRP_THREADS),
+    hipLaunchKernelGGL(batch_group_items_kernel<0>, dim3((unsigned)n_batches), dim3(GRP_THREADS),
                        (size_t)(GRP_BINS + GRP_CAP) * 4, s, (const int32_t*)pos_dev, (const int32_t*)neg_dev, batch,
                        n_items, pay_bits, kin + n, vout);
     TRS_CHECK_LAUNCH("batch_group_items_kernel");
@@ -1311,10 +1320,26 @@ extern "C" int trs_epoch_user_dups(const int32_t* user_dev, int64_t n_batches, i
   // one segment per batch; the sort reads the user ids where they lie (non-negative int32 = uint32 keys) and numbers
   // the positions q with a counting iterator — no key / payload arrays are built first: two 10-bit passes for up to
   // 2^20 users
-  hipError_t e = rocprim::segmented_radix_sort_pairs<UserSortCfg>(
-      temp_dev, temp, (const uint32_t*)user_dev, kin + n_pos, rocprim::counting_iterator<uint32_t>(0), vin + n_pos,
-      (size_t)n_pos, (unsigned)n_batches, seg_it(0, (uint32_t)batch), seg_it(1, (uint32_t)batch), 0u,
-      (unsigned)user_bits, s);
+  hipError_t e = hipSuccess;
+  const char* vs_env = getenv("TRS_VENDOR_SORT");
+  if (!(vs_env && atoi(vs_env) != 0) && n_users <= (int64_t)GRP_BINS * GRP_MAX_CHUNKS &&
+      GRP_BIN_BITS + bits_for(batch) <= 32) {
+    // small user tables: the batch's users grouped by the hand-written counting sort (one reference per position)
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute((const void*)batch_group_items_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (GRP_BINS + GRP_CAP) * 4);
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(batch_group_items_kernel<2>, dim3((unsigned)n_batches), dim3(GRP_THREADS),
+                       (size_t)(GRP_BINS + GRP_CAP) * 4, s, user_dev, (const int32_t*)nullptr, batch, n_users,
+                       bits_for(batch), kin + n_pos, (RefPayload*)(vin + n_pos));
+  } else {
+    e = rocprim::segmented_radix_sort_pairs<UserSortCfg>(
+        temp_dev, temp, (const uint32_t*)user_dev, kin + n_pos, rocprim::counting_iterator<uint32_t>(0), vin + n_pos,
+        (size_t)n_pos, (unsigned)n_batches, seg_it(0, (uint32_t)batch), seg_it(1, (uint32_t)batch), 0u,
+        (unsigned)user_bits, s);
+  }
   if (e == hipSuccess) {
     (void)hipMemsetAsync(flags_out_dev, 0, (size_t)n_pos, s);
     hipLaunchKernelGGL((user_flags_kernel<uint32_t>), gr, bl, 0, s, kin + n_pos, vin + n_pos, n_pos, batch,
@@ -1385,11 +1410,11 @@ extern "C" int trs_epoch_presort_meta(const int32_t* pos_dev, const int32_t* neg
     // the column's references grouped by the hand-written counting sort (categories = rows; keys interleaved in kin)
     static bool attr_done = false;
     if (!attr_done) {
-      (void)hipFuncSetAttribute((const void*)batch_group_items_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      (void)hipFuncSetAttribute((const void*)batch_group_items_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (GRP_BINS + GRP_CAP) * 4);
       attr_done = true;
     }
-    hipLaunchKernelGGL(batch_group_items_kernel<true>, dim3((unsigned)n_batches), dim3(GRP_THREADS),
+    hipLaunchKernelGGL(batch_group_items_kernel<1>, dim3((unsigned)n_batches), dim3(GRP_THREADS),
                        (size_t)(GRP_BINS + GRP_CAP) * 4, s, (const int32_t*)kin, (const int32_t*)nullptr, batch, n_cat,
                        bits_for(2 * batch), kin + n, vin + n);
     TRS_CHECK_LAUNCH("batch_group_items_kernel");
