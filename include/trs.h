@@ -502,14 +502,18 @@ int trs_bn_relu_forward(const void* y_dev, int32_t y_bf16, int64_t rows_per_pass
  * Synchronised BatchNorm under data parallelism (statistics over the GLOBAL batch): phase 1 only reduces —
  * sums_dev (passes,2,H) receives this rank's sum(d) and sum(d*xhat) per pass, dgamma / dbeta are written; the caller
  * all-reduces sums_dev (SUM) and calls phase 2, which applies with those sums and stat_rows = world * rows_per_pass as
- * the divisor.  phase 0 (sums_dev NULL, stat_rows 0) = both at once on the local batch. */
+ * the divisor.  phase 0 (sums_dev NULL, stat_rows 0) = both at once on the local batch.
+ * Outer-product form (the last hidden layer: its dx is the H -> 1 output layer's input gradient g (x) w, mlp.py:115):
+ * dx_dev NULL and outer_g_dev (passes*rows_per_pass) / outer_w_dev (H) given — dx[r][c] = g[r] * w[c] is formed in the
+ * kernels and never stored (needs H % 4 == 0). */
 int64_t trs_bn_backward_workspace_floats(int64_t rows_per_pass, int32_t H, int32_t passes);
 int trs_bn_relu_backward(const void* y_dev, int32_t y_bf16, const void* dx_dev, int32_t dx_bf16, int64_t rows_per_pass,
                          int32_t passes, int32_t H,
                          int64_t ld, int64_t ldd, int32_t use_bn, const float* mean_dev, const float* var_dev,
                          const float* gamma_dev, const float* beta_dev, float eps, float* dy_dev, void* dy_bf16_dev,
                          float* dgamma_dev, float* dbeta_dev, float* dy_colsum_dev, float* workspace_dev,
-                         int32_t phase, float* sums_dev, int64_t stat_rows, void* stream);
+                         int32_t phase, float* sums_dev, int64_t stat_rows, const float* outer_g_dev,
+                         const float* outer_w_dev, void* stream);
 
 /* out[h] = sum_r w[r] * x[r][h] over the passes*rows_per_pass rows (row_weight NULL: plain column sums): bias
  * gradients and the output layer's weight gradient.  Summed per pass first (identical chunking in both passes), so a

@@ -609,6 +609,19 @@ def test_bn_stats_forward_backward(B, H, passes):
     assert rel_err(dy.cpu().numpy(), ref_dy.reshape(rows, H)) < 2e-5
     assert rel_err(dg.cpu().numpy(), s2.sum(axis=0).reshape(-1)) < 2e-5
     assert rel_err(db.cpu().numpy(), s1.sum(axis=0).reshape(-1)) < 2e-5
+    if H % 4 == 0:  # outer-product form: dx[r][c] = g[r] * w[c] formed inside the kernels == the materialised dx
+        g = rs.normal(0, 1, rows).astype(np.float32)
+        w = rs.normal(0, 1, H).astype(np.float32)
+        tgv, tw = torch.from_numpy(g).to(DEV), torch.from_numpy(w).to(DEV)
+        dxo = torch.empty_like(ty)
+        ops.outer(tgv, tw, dxo)
+        dy_a, dg_a, db_a = torch.empty_like(ty), torch.empty(H, device=DEV), torch.empty(H, device=DEV)
+        dy_b, dg_b, db_b = torch.empty_like(ty), torch.empty(H, device=DEV), torch.empty(H, device=DEV)
+        ops.bn_relu_backward(ty, dxo, B, passes, True, mean, var, tg, tb, 1e-5, dy_a, dg_a, db_a)
+        ops.bn_relu_backward(ty, None, B, passes, True, mean, var, tg, tb, 1e-5, dy_b, dg_b, db_b, outer=(tgv, tw))
+        assert torch.equal(dy_a, dy_b) and torch.equal(dg_a, dg_b) and torch.equal(db_a, db_b)
+        ops.bn_relu_backward(ty, None, B, passes, False, None, None, None, None, 1e-5, dy_b, None, None, outer=(tgv, tw))
+        assert np.array_equal(dy_b.cpu().numpy(), dxo.cpu().numpy() * (y > 0))
     # no-BN variants
     ops.bn_relu_forward(ty, B, passes, False, 1, None, None, None, None, 1e-5, out)
     assert np.array_equal(out.cpu().numpy(), np.maximum(y, 0))

@@ -285,6 +285,9 @@ struct BnBwdArgs {
   const unsigned short* y16;   // bf16 images of y / dx when the fp32 pointers are NULL (bf16-resident path)
   const unsigned short* dx16;
   float inv_n;  // 1 / rows the statistics were taken over (rows_per_pass; world * rows_per_pass under sync-BatchNorm)
+  // OUTER kernels: dx[r][c] = og[r] * ow[c] is formed on the fly (the H -> 1 output layer's input gradient, never stored)
+  const float* og;
+  const float* ow;
 };
 
 __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
@@ -500,7 +503,7 @@ __device__ __forceinline__ float4 ld4t(const float* p32, const unsigned short* p
   return *reinterpret_cast<const float4*>(p32 + off);
 }
 
-template <bool Y16, bool DX16>
+template <bool Y16, bool DX16, bool OUTER = false>
 __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_reduce_v4_kernel(const BnBwdArgs a, int tpr) {
   __shared__ float4 sh[2][TRS_BLOCK];
   const int tc = threadIdx.x % tpr, rl = threadIdx.x / tpr, nrl = TRS_BLOCK / tpr;
@@ -511,6 +514,7 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_reduce_v4_kernel(const BnBwd
   const int64_t r0 = (int64_t)chunk * CHUNK_ROWS;
   const int64_t r1 = (r0 + CHUNK_ROWS < a.rows_per_pass) ? r0 + CHUNK_ROWS : a.rows_per_pass;
   const int64_t base = (int64_t)pass * a.rows_per_pass;
+  const float4 ow4 = OUTER ? *reinterpret_cast<const float4*>(a.ow + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
   float mu[4] = {0.f, 0.f, 0.f, 0.f}, is[4] = {1.f, 1.f, 1.f, 1.f}, ga[4] = {1.f, 1.f, 1.f, 1.f}, be[4] = {0.f, 0.f, 0.f, 0.f};
   if (a.use_bn) {
 #pragma unroll
@@ -530,7 +534,12 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_reduce_v4_kernel(const BnBwd
       const int64_t rr = r + (int64_t)u * nrl;
       const int64_t rc = rr < r1 ? rr : r1 - 1;
       yv[u] = ld4t<Y16>(a.y, a.y16, (base + rc) * a.ld + cc);
-      dv[u] = ld4t<DX16>(a.dx, a.dx16, (base + rc) * a.ldd + cc);
+      if (OUTER) {
+        const float gr = a.og[base + rc];
+        dv[u] = make_float4(gr * ow4.x, gr * ow4.y, gr * ow4.z, gr * ow4.w);
+      } else {
+        dv[u] = ld4t<DX16>(a.dx, a.dx16, (base + rc) * a.ldd + cc);
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -610,7 +619,7 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_relu_fwd_v4_kernel(const BnFwdAr
 }
 
 // dy from (y, dx, final sums) with the same thread-owns-columns layout; optionally the per-chunk column sums of dy.
-template <bool Y16, bool DX16>
+template <bool Y16, bool DX16, bool OUTER = false>
 __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_apply_v4_kernel(const BnBwdArgs a, int tpr) {
   __shared__ float4 sh[TRS_BLOCK];
   const int tc = threadIdx.x % tpr, rl = threadIdx.x / tpr, nrl = TRS_BLOCK / tpr;
@@ -621,6 +630,7 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_apply_v4_kernel(const BnBwdA
   const int64_t r0 = (int64_t)chunk * CHUNK_ROWS;
   const int64_t r1 = (r0 + CHUNK_ROWS < a.rows_per_pass) ? r0 + CHUNK_ROWS : a.rows_per_pass;
   const int64_t base = (int64_t)pass * a.rows_per_pass;
+  const float4 ow4 = OUTER ? *reinterpret_cast<const float4*>(a.ow + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
   const float invB = a.inv_n;
   float mu[4], is[4], ga[4], be[4], m1[4], m2[4];
 #pragma unroll
@@ -641,7 +651,12 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_apply_v4_kernel(const BnBwdA
       const int64_t rr = r + (int64_t)u * nrl;
       const int64_t rc = rr < r1 ? rr : r1 - 1;
       yv[u] = ld4t<Y16>(a.y, a.y16, (base + rc) * a.ld + cc);
-      dv[u] = ld4t<DX16>(a.dx, a.dx16, (base + rc) * a.ldd + cc);
+      if (OUTER) {
+        const float gr = a.og[base + rc];
+        dv[u] = make_float4(gr * ow4.x, gr * ow4.y, gr * ow4.z, gr * ow4.w);
+      } else {
+        dv[u] = ld4t<DX16>(a.dx, a.dx16, (base + rc) * a.ldd + cc);
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -1036,8 +1051,12 @@ extern "C" int trs_bn_relu_backward(const void* y_dev, int32_t y_bf16, const voi
                                     const float* var_dev, const float* gamma_dev, const float* beta_dev, float eps,
                                     float* dy_dev, void* dy_bf16_dev, float* dgamma_dev, float* dbeta_dev,
                                     float* dy_colsum_dev, float* workspace_dev, int32_t phase, float* sums_dev,
-                                    int64_t stat_rows, void* stream) {
-  TRS_REQUIRE(y_dev && dx_dev && (dy_dev || dy_bf16_dev || phase == 1) && workspace_dev,
+                                    int64_t stat_rows, const float* outer_g_dev, const float* outer_w_dev,
+                                    void* stream) {
+  const bool outer = outer_g_dev != nullptr;
+  TRS_REQUIRE((outer_g_dev == nullptr) == (outer_w_dev == nullptr) && (!outer || (!dx_dev && !dx_bf16)),
+              "trs_bn_relu_backward: the outer-product form takes (outer_g, outer_w) INSTEAD of dx");
+  TRS_REQUIRE(y_dev && (dx_dev || outer) && (dy_dev || dy_bf16_dev || phase == 1) && workspace_dev,
               "trs_bn_relu_backward: NULL argument");
   TRS_REQUIRE(phase >= 0 && phase <= 2 && (phase == 0 || (sums_dev && use_bn)) && stat_rows >= 0,
               "trs_bn_relu_backward: phases 1 / 2 need BatchNorm and the (passes,2,H) sums buffer");
@@ -1054,9 +1073,11 @@ extern "C" int trs_bn_relu_backward(const void* y_dev, int32_t y_bf16, const voi
                  rows_per_pass, ld, ldd, H, passes, use_bn, nc, mean_dev, var_dev, gamma_dev, beta_dev, eps,
                  workspace_dev, sums, dy_colsum_dev ? cs_part : nullptr, (unsigned short*)dy_bf16_dev,
                  y_bf16 ? (const unsigned short*)y_dev : nullptr, dx_bf16 ? (const unsigned short*)dx_dev : nullptr,
-                 1.0f / (float)(stat_rows > 0 ? stat_rows : rows_per_pass)};
+                 1.0f / (float)(stat_rows > 0 ? stat_rows : rows_per_pass), outer_g_dev, outer_w_dev};
   const bool v4in = H % 4 == 0 && ld % 4 == 0 && ldd % 4 == 0 && ((uintptr_t)y_dev & (y_bf16 ? 7 : 15)) == 0 &&
-                    ((uintptr_t)dx_dev & (dx_bf16 ? 7 : 15)) == 0 && v4_ok(workspace_dev, H, 4);
+                    ((uintptr_t)dx_dev & (dx_bf16 ? 7 : 15)) == 0 && v4_ok(workspace_dev, H, 4) &&
+                    (!outer || ((uintptr_t)outer_w_dev & 15) == 0);
+  TRS_REQUIRE(!outer || (v4in && use_bn >= 0), "trs_bn_relu_backward: the outer-product form needs H %% 4 == 0 and aligned rows");
   const bool v4a = v4in && (!dy_dev || v4_ok(dy_dev, H, ldd)) && (!dy_bf16_dev || ((uintptr_t)dy_bf16_dev & 7) == 0);
   TRS_REQUIRE(v4a || phase == 1 || (dy_dev && !dy_bf16_dev && !h16),
               "trs_bn_relu_backward: bf16 images need H %% 4 == 0 and aligned rows");
@@ -1065,11 +1086,13 @@ extern "C" int trs_bn_relu_backward(const void* y_dev, int32_t y_bf16, const voi
   const dim3 g4(v.gx, nc, passes), bl(TRS_BLOCK);
   // (y, dx) image types of the bf16-resident path: (bf16, bf16) inside the net, (bf16, fp32) at the last hidden layer
   // (its dx comes from the fp32 H -> 1 output layer)
-#define TRS_BWD(KERNEL)                                                                     \
-  {                                                                                         \
-    if (y_bf16 && dx_bf16) hipLaunchKernelGGL((KERNEL<true, true>), g4, bl, 0, s, a, v.tpr); \
-    else if (y_bf16) hipLaunchKernelGGL((KERNEL<true, false>), g4, bl, 0, s, a, v.tpr);      \
-    else hipLaunchKernelGGL((KERNEL<false, false>), g4, bl, 0, s, a, v.tpr);                 \
+#define TRS_BWD(KERNEL)                                                                             \
+  {                                                                                                 \
+    if (outer && y_bf16) hipLaunchKernelGGL((KERNEL<true, false, true>), g4, bl, 0, s, a, v.tpr);   \
+    else if (outer) hipLaunchKernelGGL((KERNEL<false, false, true>), g4, bl, 0, s, a, v.tpr);       \
+    else if (y_bf16 && dx_bf16) hipLaunchKernelGGL((KERNEL<true, true>), g4, bl, 0, s, a, v.tpr);   \
+    else if (y_bf16) hipLaunchKernelGGL((KERNEL<true, false>), g4, bl, 0, s, a, v.tpr);             \
+    else hipLaunchKernelGGL((KERNEL<false, false>), g4, bl, 0, s, a, v.tpr);                        \
   }
   TRS_REQUIRE(!dx_bf16 || y_bf16, "trs_bn_relu_backward: a bf16 dx comes with a bf16 y");
   if (use_bn && phase != 2) {

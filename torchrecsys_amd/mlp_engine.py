@@ -212,8 +212,14 @@ class MLPCompute:
         ol = net.output_layer
         ops.colsum(xL, slot(ol.weight).reshape(-1), row_weight=g, passes=passes)
         ops.colsum(g.reshape(-1, 1), slot(ol.bias), passes=passes)
-        dx = torch.empty_like(xL)
-        ops.outer(g, ol.weight.data.reshape(-1), dx)
+        # the output layer's input gradient dx[r][c] = g[r] * w[c]: formed inside the last hidden layer's backward kernels
+        # (never stored) when their 4-column form applies; else materialised
+        w_out = ol.weight.data.reshape(-1)
+        outer = (g, w_out) if (L > 0 and xL.shape[1] % 4 == 0 and ctx["y"][L - 1].stride(0) % 4 == 0) else None
+        dx = None
+        if outer is None:
+            dx = torch.empty_like(xL)
+            ops.outer(g, w_out, dx)
         if on_group_done:
             on_group_done(L)
         res = ctx.get("resident", False)
@@ -226,23 +232,25 @@ class MLPCompute:
                 dy16 = torch.empty(y.shape, dtype=torch.bfloat16, device=y.device)
             else:
                 dy, dy16 = torch.empty_like(y), None
+            ou = outer if l == L - 1 else None  # (dx is None exactly then)
             if use_bn and sync:  # statistics of the global batch: reduce, all-reduce the 2*passes*H sums, apply
                 import torch.distributed as dist
                 bn = net.bns[l]
                 sums = torch.empty((passes, 2, y.shape[1]), dtype=torch.float32, device=y.device)
                 args = (y, dx, B, passes, True, ctx["mean"][l], ctx["var"][l], bn.weight.data, bn.bias.data, BN_EPS, dy,
                         slot(bn.weight), slot(bn.bias))
-                ops.bn_relu_backward(*args, dy_colsum=slot(fc.bias), dy16=dy16, phase=1, sums=sums)
+                ops.bn_relu_backward(*args, dy_colsum=slot(fc.bias), dy16=dy16, phase=1, sums=sums, outer=ou)
                 dist.all_reduce(sums, op=dist.ReduceOp.SUM)
                 ops.bn_relu_backward(*args, dy_colsum=grads[fc.bias], dy16=dy16, phase=2, sums=sums,
-                                     stat_rows=tdist.world_info()[1] * B)
+                                     stat_rows=tdist.world_info()[1] * B, outer=ou)
             elif use_bn:
                 bn = net.bns[l]
                 ops.bn_relu_backward(y, dx, B, passes, True, ctx["mean"][l], ctx["var"][l], bn.weight.data, bn.bias.data,
-                                     BN_EPS, dy, slot(bn.weight), slot(bn.bias), dy_colsum=slot(fc.bias), dy16=dy16)
+                                     BN_EPS, dy, slot(bn.weight), slot(bn.bias), dy_colsum=slot(fc.bias), dy16=dy16,
+                                     outer=ou)
             else:
                 ops.bn_relu_backward(y, dx, B, passes, False, None, None, None, None, BN_EPS, dy, None, None,
-                                     dy_colsum=slot(fc.bias), dy16=dy16)  # db = column sums of dy, from the same kernel
+                                     dy_colsum=slot(fc.bias), dy16=dy16, outer=ou)  # db = column sums of dy, same kernel
             if res:
                 self._gemm16(True, dy16, ctx["x"][l], out=slot(fc.weight))   # dW = dy^T x (transposing LDS reads)
                 if on_group_done:

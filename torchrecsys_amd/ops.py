@@ -585,17 +585,21 @@ def bn_relu_forward(y, rows_per_pass, passes, use_bn, stat_passes, mean, var, ga
 
 
 def bn_relu_backward(y, dx, rows_per_pass, passes, use_bn, mean, var, gamma, beta, eps, dy, dgamma, dbeta,
-                     dy_colsum=None, dy16=None, phase=0, sums=None, stat_rows=0):
+                     dy_colsum=None, dy16=None, phase=0, sums=None, stat_rows=0, outer=None):
     """phase 0: whole backward on the local batch.  Synchronised BatchNorm: phase 1 (reduce: `sums` (passes,2,H) fp32
-    receives sum(d), sum(d*xhat)), all-reduce `sums`, phase 2 (apply with stat_rows = world * rows_per_pass)."""
+    receives sum(d), sum(d*xhat)), all-reduce `sums`, phase 2 (apply with stat_rows = world * rows_per_pass).
+    outer=(g, w) with dx=None: dx[r][c] = g[r] * w[c] formed inside the kernels (the output layer's input gradient)."""
     lib = _lib.load()
     H = y.shape[1]
     ws = _workspace(y.device, 4 * lib.trs_bn_backward_workspace_floats(rows_per_pass, H, passes))
-    check(lib.trs_bn_relu_backward(ptr(y), int(y.dtype == torch.bfloat16), ptr(dx), int(dx.dtype == torch.bfloat16),
-                                   rows_per_pass, passes, H, y.stride(0), dx.stride(0), int(use_bn),
+    ldd = dx.stride(0) if dx is not None else (dy16 if dy16 is not None else dy).stride(0)
+    og, ow = outer if outer is not None else (None, None)
+    check(lib.trs_bn_relu_backward(ptr(y), int(y.dtype == torch.bfloat16), ptr(dx),
+                                   int(dx is not None and dx.dtype == torch.bfloat16),
+                                   rows_per_pass, passes, H, y.stride(0), ldd, int(use_bn),
                                    ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps), ptr(dy), ptr(dy16),
                                    ptr(dgamma), ptr(dbeta), ptr(dy_colsum), ptr(ws), int(phase), ptr(sums),
-                                   int(stat_rows), _stream()), "trs_bn_relu_backward")
+                                   int(stat_rows), ptr(og), ptr(ow), _stream()), "trs_bn_relu_backward")
 
 
 def colsum(x, out, row_weight=None, passes=1):
