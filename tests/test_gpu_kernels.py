@@ -414,6 +414,29 @@ def test_gemm_f32_all_layouts(M, N, K, tA, tB):
     assert rel_err(out2.cpu().numpy(), opA @ opB) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K,stats", [(32768, 512, 160, True), (32768, 384, 96, False), (65536, 256, 32, True)])
+def test_gemm_f32_nt_lds_dma_kernel(M, N, K, stats, monkeypatch):
+    """fp32 NT GEMMs whose 256-row tiles fill the chip take gemm32_nt_glds_kernel (256 x 256 tiles, or 256 x 128 when N is
+    only a multiple of 128): exact-FMA products, bias, per-128-row BatchNorm partials; == the register-staged kernel
+    (TRS_GEMM32_NO_GLDS=1) to fp32 summation accuracy."""
+    ops = _ops()
+    rs = np.random.RandomState(M % 97 + N)
+    A = torch.from_numpy(rs.normal(0, 1, (M, K)).astype(np.float32)).to(DEV)
+    Bm = torch.from_numpy(rs.normal(0, 1, (N, K)).astype(np.float32)).to(DEV)
+    bias = torch.from_numpy(rs.normal(0, 1, N).astype(np.float32)).to(DEV)
+    ref = A.double() @ Bm.double().T + bias.double()[None, :]
+    part = torch.empty((M // 128, 2, N), dtype=torch.float32, device=DEV) if stats else None
+    out = ops.gemm(False, True, A, Bm, bias=bias, bn_part=part)
+    assert float((out.double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    if stats:
+        r3 = ref.reshape(M // 128, 128, N)
+        assert rel_err(part[:, 0].cpu().numpy(), r3.mean(dim=1).cpu().numpy()) < 1e-5
+        assert rel_err(part[:, 1].cpu().numpy(), ((r3 - r3.mean(dim=1, keepdim=True)) ** 2).sum(dim=1).cpu().numpy()) < 1e-5
+    monkeypatch.setenv("TRS_GEMM32_NO_GLDS", "1")
+    out2 = ops.gemm(False, True, A, Bm, bias=bias)
+    assert float((out - out2).abs().max()) < 2e-5 * float(ref.abs().max())
+
+
 def test_gemm_split_k_wgrad_shape_and_strided_views():
     """dW = dy^T x with K = 2B rows (split-K path) and operands that are column-slices of wider buffers."""
     ops = _ops()

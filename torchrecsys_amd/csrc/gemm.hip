@@ -728,6 +728,136 @@ __global__ __launch_bounds__(512) void gemm16_nt_glds_kernel(const Gemm16Args g)
   }
 }
 
+// ---- fp32 NT form on the LDS-DMA structure: C(M,N) = alpha * A(M,K) B(N,K)^T (+ bias), both operands k-contiguous
+// (forward y = x W^T; input gradient dx = dy W through a transposed copy of W).  A tile row = 32 floats = 128 bytes — the
+// byte geometry of the bf16 kernel above, so the DMA pieces, the swizzle and the epilogue are the same; a fragment read
+// is one ds_read_b128 = four consecutive k of a row (both lane halves read the same 16 bytes), which feeds two
+// v_mfma_f32_32x32x2_f32 steps (lane half lk takes element lk, then 2 + lk).  256 x BNT x 32 tiles, 8 waves: BNT = 256
+// as 2 x 4 waves of 128 x 64 (BatchNorm partials wave-local), BNT = 128 as 4 x 2 waves of 64 x 64 (no statistics).
+// Per k-tile a wave issues 128 (64) MFMAs of 64 cycles against one 64 (48) KB tile of DMA: the matrix pipe, not the
+// load path, sets the pace (the register-staged 128 x 128 kernel: 102 TFLOP/s at c3's shapes).
+__device__ __forceinline__ void g32_piece(const float* __restrict__ P, int64_t ld, int64_t row0, int64_t k0,
+                                          char* lds_tile, int piece, int lane) {
+  const int row = piece * 8 + (lane >> 3);
+  const float* src = P + (row0 + row) * ld + k0 + (((lane & 7) ^ ((row >> 1) & 7)) << 2);
+  __builtin_amdgcn_global_load_lds((g3_gptr)src, (g3_lptr)(lds_tile + piece * 1024), 16, 0, 0);
+}
+
+template <int BNT>
+__global__ __launch_bounds__(512) void gemm32_nt_glds_kernel(const GemmArgs g) {
+  constexpr int WN = BNT / 64, WM = 8 / WN, TM = 256 / WM, MI = TM / 32;  // 2 x 4 of 128 x 64 | 4 x 2 of 64 x 64
+  constexpr int TILE_A = 256 * 128, TILE_B = BNT * 128, STAGE = TILE_A + TILE_B;
+  constexpr int PA = 32 / 8, PB = (BNT / 8) / 8;  // DMA pieces per wave and tile: A 4, B 4 | 2
+  __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE > 8 * 16384 ? 2 * STAGE : 8 * 16384];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  int64_t lid = blockIdx.x;
+  const int64_t nwg = gridDim.x;
+  if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);
+  const int bx = (int)(lid % g.gx), by = (int)(lid / g.gx);
+  const int64_t m0 = (int64_t)by * 256, n0 = (int64_t)bx * BNT;
+  const int nk = (int)(g.K / 32);
+  f32x16 acc[MI][2];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int lr = lane & 31, lk = lane >> 5;
+  const int f = (lr >> 1) & 7;
+#pragma unroll
+  for (int q = 0; q < PA; ++q) g32_piece(g.A, g.lda, m0, 0, lds, wave * PA + q, lane);
+#pragma unroll
+  for (int q = 0; q < PB; ++q) g32_piece(g.B, g.ldb, n0, 0, lds + TILE_A, wave * PB + q, lane);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk;
+    char* nxt = lds + (cur ^ 1) * STAGE;
+    const int64_t kn = (int64_t)(kt + 1) * 32;
+    const char* ta = lds + cur * STAGE + (wm * TM + lr) * 128;
+    const char* tb = lds + cur * STAGE + TILE_A + (wn * 64 + lr) * 128;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {  // 16-byte chunk = 4 k
+      const int sw = (c ^ f) << 4;
+      f32x4 a[MI], b[2];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const f32x4*>(ta + i * 32 * 128 + sw);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f32x4*>(tb + j * 32 * 128 + sw);
+      if (more) {  // the next tile's DMA pieces, one or two per chunk step, behind the fragment reads
+        if (c < PA) g32_piece(g.A, g.lda, m0, kn, nxt, wave * PA + c, lane);
+        else if (c - PA < PB) g32_piece(g.B, g.ldb, n0, kn, nxt + TILE_A, wave * PB + (c - PA), lane);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float av = lk ? a[i][2 * h + 1] : a[i][2 * h];
+            const float bv = lk ? b[j][2 * h + 1] : b[j][2 * h];
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+          }
+      }
+    }
+  }
+  // epilogue (as gemm16_nt_glds_kernel): alpha * acc + bias through the wave's 16 KB of LDS, 16-byte stores
+  float bv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bv[j] = g.bias ? g.bias[n0 + wn * 64 + j * 32 + lr] : 0.f;
+  __syncthreads();
+  float* stage = reinterpret_cast<float*>(lds + wave * 16384);
+#pragma unroll
+  for (int h = 0; h < MI / 2; ++h) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = g.alpha * acc[2 * h + ii][j][r] + bv[j];
+          acc[2 * h + ii][j][r] = v;
+          stage[(ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * 64 + j * 32 + lr] = v;
+        }
+    const int64_t row_h = m0 + wm * TM + h * 64, col_w = n0 + wn * 64;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = q * 4 + (lane >> 4), cg = lane & 15;
+      *reinterpret_cast<f32x4*>(g.C + (row_h + row) * g.ldc + col_w + cg * 4) =
+          *reinterpret_cast<const f32x4*>(stage + row * 64 + cg * 4);
+    }
+  }
+  if (MI == 4 && g.bn_part) {  // (BNT = 256) statistics of the stored values over this wave's 128 rows, per column
+    float* o = g.bn_part + (int64_t)(by * 2 + wm) * 2 * g.N;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float s_ = 0.f;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_ += acc[i][j][r];
+      s_ += __shfl_xor(s_, 32, 64);
+      const float mean = s_ * (1.0f / 128.0f);
+      float q_ = 0.f;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float d = acc[i][j][r] - mean;
+          q_ += d * d;
+        }
+      q_ += __shfl_xor(q_, 32, 64);
+      if (lk == 0) {
+        const int64_t col = n0 + wn * 64 + j * 32 + lr;
+        o[col] = mean;
+        o[g.N + col] = q_;
+      }
+    }
+  }
+}
+
 // fp32 (rows, cols) -> bf16 copy (same layout) and, optionally, the transposed bf16 copy (cols, rows): the per-step
 // refresh of the MLP's weight images (tiny: the weights, not the activations).
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, int64_t rows, int64_t cols,
@@ -845,6 +975,22 @@ static int gemm_impl(bool bf16, int transA, int transB, int64_t M, int64_t N, in
   // split may be shorter), 16-byte loads legal
   const bool fast = g.vecA && g.vecB && M % BM == 0 && N % BN == 0 && K % BK == 0 &&
                     (int64_t)(splits - 1) * g.k_per_split < K;
+  // fp32 NT on the LDS-DMA kernel when 256-row tiles fill the chip (TRS_GEMM32_NO_GLDS=1: tuning / test knob)
+  {
+    const char* ng = getenv("TRS_GEMM32_NO_GLDS");
+    const bool want = !(ng && atoi(ng) != 0);
+    const int bnt = N % 256 == 0 ? 256 : (N % 128 == 0 && !bn_part_dev ? 128 : 0);
+    if (!bf16 && want && akc && bkc && splits == 1 && beta == 0.f && bnt && M % 256 == 0 && K % 32 == 0 &&
+        (M / 256) * (N / bnt) >= 256 && g.vecA && g.vecB && (((uintptr_t)C_dev) & 15) == 0 && ldc % 4 == 0 &&
+        (!bias_dev || true)) {
+      g.gx = (int)(N / bnt); g.gy = (int)(M / 256);
+      const dim3 grid3((unsigned)((int64_t)g.gx * g.gy));
+      if (bnt == 256) hipLaunchKernelGGL(gemm32_nt_glds_kernel<256>, grid3, dim3(512), 0, s, g);
+      else hipLaunchKernelGGL(gemm32_nt_glds_kernel<128>, grid3, dim3(512), 0, s, g);
+      TRS_CHECK_LAUNCH("gemm32_nt_glds_kernel");
+      return TRS_OK;
+    }
+  }
   if (bf16) {
 #define TRS_GEMM(A_, B_)                                                                         \
   {                                                                                              \

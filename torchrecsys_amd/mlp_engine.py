@@ -264,7 +264,14 @@ class MLPCompute:
                 self._gemm(True, False, dy, ctx["x"][l], out=slot(fc.weight), bf16=net.use_bf16)  # dW = dy^T x (split-K)
                 if on_group_done:
                     on_group_done(l)  # before the input-gradient GEMM: the collective overlaps it and the layers below
-                dx = self._gemm(False, False, dy, fc.weight.data, bf16=net.use_bf16)      # dx = dy W
+                # dx = dy W.  Tile-aligned fp32 shapes go NT through a transposed copy of W (tiny: the weights) so that the
+                # input-gradient GEMM takes the LDS-DMA kernel like the forward one (csrc/gemm.hip gemm32_nt_glds_kernel)
+                H_out, H_in = fc.weight.shape
+                if (not net.use_bf16 and dy.shape[0] % 256 == 0 and H_in % 128 == 0 and H_out % 32 == 0
+                        and (dy.shape[0] // 256) * (H_in // (256 if H_in % 256 == 0 else 128)) >= 256):
+                    dx = self._gemm(False, True, dy, fc.weight.data.t().contiguous())
+                else:
+                    dx = self._gemm(False, False, dy, fc.weight.data, bf16=net.use_bf16)
         return grads, dx
 
 
