@@ -294,6 +294,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     run(args.steps)
+    enqueued = time.perf_counter() - t0  # host time to enqueue the K steps (the GPU is still running them)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -344,6 +345,7 @@ def main():
                                    f"steps, measured in `replica_sync`"),
                    "rng": "device (Feistel epoch shuffle + Philox4x32-10 negative sampler)"},
     }
+    out["host_enqueue_ms"] = 1e3 * enqueued  # of the timed region's `1e3 * elapsed` ms: the launches run ahead of the GPU
     if not is_mlp:
         out["step_algorithmic_GBps_per_gpu"] = step_bytes * B * args.steps / elapsed / 1e9
         out["step_frac_of_hbm_peak"] = out["step_algorithmic_GBps_per_gpu"] / HBM_PEAK_GBS
