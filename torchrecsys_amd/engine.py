@@ -13,6 +13,7 @@ Moments live in optimizer.state[p] under torch's own key names, so optimizer.sta
 import os
 
 import torch
+from ctypes import addressof as C_addressof
 
 from . import ops
 
@@ -338,6 +339,16 @@ class SparseScorerTrainer:
         te, evs, ns = self._make_events(n_steps) if self.kernel_events is not None else (None, None, 0)
         if self.ustage is None:
             self.ustage = torch.empty_like(self.du)  # pre-update user rows staged by K1 for the item update
+        if isinstance(ps, ops.EpochFlags) and te is None:  # the same call with its argument struct kept between calls
+            T = self.net.tables()
+            sig = (C_addressof(T), float(self.fast_lr), int(self.loss_id), ops.ptr(self.gz), ops.ptr(self.du),
+                   ops.ptr(self.ustage), ops.ptr(self.scratch))
+            fc = getattr(self, "_flag_call", None)
+            if fc is None or fc.batch != batch or fc.sig != sig:
+                fc = self._flag_call = ops.FlagStepCall(self.net.NET, T, batch, self.fast_lr, self.gz, self.du, self.err,
+                                                        self.scratch, self.ustage, self.loss_id)
+            fc(ps, b_in_slice, n_steps, loss_sums, self._stamps(n_steps))
+            return
         if isinstance(ps, ops.EpochFlags):  # sparse regime: flags only, the flagged references follow K1 with atomics
             ids, udup, idup = ps.step_args(b_in_slice)
             ops.train_steps_sgd(self.net.NET, self.net.tables(), None, None, 0, 0, 0, batch, n_steps, self.fast_lr, *ids,

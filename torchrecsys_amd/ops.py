@@ -330,6 +330,15 @@ class EpochFlags:
                                           ptr(self.item_dup), ptr(err_flag), _samp(sampler), _stream()),
               "trs_epoch_flags")
 
+    @property
+    def base_ptrs(self):
+        """Device addresses of (user, pos, neg ids; user / item duplicate flags) — FlagStepCall offsets them itself."""
+        bp = getattr(self, "_base_ptrs", None)
+        if bp is None:
+            bp = self._base_ptrs = tuple(t.data_ptr() for t in self.ids) + (self.user_dup.data_ptr(),
+                                                                             self.item_dup.data_ptr())
+        return bp
+
     def step_args(self, b):
         """(id views, user-duplicate flags view, item-duplicate flags view) from batch b of the slice on."""
         o = b * self.batch
@@ -367,6 +376,32 @@ def train_steps_sgd(net, T, stream_ui, neg_static, shuffle_key, sample_seed, fir
         ev = (C.c_void_p * len(events))(*events)  # raw hipEvent_t handles (or None = step not timed)
         a.events = C.cast(ev, C.POINTER(C.c_void_p))
     check(_lib.load().trs_train_steps_sgd(C.byref(a), _stream()), "trs_train_steps_sgd")
+
+
+class FlagStepCall:
+    """trs_train_steps_sgd in flag mode (sparse regime) with the argument struct built ONCE: a call only writes the
+    fields that change (step count, stamp, the slice offsets of ids / flags, the loss slot).  The generic wrapper above
+    rebuilds ~40 ctypes fields per call — 50-80 us of host time that a short timed window sees as start-up latency."""
+
+    def __init__(self, net, T, batch, lr, gz_buf, du_buf, err_flag, scratch, ustage, loss):
+        a = self.a = _lib.TrsTrainArgs()
+        self.keep = (T, gz_buf, du_buf, err_flag, scratch, ustage)
+        a.net, a.tables, a.batch, a.lr, a.loss = NET_ID[net], C.pointer(T), int(batch), float(lr), int(loss)
+        a.gz_buf_dev, a.du_buf_dev = ptr(gz_buf), ptr(du_buf)
+        a.err_flag_dev, a.scratch_dev, a.ustage_buf_dev = ptr(err_flag), ptr(scratch), ptr(ustage)
+        self.batch = int(batch)
+        self.ref = C.byref(a)
+        self.fn = _lib.load().trs_train_steps_sgd
+        self.sig = (C.addressof(T), float(lr), int(loss), ptr(gz_buf), ptr(du_buf), ptr(ustage), ptr(scratch))
+
+    def __call__(self, ps, b_in_slice, n_steps, loss_sums, first_stamp):
+        a, o = self.a, b_in_slice * self.batch
+        base = ps.base_ptrs
+        a.n_steps, a.first_stamp = int(n_steps), int(first_stamp)
+        a.user_buf_dev, a.pos_buf_dev, a.neg_buf_dev = base[0] + 4 * o, base[1] + 4 * o, base[2] + 4 * o
+        a.user_dup_flags_dev, a.item_dup_flags_dev = base[3] + o, base[4] + 2 * o
+        a.loss_sums_dev = loss_sums.data_ptr()
+        check(self.fn(self.ref, _stream()), "trs_train_steps_sgd")
 
 
 def rows_scatter_add(table, idx, vals, alpha, ld=None, err_flag=None):
