@@ -82,7 +82,7 @@ def test_ctypes_structs_follow_the_header_member_by_member():
     from torchrecsys_amd import _lib
     for cname, mirror in (("trs_train_args", _lib.TrsTrainArgs), ("trs_opt", _lib.TrsOpt),
                           ("trs_meta_stage", _lib.TrsMetaStage), ("trs_tables", _lib.TrsTables),
-                          ("trs_batch", _lib.TrsBatch)):
+                          ("trs_batch", _lib.TrsBatch), ("trs_sampler", _lib.TrsSampler)):
         assert _header_struct_fields(cname) == [f[0] for f in mirror._fields_], cname
     src = open(os.path.join(ROOT, "include", "trs.h")).read()
     assert int(re.search(r"#define TRS_ABI_VERSION (\d+)", src).group(1)) == _lib.ABI_VERSION
