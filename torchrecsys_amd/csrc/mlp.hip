@@ -828,11 +828,35 @@ __global__ __launch_bounds__(TRS_BLOCK) void mlp_embed_user_item_kernel(const Em
     const int64_t r1 = (w == 2 ? B + t : t) * a.ld + (w == 0 ? 0 : D);  // first (only) d x0 segment
     const int64_t r2 = (B + t) * a.ld;                                   // the user's negative-pass segment
     float* dst = tab + id * (int64_t)D;
-    for (int d = lane; d < D; d += TRS_WAVE) {
-      float g = ld_dx1<DX16>(a, r1 + d);
-      if (w == 0) g += ld_dx1<DX16>(a, r2 + d);
-      if (alone) dst[d] -= a.lr * g;
-      else atomicAdd(dst + d, -a.lr * g);
+    for (int d0 = lane; d0 < D; d0 += 4 * TRS_WAVE) {  // four elements per lane in flight (D = 256: the whole row)
+      float g[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int d = d0 + k * TRS_WAVE;
+        const int dc = d < D ? d : d0;  // (clamped: no load inside a per-element conditional)
+        g[k] = ld_dx1<DX16>(a, r1 + dc);
+        const float g2 = ld_dx1<DX16>(a, (w == 0 ? r2 : r1) + dc);
+        if (w == 0) g[k] += g2;
+      }
+      if (alone) {  // (wave-uniform) plain read-modify-write
+        float old[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int d = d0 + k * TRS_WAVE;
+          old[k] = dst[d < D ? d : d0];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int d = d0 + k * TRS_WAVE;
+          if (d < D) dst[d] = old[k] - a.lr * g[k];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int d = d0 + k * TRS_WAVE;
+          if (d < D) atomicAdd(dst + d, -a.lr * g[k]);
+        }
+      }
     }
   }
 }
