@@ -14,8 +14,10 @@ torch.optim.SGD(lr=1e-2), fp32.  --config c2 | c1 | c3 | c5 select BASELINE.json
 metric = training interactions/s (pos+neg) = 2 x triples/s.
 
 What the timed region contains: exactly K steps through FitRunner.run_steps — the object fit() is built on — incl. the
-per-slice grouping of item references / user ids (trs_epoch_presort / trs_epoch_user_dups, prefetched on a side stream;
-slices are sized to the run so a short run carries its proportional share).  NO kernel events are recorded in it.
+per-slice presort (sparse regime, c4: trs_epoch_flags = ids + duplicate flags; dense regime, c2: trs_epoch_presort =
+ids + item references grouped by row, + user flags; prefetched on a side stream; slices are sized to the run so a
+short run carries its proportional share).  NO kernel events are recorded in it.  `host_enqueue_ms` = the host time
+that went into enqueueing the K steps (the launches run ahead of the GPU; the rest of the window is the GPU finishing).
 After it, untimed: (1) an instrumented window of the same steps with HIP events around K1 / K2 on the launch stream
 (>= 8 samples whatever --steps is) -> `roofline` of the dominant kernel; (2) the north-star pass alone
 (trs_score_forward = fused pos+neg gather + FM pairwise score) at the per-GPU batch and at the global batch 262 144
