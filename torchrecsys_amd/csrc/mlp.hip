@@ -889,6 +889,7 @@ __global__ __launch_bounds__(EMB_META_THREADS) void mlp_embed_meta_kernel(const 
   const uint32_t half = (uint32_t)B * (uint32_t)M, total = 2u * half;  // the two (B, M) id matrices, flat
   const uint32_t magic = (uint32_t)(0x100000000ull / (uint32_t)M) + 1u;  // q / M = umulhi(q, magic) for q < 2^32 / M (M > 1)
   uint32_t start = 0, span = EMB_META_THREADS * EMB_U;
+  int kept = 0;  // entries of this wave's list from earlier windows (not yet added)
   while (start < total) {  // (workgroup-uniform) windows of flat id positions
     // ---- scan: every workgroup reads ALL metadata ids of the batch (coalesced, EMB_U loads in flight per lane, none
     // inside a conditional block: a block that holds a load ends in s_waitcnt vmcnt(0)) and routes its own
@@ -918,22 +919,34 @@ __global__ __launch_bounds__(EMB_META_THREADS) void mlp_embed_meta_kernel(const 
             lists[(ow * 2 + 0) * EMB_LIST + at] = (int)((q < half ? 0u : (uint32_t)B) + r);
             lists[(ow * 2 + 1) * EMB_LIST + at] = (m << 24) | own;
           } else {
-            counts[NW] = 1;  // a list is full: the window is scanned again at half the span (nothing was added yet)
+            counts[NW] = 1;  // a list is full: this window's entries are dropped and it is scanned again (see below)
           }
         }
       }
     }
     __syncthreads();
     const bool overflow = counts[NW] != 0;
-    const int n_list = overflow ? 0 : counts[wave];
-    // ---- add: each wave sums the d x0 segments of ITS rows' references, four row loads in flight, plain LDS adds
+    const bool last = !overflow && end >= total;
+    // The lists are emptied when one is half full, at the end, and before a window is scanned again — not after every
+    // window: a window adds ~4 entries per wave (c5), i.e. one group of row loads whose latency nothing would cover.
+    const int mine = overflow ? kept : counts[wave];
+    const bool drain = __syncthreads_or((mine > EMB_LIST / 2) || overflow || last) != 0;
+    if (!drain) {  // keep collecting
+      kept = mine;
+      start = end;
+      if (span < EMB_META_THREADS * EMB_U) span *= 2;
+      continue;
+    }
+    const int n_list = mine;  // (on overflow: the entries of the earlier windows only)
+    // ---- add: each wave sums the d x0 segments of ITS rows' references, eight row loads in flight, plain LDS adds
     const int* list_row = lists + (wave * 2 + 0) * EMB_LIST;
     const int* list_own = lists + (wave * 2 + 1) * EMB_LIST;
-    for (int i = 0; i < n_list; i += 4) {
-      float4 g[4];
-      int own[4];
+    constexpr int AU = 8;
+    for (int i = 0; i < n_list; i += AU) {
+      float4 g[AU];
+      int own[AU];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < AU; ++k) {
         const int e = i + k < n_list ? i + k : n_list - 1;
         const int packed = list_own[e];
         own[k] = packed & 0xFFFFFF;
@@ -941,7 +954,7 @@ __global__ __launch_bounds__(EMB_META_THREADS) void mlp_embed_meta_kernel(const 
         g[k] = ld_dx4<DX16>(a, (int64_t)list_row[e] * a.ld + (int64_t)(2 + (packed >> 24)) * D + 4 * c);
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < AU; ++k) {
         if (i + k < n_list && lane < chunks) {
           float4* acc = reinterpret_cast<float4*>(emb_acc + (int64_t)own[k] * D) + lane;
           float4 v = *acc;
@@ -950,7 +963,7 @@ __global__ __launch_bounds__(EMB_META_THREADS) void mlp_embed_meta_kernel(const 
         }
       }
       for (int c = lane + TRS_WAVE; c < chunks; c += TRS_WAVE)  // (D > 256: the rest of the row, one entry at a time)
-        for (int k = 0; k < 4 && i + k < n_list; ++k) {
+        for (int k = 0; k < AU && i + k < n_list; ++k) {
           const int packed = list_own[i + k];
           const float4 gg = ld_dx4<DX16>(a, (int64_t)list_row[i + k] * a.ld + (int64_t)(2 + (packed >> 24)) * D + 4 * c);
           float4* acc = reinterpret_cast<float4*>(emb_acc + (int64_t)own[k] * D) + c;
@@ -962,8 +975,10 @@ __global__ __launch_bounds__(EMB_META_THREADS) void mlp_embed_meta_kernel(const 
     for (int e = lane; e < n_list; e += TRS_WAVE) touched[list_own[e] & 0xFFFFFF] = 1;
     __syncthreads();  // lists and counters are free again
     if (threadIdx.x <= NW) counts[threadIdx.x] = 0;
+    kept = 0;
     if (overflow) {
-      span = span > 2 * EMB_LIST ? span / 2 : EMB_LIST;  // <= EMB_LIST positions always fit
+      // the dropped window comes again at half the span, into empty lists (<= EMB_LIST positions always fit)
+      span = span > 2 * EMB_LIST ? span / 2 : EMB_LIST;
     } else {
       start = end;
       if (span < EMB_META_THREADS * EMB_U) span *= 2;
