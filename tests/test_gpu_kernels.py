@@ -332,6 +332,37 @@ def test_item_references_grouped_by_row(NI, B, nb, skew):
         assert np.array_equal(idup[b * B:(b + 1) * B].reshape(-1), (cnt[both] > 1).astype(np.uint8)), b
 
 
+@pytest.mark.parametrize("NU,B,nb,skew", [(3, 7, 2, False), (400, 1000, 3, False), (20_000, 65_536, 2, True),
+                                          (131_072, 4096, 2, False), (131_073, 4096, 2, False)])
+def test_users_grouped_by_row_for_the_duplicate_runs(NU, B, nb, skew):
+    """trs_epoch_user_dups: every batch's users grouped by row (the counting sort with ONE reference per position for user
+    tables up to 131 072 rows, incl. a hot user longer than the staging buffer; 131 073 rows: the segmented radix sort) —
+    keys ascending per batch, payloads the slice positions of the batch, user[payload] == key; the duplicate flags == a
+    bincount.  Bit-exact."""
+    ops = _ops()
+    rs = np.random.RandomState(NU % 991 + B)
+    n = nb * B
+    user = ((rs.zipf(1.2, n) % NU) if skew else rs.randint(0, NU, n)).astype(np.int32)
+    user[:2] = NU - 1
+    item = rs.randint(0, 50, n).astype(np.int32)
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ps = ops.EpochPresort(nb, B, NU, 50, DEV, user_sort=True, item_flags=False)
+    ps.run(None, None, 0, 0, 0, err, given_ids=(d(user), d(item), d(item)))
+    torch.cuda.synchronize()
+    assert err.item() == 0 and ps.sorted_ukeys is not None
+    keys = ps.ukeys.view(torch.uint32)[n:2 * n].cpu().numpy().astype(np.int64)
+    vals = ps.uvals.view(torch.uint32)[n:2 * n].cpu().numpy().astype(np.int64)
+    flags = ps.user_dup.cpu().numpy()
+    for b in range(nb):
+        k_, v_ = keys[b * B:(b + 1) * B], vals[b * B:(b + 1) * B]
+        ub = user[b * B:(b + 1) * B].astype(np.int64)
+        assert np.array_equal(k_, np.sort(ub)), b
+        assert np.array_equal(np.sort(v_), np.arange(b * B, (b + 1) * B)), b
+        assert np.array_equal(user[v_].astype(np.int64), k_), b
+        assert np.array_equal(flags[b * B:(b + 1) * B], (np.bincount(ub, minlength=NU)[ub] > 1).astype(np.uint8)), b
+
+
 @pytest.mark.parametrize("n,batch", [(1, 1), (1000, 7), (70_001, 512), (300, 1000), (65_536, 1024)])
 def test_hinge_auc_batches(n, batch):
     """Per-batch hinge sums / AUC counts of consecutive batches in one launch (evaluate()): each slot equals the oracle's
