@@ -401,6 +401,97 @@ __global__ __launch_bounds__(512) void gemm16_nt_persist_kernel(const u16* __res
   }
 }
 
+// Four-stage variant: k-stages of 32 (a stage = A 16 KB + B 16 KB, rows of 64 bytes), three stages of LDS-DMA in flight
+// across the barriers (counted s_waitcnt vmcnt + raw s_barrier: a __syncthreads() would drain the DMA), so a stage has
+// ~2 stage-times to land instead of one tile-time.  Swizzle for 64-byte rows: 16-byte slot ^= (row >> 2) & 3.
+__device__ __forceinline__ void s4_piece(const u16* __restrict__ P, int64_t ld, int64_t row0, int64_t k0, char* lds_op,
+                                         int piece, int lane) {
+  const int row = piece * 16 + (lane >> 2);
+  const u16* src = P + (row0 + row) * ld + k0 + (((lane & 3) ^ ((row >> 2) & 3)) << 3);
+  __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_op + piece * 1024), 16, 0, 0);
+}
+
+template <bool PRIO>
+__global__ __launch_bounds__(512) void gemm16_nt_s4_kernel(const u16* __restrict__ A, const u16* __restrict__ B,
+                                                           float* __restrict__ C, u16* __restrict__ C16, int64_t M,
+                                                           int64_t N, int64_t K, int gx) {
+  constexpr int TM = 128, TN = 64, MI = 4, NI = 2, OP = 256 * 64, STAGE = 2 * OP;  // 16 KB per operand, 32 KB per stage
+  __shared__ __attribute__((aligned(1024))) char lds[4 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  int64_t lid = blockIdx.x;
+  const int64_t nwg = gridDim.x;
+  if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);
+  const int bx = (int)(lid % gx), by = (int)(lid / gx);
+  const int64_t m0 = (int64_t)by * BMT, n0 = (int64_t)bx * BNT;
+  const int ns = (int)(K / 32);
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int lr = lane & 31, lk = lane >> 5;
+  const int f = (lr >> 2) & 3;
+  // a wave's 4 DMA pieces of a stage: 2 of A (pieces 2w, 2w+1 of 16), 2 of B
+  auto stage = [&](int s, int q) {
+    char* base = lds + (s & 3) * STAGE;
+    const int64_t k0 = (int64_t)s * 32;
+    if (q < 2) s4_piece(A, K, m0, k0, base, wave * 2 + q, lane);
+    else s4_piece(B, K, n0, k0, base + OP, wave * 2 + (q - 2), lane);
+  };
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+    if (s < ns) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) stage(s, q);
+    }
+  for (int s = 0; s < ns; ++s) {
+    // stage s has landed once at most the DMAs of the (up to two) younger stages are outstanding
+    const int younger = ns - 1 - s < 2 ? ns - 1 - s : 2;
+    if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // everyone's pieces of stage s landed; everyone finished reading stage s - 1
+    asm volatile("" ::: "memory");
+    const bool more = s + 3 < ns;
+    const char* ta = lds + (s & 3) * STAGE + (wm * TM + lr) * 64;
+    const char* tb = lds + (s & 3) * STAGE + OP + (wn * TN + lr) * 64;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int sw = ((ks * 2 + lk) ^ f) << 4;
+      bf16x8 a[MI], b[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(ta + i * 32 * 64 + sw);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 64 + sw);
+      if (more) {
+        stage(s + 3, 2 * ks);
+        stage(s + 3, 2 * ks + 1);
+      }
+      if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      if (PRIO) __builtin_amdgcn_s_setprio(0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int64_t col = n0 + wn * TN + j * 32 + lr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        C16[row * N + col] = __builtin_bit_cast(u16, (__bf16)acc[i][j][r]);
+      }
+    }
+}
+
 // Ablations of the one-barrier loop (results are wrong by construction; only the time is read):
 //   MODE 1: no LDS-DMA in the loop (every k-tile re-reads tile 0)   MODE 2: DMA + barrier, no ds_read / MFMA
 //   MODE 3: DMA + ds_reads, no MFMA                                  MODE 4: MFMA only (fragments read once)
@@ -600,6 +691,30 @@ int main(int argc, char** argv) {
              (long long)K, NAME, ms * 1e3, 2.0 * M * N * K / ms / 1e9, w, w <= 1.0 ? "ok" : "WRONG",           \
              hipGetErrorString(hipGetLastError()));                                                           \
     }
+#define RUN4(NAME, PRIO_)                                                                                      \
+    {                                                                                                         \
+      float ms = 0;                                                                                           \
+      hipLaunchKernelGGL((gemm16_nt_spread_kernel<2>), dim3(gx * gy), dim3(512), 0, 0, dA, dB, dC, dC16, M, N, K, gx); \
+      std::vector<u16> ref((size_t)M * N);                                                                    \
+      hipMemcpy(ref.data(), dC16, ref.size() * 2, hipMemcpyDeviceToHost);                                     \
+      size_t bad = 0;                                                                                         \
+      for (int rep = 0; rep < 8; ++rep) {                                                                     \
+        hipMemset(dC16, 0, (size_t)M * N * 2);                                                                \
+        if (rep == 3) hipEventRecord(e0);                                                                     \
+        hipLaunchKernelGGL((gemm16_nt_s4_kernel<PRIO_>), dim3(gx * gy), dim3(512), 0, 0, dA, dB, dC, dC16, M, N, K, gx); \
+        if (rep < 3) {  /* every element against the one-barrier kernel: same k order, so bit for bit */     \
+          std::vector<u16> got((size_t)M * N);                                                                \
+          hipMemcpy(got.data(), dC16, got.size() * 2, hipMemcpyDeviceToHost);                                 \
+          for (size_t e = 0; e < got.size(); ++e) bad += got[e] != ref[e];                                    \
+        }                                                                                                     \
+      }                                                                                                       \
+      hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); ms /= 5;                 \
+      printf("%-9s N=%4lld K=%4lld %-22s %8.1f us %7.1f TF   elements differing from the one-barrier kernel (3 runs): %zu (%s)\n", \
+             sh.name, (long long)N, (long long)K, NAME, ms * 1e3, 2.0 * M * N * K / ms / 1e9, bad,            \
+             hipGetErrorString(hipGetLastError()));                                                           \
+    }
+    RUN4("4 stages of 32", false)
+    RUN4("4 stages of 32 + setprio", true)
     RUNQ("persistent 256 WGs", 2, 256)
     RUNP("ping-pong", false)
     RUNP("ping-pong + setprio", true)
