@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstring>
 #include <vector>
+#include <dlfcn.h>
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -579,6 +580,7 @@ static float bf2f(u16 h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &
 
 int main(int argc, char** argv) {
   const int64_t M = argc > 1 ? atoll(argv[1]) : 65536;
+  const int REPS = getenv("REPS") ? atoi(getenv("REPS")) : 6;  // launches per timing (the first is not timed); 30+ = sustained load
   struct Shape { int64_t N, K; const char* name; } shapes[] = {{1024, 1280, "fwd L1"}, {512, 1024, "fwd L2"},
                                                                {256, 512, "fwd L3"}, {1280, 1024, "dgrad L1"},
                                                                {1024, 512, "dgrad L2"}, {512, 256, "dgrad L3"}};
@@ -616,11 +618,11 @@ int main(int argc, char** argv) {
     {                                                                                                         \
       float ms = 0;                                                                                           \
       hipMemset(dC, 0, (size_t)M * N * 4); hipMemset(dC16, 0, (size_t)M * N * 2);                             \
-      for (int rep = 0; rep < 6; ++rep) {                                                                     \
+      for (int rep = 0; rep < REPS; ++rep) {                                                                     \
         if (rep == 1) hipEventRecord(e0);                                                                     \
         hipLaunchKernelGGL((gemm16_nt_kernel<WM_, WN_, O16, SWZ_, M16_>), dim3(gx * gy), dim3(WM_ * WN_ * 64), 0, 0, dA, dB, dC, dC16, M, N, K, gx); \
       }                                                                                                       \
-      hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); ms /= 5;                 \
+      hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); ms /= (REPS - 1);                 \
       const double w = check(O16);                                                                            \
       printf("%-9s N=%4lld K=%4lld %-22s %8.1f us %7.1f TF   worst err/tol %.3f %s (%s)\n", sh.name, (long long)N, \
              (long long)K, NAME, ms * 1e3, 2.0 * M * N * K / ms / 1e9, w, w <= 1.0 ? "ok" : "WRONG",           \
@@ -632,11 +634,11 @@ int main(int argc, char** argv) {
     {                                                                                                         \
       float ms = 0;                                                                                           \
       hipMemset(dC16, 0, (size_t)M * N * 2);                                                                  \
-      for (int rep = 0; rep < 6; ++rep) {                                                                     \
+      for (int rep = 0; rep < REPS; ++rep) {                                                                     \
         if (rep == 1) hipEventRecord(e0);                                                                     \
         hipLaunchKernelGGL((gemm16_nt_pp_kernel<PRIO_>), dim3(gx * gy), dim3(512), 0, 0, dA, dB, dC, dC16, M, N, K, gx); \
       }                                                                                                       \
-      hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); ms /= 5;                 \
+      hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); ms /= (REPS - 1);                 \
       const double w = check(true);                                                                           \
       printf("%-9s N=%4lld K=%4lld %-22s %8.1f us %7.1f TF   worst err/tol %.3f %s (%s)\n", sh.name, (long long)N, \
              (long long)K, NAME, ms * 1e3, 2.0 * M * N * K / ms / 1e9, w, w <= 1.0 ? "ok" : "WRONG",           \
@@ -645,11 +647,11 @@ int main(int argc, char** argv) {
 #define RUNA(NAME, MODE_)                                                                                      \
     {                                                                                                         \
       float ms = 0;                                                                                           \
-      for (int rep = 0; rep < 6; ++rep) {                                                                     \
+      for (int rep = 0; rep < REPS; ++rep) {                                                                     \
         if (rep == 1) hipEventRecord(e0);                                                                     \
         hipLaunchKernelGGL((gemm16_nt_abl_kernel<MODE_>), dim3(gx * gy), dim3(512), 0, 0, dA, dB, dC, dC16, M, N, K, gx); \
       }                                                                                                       \
-      hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); ms /= 5;                 \
+      hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); ms /= (REPS - 1);                 \
       printf("%-9s N=%4lld K=%4lld %-22s %8.1f us %7.1f TF-equivalent (%s)\n", sh.name, (long long)N,        \
              (long long)K, NAME, ms * 1e3, 2.0 * M * N * K / ms / 1e9, hipGetErrorString(hipGetLastError())); \
     }
@@ -664,11 +666,11 @@ int main(int argc, char** argv) {
     {                                                                                                         \
       float ms = 0;                                                                                           \
       hipMemset(dC16, 0, (size_t)M * N * 2);                                                                  \
-      for (int rep = 0; rep < 6; ++rep) {                                                                     \
+      for (int rep = 0; rep < REPS; ++rep) {                                                                     \
         if (rep == 1) hipEventRecord(e0);                                                                     \
         hipLaunchKernelGGL((gemm16_nt_spread_kernel<SP_>), dim3(gx * gy), dim3(512), 0, 0, dA, dB, dC, dC16, M, N, K, gx); \
       }                                                                                                       \
-      hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); ms /= 5;                 \
+      hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); ms /= (REPS - 1);                 \
       const double w = check(true);                                                                           \
       printf("%-9s N=%4lld K=%4lld %-22s %8.1f us %7.1f TF   worst err/tol %.3f %s (%s)\n", sh.name, (long long)N, \
              (long long)K, NAME, ms * 1e3, 2.0 * M * N * K / ms / 1e9, w, w <= 1.0 ? "ok" : "WRONG",           \
@@ -681,11 +683,11 @@ int main(int argc, char** argv) {
     {                                                                                                         \
       float ms = 0;                                                                                           \
       hipMemset(dC16, 0, (size_t)M * N * 2);                                                                  \
-      for (int rep = 0; rep < 6; ++rep) {                                                                     \
+      for (int rep = 0; rep < REPS; ++rep) {                                                                     \
         if (rep == 1) hipEventRecord(e0);                                                                     \
         hipLaunchKernelGGL((gemm16_nt_persist_kernel<SP_>), dim3(GRID_), dim3(512), 0, 0, dA, dB, dC, dC16, M, N, K, gx); \
       }                                                                                                       \
-      hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); ms /= 5;                 \
+      hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); ms /= (REPS - 1);                 \
       const double w = check(true);                                                                           \
       printf("%-9s N=%4lld K=%4lld %-22s %8.1f us %7.1f TF   worst err/tol %.3f %s (%s)\n", sh.name, (long long)N, \
              (long long)K, NAME, ms * 1e3, 2.0 * M * N * K / ms / 1e9, w, w <= 1.0 ? "ok" : "WRONG",           \
@@ -698,7 +700,7 @@ int main(int argc, char** argv) {
       std::vector<u16> ref((size_t)M * N);                                                                    \
       hipMemcpy(ref.data(), dC16, ref.size() * 2, hipMemcpyDeviceToHost);                                     \
       size_t bad = 0;                                                                                         \
-      for (int rep = 0; rep < 8; ++rep) {                                                                     \
+      for (int rep = 0; rep < REPS + 2; ++rep) {                                                               \
         hipMemset(dC16, 0, (size_t)M * N * 2);                                                                \
         if (rep == 3) hipEventRecord(e0);                                                                     \
         hipLaunchKernelGGL((gemm16_nt_s4_kernel<PRIO_>), dim3(gx * gy), dim3(512), 0, 0, dA, dB, dC, dC16, M, N, K, gx); \
@@ -708,14 +710,32 @@ int main(int argc, char** argv) {
           for (size_t e = 0; e < got.size(); ++e) bad += got[e] != ref[e];                                    \
         }                                                                                                     \
       }                                                                                                       \
-      hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); ms /= 5;                 \
+      hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); ms /= (REPS - 1);                 \
       printf("%-9s N=%4lld K=%4lld %-22s %8.1f us %7.1f TF   elements differing from the one-barrier kernel (3 runs): %zu (%s)\n", \
              sh.name, (long long)N, (long long)K, NAME, ms * 1e3, 2.0 * M * N * K / ms / 1e9, bad,            \
              hipGetErrorString(hipGetLastError()));                                                           \
     }
+    {  // the library's kernel on the same buffers (argv[2] = path of libtrs_hip.so)
+      static void* lib = argc > 2 ? dlopen(argv[2], RTLD_NOW) : nullptr;
+      typedef int (*gemm_fn)(int, int64_t, int64_t, int64_t, float, const void*, int64_t, const void*, int64_t, float, float*,
+                             void*, int64_t, const float*, float*, void*, int64_t, void*);
+      gemm_fn fn = lib ? (gemm_fn)dlsym(lib, "trs_gemm_bf16in") : nullptr;
+      if (fn) {
+        float ms = 0;
+        for (int rep = 0; rep < REPS; ++rep) {
+          if (rep == 1) hipEventRecord(e0);
+          fn(0, M, N, K, 1.0f, dA, K, dB, K, 0.0f, nullptr, dC16, N, nullptr, nullptr, nullptr, 0, nullptr);
+        }
+        hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); ms /= (REPS - 1);
+        const double w = check(true);
+        printf("%-9s N=%4lld K=%4lld %-22s %8.1f us %7.1f TF   worst err/tol %.3f\n", sh.name, (long long)N, (long long)K,
+               "libtrs_hip.so", ms * 1e3, 2.0 * M * N * K / ms / 1e9, w);
+      }
+    }
     RUN4("4 stages of 32", false)
     RUN4("4 stages of 32 + setprio", true)
     RUNQ("persistent 256 WGs", 2, 256)
+    RUNQ("persistent, DMA after 1st reads", 1, 256)
     RUNP("ping-pong", false)
     RUNP("ping-pong + setprio", true)
     hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dC16);
