@@ -493,6 +493,72 @@ __global__ __launch_bounds__(512) void gemm16_nt_s4_kernel(const u16* __restrict
     }
 }
 
+// "reads first": all 24 fragment reads of the tile are issued right behind the barrier, then the 8 DMA pieces, then the 32
+// MFMAs run from registers — the LDS array serves the reads and the DMA writes one after the other, not interleaved
+__global__ __launch_bounds__(512) void gemm16_nt_rf_kernel(const u16* __restrict__ A, const u16* __restrict__ B,
+                                                           float* __restrict__ C, u16* __restrict__ C16, int64_t M,
+                                                           int64_t N, int64_t K, int gx) {
+  constexpr int NWAVES = 8, TM = 128, TN = 64, MI = 4, NI = 2;
+  __shared__ __attribute__((aligned(1024))) char lds[4 * TILE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  int64_t lid = blockIdx.x;
+  const int64_t nwg = gridDim.x;
+  if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);
+  const int bx = (int)(lid % gx), by = (int)(lid / gx);
+  const int64_t m0 = (int64_t)by * BMT, n0 = (int64_t)bx * BNT;
+  const int nk = (int)(K / BKT);
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int lr = lane & 31, lk = lane >> 5;
+  const int f = (lr >> 1) & 7;
+  stage_tile<NWAVES, 1>(A, K, m0, 0, lds, wave, lane);
+  stage_tile<NWAVES, 1>(B, K, n0, 0, lds + TILE_BYTES, wave, lane);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    const int cur = kt & 1;
+    const char* ta = lds + cur * 2 * TILE_BYTES + (wm * TM + lr) * 128;
+    const char* tb = lds + cur * 2 * TILE_BYTES + TILE_BYTES + (wn * TN + lr) * 128;
+    bf16x8 a[4][MI], b[4][NI];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int sw = ((ks * 2 + lk) ^ f) << 4;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) a[ks][i] = *reinterpret_cast<const bf16x8*>(ta + i * 32 * 128 + sw);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) b[ks][j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 128 + sw);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < nk) {
+      stage_tile<NWAVES, 1>(A, K, m0, (int64_t)(kt + 1) * BKT, lds + (cur ^ 1) * 2 * TILE_BYTES, wave, lane);
+      stage_tile<NWAVES, 1>(B, K, n0, (int64_t)(kt + 1) * BKT, lds + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES, wave, lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int64_t col = n0 + wn * TN + j * 32 + lr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        C16[row * N + col] = __builtin_bit_cast(u16, (__bf16)acc[i][j][r]);
+      }
+    }
+}
+
 // Ablations of the one-barrier loop (results are wrong by construction; only the time is read):
 //   MODE 1: no LDS-DMA in the loop (every k-tile re-reads tile 0)   MODE 2: DMA + barrier, no ds_read / MFMA
 //   MODE 3: DMA + ds_reads, no MFMA                                  MODE 4: MFMA only (fragments read once)
@@ -675,6 +741,19 @@ int main(int argc, char** argv) {
       printf("%-9s N=%4lld K=%4lld %-22s %8.1f us %7.1f TF   worst err/tol %.3f %s (%s)\n", sh.name, (long long)N, \
              (long long)K, NAME, ms * 1e3, 2.0 * M * N * K / ms / 1e9, w, w <= 1.0 ? "ok" : "WRONG",           \
              hipGetErrorString(hipGetLastError()));                                                           \
+    }
+    {
+      float ms = 0;
+      hipMemset(dC16, 0, (size_t)M * N * 2);
+      for (int rep = 0; rep < REPS; ++rep) {
+        if (rep == 1) hipEventRecord(e0);
+        hipLaunchKernelGGL(gemm16_nt_rf_kernel, dim3(gx * gy), dim3(512), 0, 0, dA, dB, dC, dC16, M, N, K, gx);
+      }
+      hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); ms /= (REPS - 1);
+      const double w = check(true);
+      printf("%-9s N=%4lld K=%4lld %-22s %8.1f us %7.1f TF   worst err/tol %.3f %s (%s)\n", sh.name, (long long)N,
+             (long long)K, "reads first, DMA, MFMAs", ms * 1e3, 2.0 * M * N * K / ms / 1e9, w, w <= 1.0 ? "ok" : "WRONG",
+             hipGetErrorString(hipGetLastError()));
     }
     RUNS2("DMA after 1st reads", 1)
     RUNS2("DMA 2 per k-step", 2)
