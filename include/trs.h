@@ -387,6 +387,10 @@ int trs_hinge_auc_batches(const float* pos_dev, const float* neg_dev, int64_t n_
 /* d(mean hinge)/d(pos), d(.)/d(neg): -a/B, +a/B with a = [neg-pos+1 >= 0] (torch clamp subgradient). */
 int trs_hinge_backward(const float* pos_dev, const float* neg_dev, int64_t B, float inv_B, float* gpos_dev,
                        float* gneg_dev, int32_t loss, void* stream);
+/* trs_hinge_auc and trs_hinge_backward in one sweep over the scores (the MLP training step; the sums are formed in
+ * trs_hinge_auc's order, the gradients are trs_hinge_backward's).  loss_sum_dev / auc_count_dev may be NULL. */
+int trs_hinge_auc_backward(const float* pos_dev, const float* neg_dev, int64_t B, float inv_B, float* loss_sum_dev,
+                           int32_t* auc_count_dev, float* gpos_dev, float* gneg_dev, int32_t loss, void* stream);
 
 /* ---------------------------------------------------------------------------------- predict (a13) */
 /* Scores of ONE user against items [item0, item0+n) (model.py:341-452: net.forward over item chunks, pos keys
@@ -487,11 +491,15 @@ int trs_bn_stats_finalize(const float* part_dev, int64_t rows_per_pass, int32_t 
  * pass when stat_passes == passes, shared when stat_passes == 1 (eval mode: running statistics).  out_dev (fp32)
  * and/or out_bf16_dev (bf16 image for the bf16-resident GEMMs; needs H % 4 == 0), same row stride ldo in elements.
  * y_bf16 != 0: y_dev is a bf16 image (written by trs_gemm_bf16in), else fp32.
+ * running_mean_dev / running_var_dev (both or neither; need use_bn and stat_passes == passes): the momentum update of
+ * the running statistics from mean_dev / var_dev, pass by pass — what trs_bn_stats_finalize does when IT is given the
+ * running pointers (same arithmetic, bit for bit); pass them to one of the two, not both.  Done by the forward kernel's
+ * first row block, which saves the training step one launch per layer.
  * (collaborative/mlp.py:108-112) */
 int trs_bn_relu_forward(const void* y_dev, int32_t y_bf16, int64_t rows_per_pass, int32_t passes, int32_t H, int64_t ld,
                         int32_t use_bn, int32_t stat_passes, const float* mean_dev, const float* var_dev,
                         const float* gamma_dev, const float* beta_dev, float eps, float* out_dev, void* out_bf16_dev,
-                        int64_t ldo, void* stream);
+                        int64_t ldo, float momentum, float* running_mean_dev, float* running_var_dev, void* stream);
 
 /* Backward of relu(bn(y)) in train mode from dx = dL/d(out): dy (same shape), dgamma/dbeta (H) summed over both
  * passes.  use_bn = 0: dy = dx * [y > 0].  dy_colsum_dev (H, may be NULL): column sums of dy = the gradient of the

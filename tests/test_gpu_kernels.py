@@ -118,6 +118,20 @@ def test_forward_and_fwd_bwd(net, D, M, idx_dtype):
     assert np.array_equal(gp.cpu().numpy(), ogp) and np.array_equal(gn.cpu().numpy(), ogn)
     gr2, gl2 = ops.score_backward(net, T, Bt, B, D, M, DEV, gp, gn)
     assert torch.equal(gr2, gr) and torch.equal(gl2, gl)
+    # the one-sweep form (MLP step): trs_hinge_auc's sums and trs_hinge_backward's gradients, bit for bit
+    for loss_id in (0, 1):
+        ls1 = torch.zeros(1, dtype=torch.float32, device=DEV)
+        a1 = torch.zeros(1, dtype=torch.int32, device=DEV)
+        ops.hinge_auc(pos, neg, ls1, a1, loss=loss_id)
+        g1p, g1n = ops.hinge_backward(pos, neg, loss=loss_id)
+        ls2, a2 = torch.zeros_like(ls1), torch.zeros_like(a1)
+        g2p, g2n = ops.hinge_auc_backward(pos, neg, ls2, a2, loss=loss_id)
+        assert torch.equal(g2p, g1p) and torch.equal(g2n, g1n) and a1.item() == a2.item()
+        assert g2p._base is g2n._base and g2p._base.numel() == 2 * B
+        if B <= 1024:  # one workgroup: one atomic, the same sum
+            assert ls1.item() == ls2.item()
+        else:
+            assert abs(ls1.item() - ls2.item()) <= 1e-5 * abs(ls1.item())
 
 
 @pytest.mark.parametrize("net,D,M", [("fm", 64, 0), ("fm", 16, 2), ("linear", 32, 1), ("linear", 80, 0)])
@@ -549,6 +563,30 @@ def test_gemm_bf16_resident_split_k_wgrad_shape(H, Kin, rows):
     x = torch.from_numpy(rs.normal(0, 1, (rows, Kin)).astype(np.float32)).to(DEV).to(torch.bfloat16)
     out = ops.gemm_bf16in(True, dy, x)
     assert rel_err(out.cpu().numpy(), dy.double().cpu().numpy().T @ x.double().cpu().numpy()) < 3e-6
+    # out = alpha * product + beta * out in place (the SGD step folded into the weight gradient): (alpha * sum) + beta * W
+    # on the sums of the call above, bit for bit
+    W = torch.from_numpy(rs.normal(0, 1, (H, Kin)).astype(np.float32)).to(DEV)
+    W0 = W.clone()
+    ops.gemm_bf16in(True, dy, x, out=W, alpha=-0.05, beta=1.0)
+    assert torch.equal(W, W0 + (-0.05) * out)
+    ops.gemm_bf16in(True, dy, x, out=W, alpha=0.5, beta=-2.0)
+    assert torch.equal(W, 0.5 * out + (-2.0) * (W0 + (-0.05) * out))
+
+
+def test_gemm_bf16_resident_alpha_beta_without_split_k():
+    """The same epilogue inside the GEMM kernels (one k-split: short K, and the NT form)."""
+    ops = _ops()
+    rs = np.random.RandomState(4)
+    for tn, (M, N, K) in ((True, (256, 256, 128)), (True, (128, 384, 64)), (False, (512, 256, 128)), (False, (128, 128, 64))):
+        A = torch.from_numpy(rs.normal(0, 1, (K, M) if tn else (M, K)).astype(np.float32)).to(DEV).to(torch.bfloat16)
+        Bm = torch.from_numpy(rs.normal(0, 1, (K, N) if tn else (N, K)).astype(np.float32)).to(DEV).to(torch.bfloat16)
+        prod = ops.gemm_bf16in(tn, A, Bm)
+        C0 = torch.from_numpy(rs.normal(0, 1, (M, N)).astype(np.float32)).to(DEV)
+        C = C0.clone()
+        ops.gemm_bf16in(tn, A, Bm, out=C, alpha=-0.3, beta=1.0)
+        assert rel_err(C.cpu().numpy(), (C0.double() - 0.3 * prod.double()).cpu().numpy()) < 1e-6, (tn, M, N, K)
+    with pytest.raises(ValueError):
+        ops.gemm_bf16in(False, A, Bm, out_bf16=True, beta=1.0)
 
 
 @pytest.mark.parametrize("D,M,B,n_cat", [(8, 0, 300, 0), (64, 1, 1000, 37), (256, 3, 4096, 1000), (128, 2, 777, 5000),
@@ -646,6 +684,16 @@ def test_bn_stats_forward_backward(B, H, passes):
     tg, tb = torch.from_numpy(gamma).to(DEV), torch.from_numpy(beta).to(DEV)
     out = torch.empty_like(ty)
     ops.bn_relu_forward(ty, B, passes, True, passes, mean, var, tg, tb, 1e-5, out)
+    # the running update riding in the forward launch == the one bn_batch_stats made above, bit for bit; same output
+    rm2, rv2 = torch.from_numpy(rm0.copy()).to(DEV), torch.from_numpy(rv0.copy()).to(DEV)
+    out2 = torch.empty_like(ty)
+    ops.bn_relu_forward(ty, B, passes, True, passes, mean, var, tg, tb, 1e-5, out2, momentum=0.1, running_mean=rm2,
+                        running_var=rv2)
+    assert torch.equal(rm2, rm) and torch.equal(rv2, rv) and torch.equal(out2, out)
+    if passes == 2:  # eval-mode statistics (one shared set) cannot feed a running update
+        with pytest.raises(RuntimeError, match="running update"):
+            ops.bn_relu_forward(ty, B, passes, True, 1, mean, var, tg, tb, 1e-5, out2, momentum=0.1, running_mean=rm2,
+                                running_var=rv2)
     xhat = (y64 - rmean[:, None, :]) / np.sqrt(rvar[:, None, :] + 1e-5)
     yhat = xhat * gamma + beta
     assert rel_err(out.cpu().numpy(), np.maximum(yhat, 0).reshape(rows, H)) < 1e-5  # fp32 (y - mean) with |mean| ~ 5 sigma

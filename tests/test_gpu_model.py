@@ -502,6 +502,68 @@ def test_mlp_bf16_resident_step_matches_the_bf16_oracle(use_bn, M, shape):
             for stat in ("running_mean", "running_var"):
                 assert rel_err(sd[f"bns.{l}.{stat}"].cpu().numpy(), params[f"bns.{l}.{stat}"]) < 1e-4, (l, stat)
             assert int(sd[f"bns.{l}.num_batches_tracked"]) == 2
+    # plain SGD folded into the weight-gradient GEMM (MLPCompute.backward's sgd_lr): W - lr * dW with the dW checked
+    # above, bit for bit (same kernels and summation order; the reduce computes (-lr * sum) + W), dW not returned, d x0
+    # unchanged (the input-gradient GEMM reads the W^T image of the forward pass, not the stepped master weights)
+    lrs = [0.05 * (l + 1) for l in range(len(hidden))]
+    W0 = [fc.weight.data.clone() for fc in net.fcs]
+    scores2, ctx2 = net.compute.forward(ids, 2, True)
+    assert torch.equal(scores2, scores)
+    grads2, dx02 = net.compute.backward(ctx2, torch.cat([gp, gn]), sgd_lr=lrs)
+    for l, fc in enumerate(net.fcs):
+        assert fc.weight not in grads2 and fc.bias in grads2
+        assert torch.equal(fc.weight.data, W0[l] - lrs[l] * grads[fc.weight]), l
+    assert torch.equal(dx02, dx0)
+    assert torch.equal(grads2[net.output_layer.weight], grads[net.output_layer.weight])
+
+
+def test_mlp_trainer_steps_the_weights_in_the_gradient_gemm(monkeypatch):
+    """MLPTrainer.step on the bf16-resident path: with momentum-free torch.optim.SGD the hidden layers' weights are
+    stepped by their weight-gradient GEMMs (no .grad, the optimiser skips them) and end where the torch optimiser puts
+    them (TRS_MLP_FUSED_DENSE=0: same kernels, dW materialised, torch's foreach step); with momentum, or another
+    optimiser, the fold is off."""
+    from torchrecsys_amd.mlp_engine import MLPTrainer
+    from torchrecsys_amd.model import TorchRecSys
+    rs = np.random.RandomState(3)
+    n_u, n_i, n, B, D = 500, 300, 4096, 256, 64
+    users = torch.from_numpy(np.concatenate([np.arange(n_u), rs.randint(0, n_u, n - n_u)]).astype(np.int64))
+    items = torch.from_numpy(np.concatenate([np.arange(n_i), rs.randint(0, n_i, n - n_i)]).astype(np.int64))
+    h = [{"user": rs.randint(0, n_u, B), "pos": rs.randint(0, n_i, B), "neg": rs.randint(0, n_i, B)} for _ in range(3)]
+    out = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("TRS_MLP_FUSED_DENSE", fused)
+        seed(11)
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = TorchRecSys.from_tensors(users, items, n_users=n_u, n_items=n_i, n_factors=D, net_type="mlp",
+                                             hidden_layers=[256, 128], use_amp=True, dynamic_neg_sampling=True,
+                                             rng="reference")
+        net = model.net
+        net.train()
+        dev = net.user.weight.device
+        def groups():  # (fresh dicts: an optimiser writes its defaults into the ones it is given)
+            return [{"params": [p for n_, p in net.named_parameters() if not n_.startswith("fcs.0")]},
+                    {"params": list(net.fcs[0].parameters()), "lr": 0.02}]
+        assert MLPTrainer(net, torch.optim.SGD(groups(), lr=0.05, momentum=0.9), B)._fused_weight_lrs() is None
+        assert MLPTrainer(net, torch.optim.Adam(groups(), lr=0.05), B)._fused_weight_lrs() is None
+        opt = torch.optim.SGD(groups(), lr=0.05)
+        tr = MLPTrainer(net, opt, B)
+        assert tr._fused_weight_lrs() == ([0.02, 0.05] if fused == "1" else None)
+        slot = torch.zeros(1, device=dev)
+        for hb in h:
+            tr.step({k: torch.from_numpy(v).to(dev) for k, v in hb.items()}, slot)
+        tr.check_errors()
+        torch.cuda.synchronize()
+        assert (net.fcs[0].weight.grad is None) == (fused == "1")
+        assert net.fcs[0].bias.grad is not None
+        out[fused] = ({k: v.detach().cpu().numpy().copy() for k, v in net.state_dict().items()}, slot.item())
+    for k, v in out["1"][0].items():
+        if v.dtype.kind == "f":
+            # the same gradients; W + (-lr) * dW is one fused multiply-add in torch's kernel and two roundings in the
+            # GEMM's reduce, and three steps of bf16 GEMMs carry that last bit along
+            assert rel_err(v, out["0"][0][k]) < 2e-4, k
+        else:
+            assert np.array_equal(v, out["0"][0][k]), k
+    assert abs(out["1"][1] - out["0"][1]) <= 1e-3 * abs(out["0"][1])
 
 
 @pytest.mark.parametrize("net_type", ["linear", "mlp"])

@@ -140,6 +140,7 @@ PROTOTYPES = {
     "trs_hinge_auc": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i32, _vp]),
     "trs_hinge_auc_batches": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i32, _vp]),
     "trs_hinge_backward": (C.c_int, [_vp, _vp, _i64, _f, _vp, _vp, _i32, _vp]),
+    "trs_hinge_auc_backward": (C.c_int, [_vp, _vp, _i64, _f, _vp, _vp, _vp, _vp, _i32, _vp]),
     "trs_score_all_items": (C.c_int, [C.c_int, _T, _i64, _i64, _i64, _vp, _vp, _vp]),
     "trs_topk_workspace_bytes": (C.c_int64, [_i64, _i32]),
     "trs_topk": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _i64, _vp]),
@@ -159,7 +160,7 @@ PROTOTYPES = {
     "trs_bn_workspace_floats": (C.c_int64, [_i64, _i32, _i32]),
     "trs_bn_batch_stats": (C.c_int, [_vp, _i64, _i32, _i64, _i32, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "trs_bn_relu_forward": (C.c_int, [_vp, _i32, _i64, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _f, _vp, _vp,
-                                      _i64, _vp]),
+                                      _i64, _f, _vp, _vp, _vp]),
     "trs_bn_backward_workspace_floats": (C.c_int64, [_i64, _i32, _i32]),
     "trs_bn_relu_backward": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _i32, _i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _f,
                                        _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp]),

@@ -6,7 +6,9 @@ namespace {
 
 __global__ __launch_bounds__(TRS_BLOCK) void hinge_auc_kernel(const float* __restrict__ pos,
                                                              const float* __restrict__ neg, int64_t B,
-                                                             float* loss_sum, int32_t* auc_count, int loss) {
+                                                             float* loss_sum, int32_t* auc_count, int loss,
+                                                             float inv_B, float* __restrict__ gpos,
+                                                             float* __restrict__ gneg) {
   float L = 0.f;
   int A = 0;
   const int64_t stride = (int64_t)gridDim.x * TRS_BLOCK;
@@ -16,6 +18,11 @@ __global__ __launch_bounds__(TRS_BLOCK) void hinge_auc_kernel(const float* __res
     trs_pair_loss(loss, p, n, lval, dneg);
     L += lval;
     A += (p > n) ? 1 : 0;
+    if (gpos) {  // trs_hinge_auc_backward: the gradient of the mean loss in the same sweep
+      const float act = dneg * inv_B;
+      gpos[t] = -act;
+      gneg[t] = act;
+    }
   }
   __shared__ float s_l[TRS_BLOCK / TRS_WAVE];
   __shared__ int s_a[TRS_BLOCK / TRS_WAVE];
@@ -221,7 +228,20 @@ extern "C" int trs_hinge_auc(const float* pos_dev, const float* neg_dev, int64_t
   if (B == 0) return TRS_OK;
   TRS_REQUIRE(pos_dev && neg_dev, "trs_hinge_auc: scores are NULL");
   hipLaunchKernelGGL(hinge_auc_kernel, dim3(trs_grid(B, TRS_BLOCK * 4)), dim3(TRS_BLOCK), 0, (hipStream_t)stream,
-                     pos_dev, neg_dev, B, loss_sum_dev, auc_count_dev, (int)loss);
+                     pos_dev, neg_dev, B, loss_sum_dev, auc_count_dev, (int)loss, 0.f, (float*)nullptr, (float*)nullptr);
+  TRS_CHECK_LAUNCH("hinge_auc_kernel");
+  return TRS_OK;
+}
+
+extern "C" int trs_hinge_auc_backward(const float* pos_dev, const float* neg_dev, int64_t B, float inv_B,
+                                      float* loss_sum_dev, int32_t* auc_count_dev, float* gpos_dev, float* gneg_dev,
+                                      int32_t loss, void* stream) {
+  TRS_REQUIRE(loss == TRS_LOSS_HINGE || loss == TRS_LOSS_BPR, "trs_hinge_auc_backward: bad loss kind");
+  TRS_REQUIRE(B >= 0, "trs_hinge_auc_backward: negative B");
+  if (B == 0) return TRS_OK;
+  TRS_REQUIRE(pos_dev && neg_dev && gpos_dev && gneg_dev, "trs_hinge_auc_backward: NULL argument");
+  hipLaunchKernelGGL(hinge_auc_kernel, dim3(trs_grid(B, TRS_BLOCK * 4)), dim3(TRS_BLOCK), 0, (hipStream_t)stream,
+                     pos_dev, neg_dev, B, loss_sum_dev, auc_count_dev, (int)loss, inv_B, gpos_dev, gneg_dev);
   TRS_CHECK_LAUNCH("hinge_auc_kernel");
   return TRS_OK;
 }

@@ -245,6 +245,11 @@ struct BnFwdArgs {
   const float *mean, *var, *gamma, *beta;
   float eps;
   const unsigned short* y16;  // bf16 image of y (bf16-resident path) when y is NULL
+  // optional: the running-statistics momentum update of bn_running_update_kernel done by the first row block's threads
+  // (train mode, stat_passes == passes); NULL = not here
+  float momentum;
+  float* running_mean;
+  float* running_var;
 };
 
 __global__ __launch_bounds__(TRS_BLOCK) void bn_relu_fwd_kernel(const BnFwdArgs a) {
@@ -633,6 +638,23 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_relu_fwd_v4_kernel(const BnFwdAr
         if (a.out) *reinterpret_cast<float4*>(a.out + (base + rr) * a.ldo + col) = make_float4(v[0], v[1], v[2], v[3]);
         if (a.out16) st_bf16x4(a.out16 + (base + rr) * a.ldo + col, v[0], v[1], v[2], v[3]);
       }
+    }
+  }
+  if (a.running_mean && chunk == 0 && pass == 0 && rl == 0) {
+    // one thread per 4 columns: the arithmetic of bn_running_update_kernel, pass by pass
+    const float n = (float)a.rows_per_pass;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float rm = a.running_mean[col + q], rv = a.running_var[col + q];
+      for (int p = 0; p < a.passes; ++p) {
+        const float m = a.mean[p * a.H + col + q];
+        const double m2 = (double)a.var[p * a.H + col + q] * (double)n;
+        const float unb = (float)(m2 / (n > 1.f ? (double)n - 1.0 : 1.0));
+        rm = (1.0f - a.momentum) * rm + a.momentum * m;
+        rv = (1.0f - a.momentum) * rv + a.momentum * unb;
+      }
+      a.running_mean[col + q] = rm;
+      a.running_var[col + q] = rv;
     }
   }
 }
@@ -1076,15 +1098,19 @@ extern "C" int trs_bn_stats_finalize(const float* part_dev, int64_t rows_per_pas
 extern "C" int trs_bn_relu_forward(const void* y_dev, int32_t y_bf16, int64_t rows_per_pass, int32_t passes, int32_t H,
                                    int64_t ld, int32_t use_bn, int32_t stat_passes, const float* mean_dev,
                                    const float* var_dev, const float* gamma_dev, const float* beta_dev, float eps,
-                                   float* out_dev, void* out_bf16_dev, int64_t ldo, void* stream) {
+                                   float* out_dev, void* out_bf16_dev, int64_t ldo, float momentum,
+                                   float* running_mean_dev, float* running_var_dev, void* stream) {
   TRS_REQUIRE(y_dev && (out_dev || out_bf16_dev), "trs_bn_relu_forward: NULL argument");
+  TRS_REQUIRE((running_mean_dev == nullptr) == (running_var_dev == nullptr), "trs_bn_relu_forward: running stats");
+  TRS_REQUIRE(!running_mean_dev || (use_bn && stat_passes == passes),
+              "trs_bn_relu_forward: the running update needs the batch statistics of every pass");
   TRS_REQUIRE(rows_per_pass >= 0 && H > 0 && ld >= H && ldo >= H && passes >= 1, "trs_bn_relu_forward: bad shape");
   TRS_REQUIRE(!use_bn || (mean_dev && var_dev && gamma_dev && beta_dev), "trs_bn_relu_forward: BN tensors are NULL");
   TRS_REQUIRE(stat_passes == 1 || stat_passes == passes, "trs_bn_relu_forward: stat_passes must be 1 or passes");
   if (rows_per_pass == 0) return TRS_OK;
   BnFwdArgs a = {y_bf16 ? nullptr : (const float*)y_dev, out_dev, (unsigned short*)out_bf16_dev, rows_per_pass, ld,
                  ldo, H, passes, stat_passes, use_bn, mean_dev, var_dev, gamma_dev, beta_dev, eps,
-                 y_bf16 ? (const unsigned short*)y_dev : nullptr};
+                 y_bf16 ? (const unsigned short*)y_dev : nullptr, momentum, running_mean_dev, running_var_dev};
   const bool v4 = H % 4 == 0 && ld % 4 == 0 && ((uintptr_t)y_dev & (y_bf16 ? 7 : 15)) == 0 &&
                   (!out_dev || v4_ok(out_dev, H, ldo)) &&
                   (!out_bf16_dev || (ldo % 4 == 0 && ((uintptr_t)out_bf16_dev & 7) == 0));
@@ -1098,6 +1124,10 @@ extern "C" int trs_bn_relu_forward(const void* y_dev, int32_t y_bf16, int64_t ro
   } else {
     const int64_t total = rows_per_pass * passes * ((H + 3) / 4);
     hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3(trs_grid(total, TRS_BLOCK)), dim3(TRS_BLOCK), 0, (hipStream_t)stream, a);
+    if (running_mean_dev)
+      hipLaunchKernelGGL(bn_running_update_kernel, dim3((H + TRS_BLOCK - 1) / TRS_BLOCK), dim3(TRS_BLOCK), 0,
+                         (hipStream_t)stream, mean_dev, var_dev, rows_per_pass, H, passes, momentum, running_mean_dev,
+                         running_var_dev);
   }
   TRS_CHECK_LAUNCH("bn_relu_fwd_kernel");
   return TRS_OK;

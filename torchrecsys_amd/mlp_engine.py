@@ -134,6 +134,7 @@ class MLPCompute:
             ctx["y"].append(y)
             mean = var = gamma = beta = None
             stat_passes = 1
+            run = {}
             if use_bn:
                 bn = net.bns[l]
                 gamma, beta = bn.weight.data, bn.bias.data
@@ -142,11 +143,13 @@ class MLPCompute:
                     mean = torch.empty((passes, H), dtype=torch.float32, device=dev)
                     var = torch.empty((passes, H), dtype=torch.float32, device=dev)
                     sync = self.sync_bn and tdist.world_info()[1] > 1
-                    rm, rv = (None, None) if sync else (bn.running_mean, bn.running_var)
+                    # the running statistics' momentum update rides in the BN+ReLU launch below
+                    if not sync:
+                        run = {"momentum": BN_MOMENTUM, "running_mean": bn.running_mean, "running_var": bn.running_var}
                     if fuse_stats:
-                        ops.bn_stats_finalize(part, B, ops.GEMM_TILE_ROWS, H, passes, BN_MOMENTUM, mean, var, rm, rv)
+                        ops.bn_stats_finalize(part, B, ops.GEMM_TILE_ROWS, H, passes, BN_MOMENTUM, mean, var, None, None)
                     else:
-                        ops.bn_batch_stats(y, B, passes, BN_MOMENTUM, mean, var, rm, rv)
+                        ops.bn_batch_stats(y, B, passes, BN_MOMENTUM, mean, var, None, None)
                     if sync:
                         self._sync_stats(mean, var, bn, B)
                     tracked.append(bn.num_batches_tracked)
@@ -157,10 +160,10 @@ class MLPCompute:
             ctx["var"].append(var)
             if res and l < L - 1:  # the next layer's input: bf16 only (the last layer's output feeds the fp32 H -> 1 dot)
                 xn = torch.empty(y.shape, dtype=torch.bfloat16, device=dev)
-                ops.bn_relu_forward(y, B, passes, use_bn, stat_passes, mean, var, gamma, beta, BN_EPS, out16=xn)
+                ops.bn_relu_forward(y, B, passes, use_bn, stat_passes, mean, var, gamma, beta, BN_EPS, out16=xn, **run)
             else:
                 xn = torch.empty(y.shape, dtype=torch.float32, device=dev)
-                ops.bn_relu_forward(y, B, passes, use_bn, stat_passes, mean, var, gamma, beta, BN_EPS, xn)
+                ops.bn_relu_forward(y, B, passes, use_bn, stat_passes, mean, var, gamma, beta, BN_EPS, xn, **run)
             x = xn
             ctx["x"].append(x)
         if tracked:  # BatchNorm1d.num_batches_tracked of every layer: + passes, one launch
@@ -189,12 +192,16 @@ class MLPCompute:
             bn.running_mean.mul_(1.0 - BN_MOMENTUM).add_(gm[ps].float(), alpha=BN_MOMENTUM)
             bn.running_var.mul_(1.0 - BN_MOMENTUM).add_(unb[ps].float(), alpha=BN_MOMENTUM)
 
-    def backward(self, ctx, g, grad_of=None, on_group_done=None):
+    def backward(self, ctx, g, grad_of=None, on_group_done=None, sgd_lr=None):
         """g: (passes*B,) = dL/dscore.  grad_of(param) -> tensor to write that dense parameter's gradient into
         (default: fresh tensors).  on_group_done(i): called once the kernels that write the dense gradients of group i
         are enqueued — i = L for the output layer (first), then L-1 ... 0 for the hidden layers (Linear + BatchNorm
         parameters of layer i): the data-parallel trainer starts that group's all-reduce while the layers below are
-        still being differentiated.  Returns (grads dict keyed by parameter, d x0)."""
+        still being differentiated.  Returns (grads dict keyed by parameter, d x0).
+        sgd_lr (list, one learning rate per hidden Linear layer, or None): plain SGD folded into the weight-gradient
+        GEMM on the bf16-resident path — W_l = W_l - lr_l * dW_l written by the GEMM's reduce, dW_l never stored and W_l
+        absent from `grads` (single process only: nothing to all-reduce; the input-gradient GEMM reads the W^T image
+        taken in the forward pass, not the master weights)."""
         net = self.net
         D, M, L, use_bn = self._dims()
         B, passes = ctx["B"], ctx["passes"]
@@ -252,7 +259,10 @@ class MLPCompute:
                 ops.bn_relu_backward(y, dx, B, passes, False, None, None, None, None, BN_EPS, dy, None, None,
                                      dy_colsum=slot(fc.bias), dy16=dy16, outer=ou)  # db = column sums of dy, same kernel
             if res:
-                self._gemm16(True, dy16, ctx["x"][l], out=slot(fc.weight))   # dW = dy^T x (transposing LDS reads)
+                if sgd_lr is not None:  # W -= lr * dy^T x in the GEMM's reduce
+                    self._gemm16(True, dy16, ctx["x"][l], out=fc.weight.data, alpha=-float(sgd_lr[l]), beta=1.0)
+                else:
+                    self._gemm16(True, dy16, ctx["x"][l], out=slot(fc.weight))   # dW = dy^T x (transposing LDS reads)
                 if on_group_done:
                     on_group_done(l)
                 # dx = dy W through the W^T image: bf16 between layers (when the layer below keeps a bf16 y), fp32 for the
@@ -339,9 +349,8 @@ class MLPTrainer:
         net.compute.dx0_bf16 = fused_lr is not None  # (only read on the bf16-resident path)
         scores, ctx = net.compute.forward(ids, 2, True)
         pos, neg = scores[:B], scores[B:]
-        ops.hinge_auc(pos, neg, loss_slot, auc_slot, loss=self.loss_id)
-        gp, gn = ops.hinge_backward(pos, neg, loss=self.loss_id)
-        g = torch.cat([gp, gn])
+        gp, gn = ops.hinge_auc_backward(pos, neg, loss_slot, auc_slot, loss=self.loss_id)
+        g = gp._base  # (2B,): positive half, negative half
         # ---- dense parameters under data parallelism: RCCL all-reduce per layer, started as the backward produces the
         # layer's gradients (it runs on the collective stream beside the remaining backward GEMMs and the embedding-row
         # updates below) and awaited right before the user's optimiser steps the dense parameters
@@ -349,7 +358,8 @@ class MLPTrainer:
         dp = tdist.world_info()[1] > 1
         grads, dx0 = net.compute.backward(ctx, g, grad_of=self.bucket.grad_of,
                                           on_group_done=(lambda i: works.append(
-                                              self.bucket.allreduce_segment_async(self.segs[i]))) if dp else None)
+                                              self.bucket.allreduce_segment_async(self.segs[i]))) if dp else None,
+                                          sgd_lr=None if dp else self._fused_weight_lrs())
         net.compute.dx0_bf16 = False
         tables = []
         if fused_lr is None:  # per-table paths: one index vector per table over the 2B rows of d x0
@@ -367,8 +377,8 @@ class MLPTrainer:
         else:
             for p in self.emb_params:
                 p.grad = None
-        for p in self.dense_params:
-            p.grad = self.bucket.grad_of(p)
+        for p in self.dense_params:  # (a weight already stepped by its gradient GEMM has no gradient: the optimiser skips it)
+            p.grad = self.bucket.grad_of(p) if p in grads else None
         # ---- embedding tables: fused sparse-row updates from the column blocks of d x0 (independent of the dense
         # gradients still being reduced)
         if fused_lr is not None:
@@ -383,6 +393,20 @@ class MLPTrainer:
                 self._rows(p, idx, dx0[:, f * D:], ld)
         self.bucket.finish_segments(works)
         opt.step()
+
+    def _fused_weight_lrs(self):
+        """Per hidden Linear layer, the learning rate of the plain SGD step folded into its weight-gradient GEMM
+        (MLPCompute.backward's sgd_lr), or None: the optimiser is not momentum-free, decay-free torch.optim.SGD for
+        those weights, or TRS_MLP_FUSED_DENSE=0."""
+        import os
+        if os.environ.get("TRS_MLP_FUSED_DENSE", "1") == "0":
+            return None
+        ws = [fc.weight for fc in self.net.fcs]
+        if getattr(self, "_w_kind", None) is None:
+            self._w_kind = classify_optimizer(self.opt, ws) if ws else "generic"
+        if self._w_kind != "sgd":
+            return None
+        return [_group_of(self.opt, w)["lr"] for w in ws]
 
     def _fused_embed_lr(self):
         """The one learning rate of the fused embedding update, or None when it does not apply (tables in parameter

@@ -442,10 +442,23 @@ def hinge_auc_batches(pos, neg, batch, loss_sums, auc_counts, loss=0):
 
 
 def hinge_backward(pos, neg, loss=0):
+    """-> (gp, gn): the two halves of one (2B,) buffer (`gp._base` is the concatenated gradient the MLP backward reads)."""
     B = pos.numel()
-    gp, gn = torch.empty_like(pos), torch.empty_like(neg)
+    g = torch.empty(2 * B, dtype=pos.dtype, device=pos.device)
+    gp, gn = g[:B], g[B:]
     check(_lib.load().trs_hinge_backward(ptr(pos), ptr(neg), B, 1.0 / B if B else 0.0, ptr(gp), ptr(gn), int(loss),
                                          _stream()), "trs_hinge_backward")
+    return gp, gn
+
+
+def hinge_auc_backward(pos, neg, loss_sum, auc_count, loss=0):
+    """hinge_auc + hinge_backward in one launch -> (gp, gn), the halves of one (2B,) buffer."""
+    B = pos.numel()
+    g = torch.empty(2 * B, dtype=pos.dtype, device=pos.device)
+    gp, gn = g[:B], g[B:]
+    check(_lib.load().trs_hinge_auc_backward(ptr(pos), ptr(neg), B, 1.0 / B if B else 0.0, ptr(loss_sum),
+                                             ptr(auc_count), ptr(gp), ptr(gn), int(loss), _stream()),
+          "trs_hinge_auc_backward")
     return gp, gn
 
 
@@ -554,10 +567,10 @@ def gemm(transA, transB, A, B, out=None, bias=None, alpha=1.0, beta=0.0, bf16=Fa
     return out
 
 
-def gemm_bf16in(tn, A, B, out=None, bias=None, bn_part=None, out_bf16=False):
+def gemm_bf16in(tn, A, B, out=None, bias=None, bn_part=None, out_bf16=False, alpha=1.0, beta=0.0):
     """bf16-resident GEMM: tn False: out(M,N) = A(M,K) B(N,K)^T; tn True: out(M,N) = A(K,M)^T B(K,N).  A, B bfloat16 GPU
     tensors with a contiguous last dimension; fp32 accumulation; fp32 output, or bfloat16 when out_bf16 (or `out` is a
-    bfloat16 tensor)."""
+    bfloat16 tensor).  alpha, beta: out = alpha * (product) + beta * out (fp32 `out` given; beta != 0 reads it)."""
     lib = _lib.load()
     for t in (A, B):
         if t.dtype != torch.bfloat16 or t.stride(-1) != 1 or not t.is_cuda:
@@ -575,7 +588,9 @@ def gemm_bf16in(tn, A, B, out=None, bias=None, bn_part=None, out_bf16=False):
     o16 = out.dtype == torch.bfloat16
     wsb = 0 if (bn_part is not None or o16) else lib.trs_gemm_bf16in_workspace_bytes(M, N, K)
     ws = _workspace(A.device, wsb) if wsb else None
-    check(lib.trs_gemm_bf16in(int(tn), M, N, K, 1.0, ptr(A), A.stride(0), ptr(B), B.stride(0), 0.0,
+    if beta != 0.0 and (o16 or bn_part is not None):
+        raise ValueError("gemm_bf16in: beta != 0 needs an fp32 `out` and no fused statistics")
+    check(lib.trs_gemm_bf16in(int(tn), M, N, K, float(alpha), ptr(A), A.stride(0), ptr(B), B.stride(0), float(beta),
                               None if o16 else ptr(out), ptr(out) if o16 else None, out.stride(0), ptr(bias),
                               ptr(bn_part), ptr(ws), wsb, _stream()), "trs_gemm_bf16in")
     return out
@@ -609,14 +624,17 @@ def bn_stats_finalize(part, rows_per_pass, chunk_rows, H, passes, momentum, mean
           "trs_bn_stats_finalize")
 
 
-def bn_relu_forward(y, rows_per_pass, passes, use_bn, stat_passes, mean, var, gamma, beta, eps, out=None, out16=None):
-    """out: fp32 and/or out16: bfloat16 image of relu(bn(y)) (same row stride in elements)."""
+def bn_relu_forward(y, rows_per_pass, passes, use_bn, stat_passes, mean, var, gamma, beta, eps, out=None, out16=None,
+                    momentum=0.0, running_mean=None, running_var=None):
+    """out: fp32 and/or out16: bfloat16 image of relu(bn(y)) (same row stride in elements).  running_mean/var: the
+    momentum update of the running statistics rides in this launch (instead of bn_stats_finalize's)."""
     H = y.shape[1]
     ldo = (out if out is not None else out16).stride(0)
     check(_lib.load().trs_bn_relu_forward(ptr(y), int(y.dtype == torch.bfloat16), rows_per_pass, passes, H, y.stride(0),
                                           int(use_bn), stat_passes,
                                           ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps), ptr(out), ptr(out16),
-                                          ldo, _stream()), "trs_bn_relu_forward")
+                                          ldo, float(momentum), ptr(running_mean), ptr(running_var), _stream()),
+          "trs_bn_relu_forward")
 
 
 def bn_relu_backward(y, dx, rows_per_pass, passes, use_bn, mean, var, gamma, beta, eps, dy, dgamma, dbeta,
