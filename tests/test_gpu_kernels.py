@@ -659,7 +659,7 @@ def test_mlp_embed_sgd_update_refuses_what_it_cannot_do():
     assert not ops.mlp_embed_sgd_supported(T2)      # D % 4 != 0
 
 
-@pytest.mark.parametrize("B,H", [(64, 32), (1000, 130), (5000, 7), (256, 512)])
+@pytest.mark.parametrize("B,H", [(64, 32), (1000, 130), (5000, 7), (256, 512), (300, 256), (97, 128)])
 @pytest.mark.parametrize("passes", [1, 2])
 def test_bn_stats_forward_backward(B, H, passes):
     ops = _ops()
@@ -690,6 +690,18 @@ def test_bn_stats_forward_backward(B, H, passes):
     ops.bn_relu_forward(ty, B, passes, True, passes, mean, var, tg, tb, 1e-5, out2, momentum=0.1, running_mean=rm2,
                         running_var=rv2)
     assert torch.equal(rm2, rm) and torch.equal(rv2, rv) and torch.equal(out2, out)
+    # the H -> 1 output layer from the same launch (H a power of two <= 256: a row sits in one wave) or by the row-dot
+    # kernel behind it (wide / unaligned layers): scores = out . w + bias
+    wv = torch.from_numpy(rs.normal(0, 1, H).astype(np.float32)).to(DEV)
+    bv = torch.from_numpy(rs.normal(0, 1, 1).astype(np.float32)).to(DEV)
+    sc = torch.full((rows,), float("nan"), device=DEV)
+    out3 = torch.empty_like(ty)
+    ops.bn_relu_forward(ty, B, passes, True, passes, mean, var, tg, tb, 1e-5, out3, dot=(wv, bv, sc))
+    assert torch.equal(out3, out)
+    assert rel_err(sc.cpu().numpy(), out.double().cpu().numpy() @ wv.double().cpu().numpy() + float(bv.item())) < 1e-6
+    sc0 = torch.empty_like(sc)
+    ops.rowdot(out, wv, bv, sc0)
+    assert rel_err(sc.cpu().numpy(), sc0.cpu().numpy()) < 1e-6
     if passes == 2:  # eval-mode statistics (one shared set) cannot feed a running update
         with pytest.raises(RuntimeError, match="running update"):
             ops.bn_relu_forward(ty, B, passes, True, 1, mean, var, tg, tb, 1e-5, out2, momentum=0.1, running_mean=rm2,

@@ -250,6 +250,11 @@ struct BnFwdArgs {
   float momentum;
   float* running_mean;
   float* running_var;
+  // optional (v4 kernel, H == 4 * threads-per-row <= 256: a row's columns sit in one wave): the H -> 1 output layer
+  // dot_out[row] = sum_c out[row][c] * dot_w[c] + dot_b[0] formed from the registers that hold the row; NULL = not here
+  const float* dot_w;
+  const float* dot_b;
+  float* dot_out;
 };
 
 __global__ __launch_bounds__(TRS_BLOCK) void bn_relu_fwd_kernel(const BnFwdArgs a) {
@@ -617,6 +622,12 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_relu_fwd_v4_kernel(const BnFwdAr
     ga[q] = a.use_bn ? a.gamma[col + q] : 1.f;
     be[q] = a.use_bn ? a.beta[col + q] : 0.f;
   }
+  float dw[4] = {0.f, 0.f, 0.f, 0.f}, db = 0.f;
+  if (a.dot_out) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dw[q] = a.dot_w[col + q];
+    db = a.dot_b ? a.dot_b[0] : 0.f;
+  }
   constexpr int U = 8;
   for (int64_t r = r0 + rl; r < r1; r += (int64_t)nrl * U) {
     float4 yv[U];
@@ -637,6 +648,11 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_relu_fwd_v4_kernel(const BnFwdAr
       if (rr < r1) {
         if (a.out) *reinterpret_cast<float4*>(a.out + (base + rr) * a.ldo + col) = make_float4(v[0], v[1], v[2], v[3]);
         if (a.out16) st_bf16x4(a.out16 + (base + rr) * a.ldo + col, v[0], v[1], v[2], v[3]);
+      }
+      if (a.dot_out) {  // (wave-uniform; the tpr lanes of the row are adjacent lanes of this wave, every one alive)
+        float d = ((v[0] * dw[0] + v[1] * dw[1]) + v[2] * dw[2]) + v[3] * dw[3];
+        for (int m = tpr >> 1; m > 0; m >>= 1) d += __shfl_xor(d, m);
+        if (tc == 0 && rr < r1) a.dot_out[base + rr] = d + db;
       }
     }
   }
@@ -1099,8 +1115,11 @@ extern "C" int trs_bn_relu_forward(const void* y_dev, int32_t y_bf16, int64_t ro
                                    int64_t ld, int32_t use_bn, int32_t stat_passes, const float* mean_dev,
                                    const float* var_dev, const float* gamma_dev, const float* beta_dev, float eps,
                                    float* out_dev, void* out_bf16_dev, int64_t ldo, float momentum,
-                                   float* running_mean_dev, float* running_var_dev, void* stream) {
+                                   float* running_mean_dev, float* running_var_dev, const float* dot_w_dev,
+                                   const float* dot_bias_dev, float* dot_out_dev, void* stream) {
   TRS_REQUIRE(y_dev && (out_dev || out_bf16_dev), "trs_bn_relu_forward: NULL argument");
+  TRS_REQUIRE((dot_w_dev == nullptr) == (dot_out_dev == nullptr) && (!dot_out_dev || out_dev),
+              "trs_bn_relu_forward: the output-layer dot needs its weights, its output and the fp32 out");
   TRS_REQUIRE((running_mean_dev == nullptr) == (running_var_dev == nullptr), "trs_bn_relu_forward: running stats");
   TRS_REQUIRE(!running_mean_dev || (use_bn && stat_passes == passes),
               "trs_bn_relu_forward: the running update needs the batch statistics of every pass");
@@ -1110,14 +1129,20 @@ extern "C" int trs_bn_relu_forward(const void* y_dev, int32_t y_bf16, int64_t ro
   if (rows_per_pass == 0) return TRS_OK;
   BnFwdArgs a = {y_bf16 ? nullptr : (const float*)y_dev, out_dev, (unsigned short*)out_bf16_dev, rows_per_pass, ld,
                  ldo, H, passes, stat_passes, use_bn, mean_dev, var_dev, gamma_dev, beta_dev, eps,
-                 y_bf16 ? (const unsigned short*)y_dev : nullptr, momentum, running_mean_dev, running_var_dev};
+                 y_bf16 ? (const unsigned short*)y_dev : nullptr, momentum, running_mean_dev, running_var_dev,
+                 nullptr, nullptr, nullptr};
   const bool v4 = H % 4 == 0 && ld % 4 == 0 && ((uintptr_t)y_dev & (y_bf16 ? 7 : 15)) == 0 &&
                   (!out_dev || v4_ok(out_dev, H, ldo)) &&
                   (!out_bf16_dev || (ldo % 4 == 0 && ((uintptr_t)out_bf16_dev & 7) == 0));
   TRS_REQUIRE(v4 || (out_dev && !out_bf16_dev && !y_bf16),
               "trs_bn_relu_forward: bf16 images need H %% 4 == 0 and aligned rows");
+  bool dot_fused = false;
   if (v4) {
     const V4Shape v = v4_shape(H);
+    if (dot_out_dev && v.gx == 1 && v.tpr <= TRS_WAVE && 4 * v.tpr == H) {  // a row = adjacent lanes of one wave
+      a.dot_w = dot_w_dev; a.dot_b = dot_bias_dev; a.dot_out = dot_out_dev;
+      dot_fused = true;
+    }
     const dim3 gr(v.gx, (unsigned)((rows_per_pass + FWD_ROWS - 1) / FWD_ROWS), passes);
     if (y_bf16) hipLaunchKernelGGL(bn_relu_fwd_v4_kernel<true>, gr, dim3(TRS_BLOCK), 0, (hipStream_t)stream, a, v.tpr);
     else hipLaunchKernelGGL(bn_relu_fwd_v4_kernel<false>, gr, dim3(TRS_BLOCK), 0, (hipStream_t)stream, a, v.tpr);
@@ -1130,6 +1155,8 @@ extern "C" int trs_bn_relu_forward(const void* y_dev, int32_t y_bf16, int64_t ro
                          running_var_dev);
   }
   TRS_CHECK_LAUNCH("bn_relu_fwd_kernel");
+  if (dot_out_dev && !dot_fused)  // wide or unaligned layers: the stand-alone row dot on the fp32 output
+    return trs_rowdot(out_dev, rows_per_pass * passes, H, ldo, dot_w_dev, dot_bias_dev, dot_out_dev, stream);
   return TRS_OK;
 }
 

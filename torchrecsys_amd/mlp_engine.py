@@ -115,6 +115,7 @@ class MLPCompute:
         ctx = {"ids": ids, "B": B, "passes": passes, "x": [x], "y": [], "mean": [], "var": [], "training": training,
                "resident": res, "Bt": (Bt, keep)}
         tracked = []
+        out = torch.empty(rows, dtype=torch.float32, device=dev)  # the scores
         for l in range(L):
             fc = net.fcs[l]
             # train-mode BN: the batch statistics come out of the GEMM epilogue (one partial per 128-row tile) when no
@@ -163,13 +164,15 @@ class MLPCompute:
                 ops.bn_relu_forward(y, B, passes, use_bn, stat_passes, mean, var, gamma, beta, BN_EPS, out16=xn, **run)
             else:
                 xn = torch.empty(y.shape, dtype=torch.float32, device=dev)
+                if l == L - 1:  # the H -> 1 output layer rides in the last hidden layer's BN + ReLU launch
+                    run = dict(run, dot=(net.output_layer.weight.data.reshape(-1), net.output_layer.bias.data, out))
                 ops.bn_relu_forward(y, B, passes, use_bn, stat_passes, mean, var, gamma, beta, BN_EPS, xn, **run)
             x = xn
             ctx["x"].append(x)
         if tracked:  # BatchNorm1d.num_batches_tracked of every layer: + passes, one launch
             torch._foreach_add_(tracked, passes)
-        out = torch.empty(rows, dtype=torch.float32, device=dev)
-        ops.rowdot(x, net.output_layer.weight.data.reshape(-1), net.output_layer.bias.data, out)
+        if L == 0:
+            ops.rowdot(x, net.output_layer.weight.data.reshape(-1), net.output_layer.bias.data, out)
         return out, ctx
 
     @staticmethod
