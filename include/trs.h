@@ -496,9 +496,11 @@ int trs_bn_stats_finalize(const float* part_dev, int64_t rows_per_pass, int32_t 
  * running pointers (same arithmetic, bit for bit); pass them to one of the two, not both.  Done by the forward kernel's
  * first row block, which saves the training step one launch per layer.
  * dot_w_dev (H) / dot_bias_dev (1, may be NULL) / dot_out_dev (rows_per_pass * passes): the H -> 1 output layer on the
- * last hidden layer's activations, dot_out[r] = sum_c out[r][c] * dot_w[c] + dot_bias (mlp.py:114) — needs out_dev; formed
- * from the registers of this launch when a row's columns sit in one wave (H a power of two <= 256, aligned rows), by
- * trs_rowdot on out_dev otherwise (same result up to the order of the sum).
+ * last hidden layer's activations, dot_out[r] = sum_c out[r][c] * dot_w[c] + dot_bias (mlp.py:114); formed from the
+ * registers of this launch when a row's columns sit in one wave (H a power of two <= 256, aligned rows) — out_dev and
+ * out_bf16_dev may then both be NULL: the activations are not stored at all (trs_bn_relu_backward's outer_xw_dev gives the
+ * output layer's weight gradient without them) — and by trs_rowdot on out_dev otherwise (same result up to the order of
+ * the sum; an error when out_dev is NULL).
  * (collaborative/mlp.py:108-114) */
 int trs_bn_relu_forward(const void* y_dev, int32_t y_bf16, int64_t rows_per_pass, int32_t passes, int32_t H, int64_t ld,
                         int32_t use_bn, int32_t stat_passes, const float* mean_dev, const float* var_dev,
@@ -518,7 +520,9 @@ int trs_bn_relu_forward(const void* y_dev, int32_t y_bf16, int64_t rows_per_pass
  * the divisor.  phase 0 (sums_dev NULL, stat_rows 0) = both at once on the local batch.
  * Outer-product form (the last hidden layer: its dx is the H -> 1 output layer's input gradient g (x) w, mlp.py:115):
  * dx_dev NULL and outer_g_dev (passes*rows_per_pass) / outer_w_dev (H) given — dx[r][c] = g[r] * w[c] is formed in the
- * kernels and never stored (needs H % 4 == 0). */
+ * kernels and never stored (needs H % 4 == 0).  outer_xw_dev (H, may be NULL; outer form with BatchNorm, phase 0):
+ * sum_r g[r] * relu(bn(y))[r][:] = the output layer's weight gradient (what trs_colsum(out, row_weight = g) gives on the
+ * stored activations), from the activations the reduce kernel recomputes anyway. */
 int64_t trs_bn_backward_workspace_floats(int64_t rows_per_pass, int32_t H, int32_t passes);
 int trs_bn_relu_backward(const void* y_dev, int32_t y_bf16, const void* dx_dev, int32_t dx_bf16, int64_t rows_per_pass,
                          int32_t passes, int32_t H,
@@ -526,7 +530,7 @@ int trs_bn_relu_backward(const void* y_dev, int32_t y_bf16, const void* dx_dev, 
                          const float* gamma_dev, const float* beta_dev, float eps, float* dy_dev, void* dy_bf16_dev,
                          float* dgamma_dev, float* dbeta_dev, float* dy_colsum_dev, float* workspace_dev,
                          int32_t phase, float* sums_dev, int64_t stat_rows, const float* outer_g_dev,
-                         const float* outer_w_dev, void* stream);
+                         const float* outer_w_dev, float* outer_xw_dev, void* stream);
 
 /* out[h] = sum_r w[r] * x[r][h] over the passes*rows_per_pass rows (row_weight NULL: plain column sums): bias
  * gradients and the output layer's weight gradient.  Summed per pass first (identical chunking in both passes), so a

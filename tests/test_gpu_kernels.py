@@ -734,6 +734,28 @@ def test_bn_stats_forward_backward(B, H, passes):
         ops.bn_relu_backward(ty, dxo, B, passes, True, mean, var, tg, tb, 1e-5, dy_a, dg_a, db_a)
         ops.bn_relu_backward(ty, None, B, passes, True, mean, var, tg, tb, 1e-5, dy_b, dg_b, db_b, outer=(tgv, tw))
         assert torch.equal(dy_a, dy_b) and torch.equal(dg_a, dg_b) and torch.equal(db_a, db_b)
+        # ... and the output layer's weight gradient sum_r g[r] * relu(bn(y))[r] out of the same reduce pass == the weighted
+        # column sums of the stored activations; everything else unchanged
+        xw = torch.full((H,), float("nan"), device=DEV)
+        dy_c, dg_c, db_c = torch.empty_like(ty), torch.empty(H, device=DEV), torch.empty(H, device=DEV)
+        ops.bn_relu_backward(ty, None, B, passes, True, mean, var, tg, tb, 1e-5, dy_c, dg_c, db_c, outer=(tgv, tw), outer_xw=xw)
+        assert torch.equal(dy_c, dy_b) and torch.equal(dg_c, dg_b) and torch.equal(db_c, db_b)
+        ref_xw = (g.astype(np.float64)[:, None] * np.maximum(yhat, 0).reshape(rows, H)).sum(0)
+        assert rel_err(xw.cpu().numpy(), ref_xw) < 2e-5
+        xw2 = torch.empty(H, device=DEV)
+        ops.colsum(out, xw2, row_weight=tgv, passes=passes)
+        assert rel_err(xw.cpu().numpy(), xw2.cpu().numpy()) < 2e-5
+        with pytest.raises(RuntimeError, match="outer_xw"):  # no BatchNorm: no reduce pass to ride in
+            ops.bn_relu_backward(ty, None, B, passes, False, None, None, None, None, 1e-5, dy_c, None, None,
+                                 outer=(tgv, tw), outer_xw=xw)
+        # forward without a stored output: the dot alone, where the launch forms it
+        if ops.bn_relu_forward_forms_dot(ty):
+            sc2 = torch.empty_like(sc)
+            ops.bn_relu_forward(ty, B, passes, True, passes, mean, var, tg, tb, 1e-5, None, dot=(wv, bv, sc2))
+            assert torch.equal(sc2, sc)
+        else:
+            with pytest.raises(RuntimeError, match="out_dev"):
+                ops.bn_relu_forward(ty, B, passes, True, passes, mean, var, tg, tb, 1e-5, None, dot=(wv, bv, sc))
         ops.bn_relu_backward(ty, None, B, passes, False, None, None, None, None, 1e-5, dy_b, None, None, outer=(tgv, tw))
         assert np.array_equal(dy_b.cpu().numpy(), dxo.cpu().numpy() * (y > 0))
     # no-BN variants

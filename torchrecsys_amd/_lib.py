@@ -163,7 +163,7 @@ PROTOTYPES = {
                                       _i64, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "trs_bn_backward_workspace_floats": (C.c_int64, [_i64, _i32, _i32]),
     "trs_bn_relu_backward": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _i32, _i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _f,
-                                       _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp]),
+                                       _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),
     "trs_colsum_workspace_floats": (C.c_int64, [_i64, _i32, _i32]),
     "trs_colsum": (C.c_int, [_vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
     "trs_rowdot": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),

@@ -317,6 +317,9 @@ struct BnBwdArgs {
   // OUTER kernels: dx[r][c] = og[r] * ow[c] is formed on the fly (the H -> 1 output layer's input gradient, never stored)
   const float* og;
   const float* ow;
+  // OUTER reduce kernel, optional: (passes, n_chunks, H) per-chunk column sums of og[r] * relu(bn(y))[r][c] — the output
+  // layer's weight gradient, from the activations the kernel recomputes anyway (they are then never stored)
+  float* xw_part;
 };
 
 __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
@@ -534,7 +537,7 @@ __device__ __forceinline__ float4 ld4t(const float* p32, const unsigned short* p
 
 template <bool Y16, bool DX16, bool OUTER = false>
 __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_reduce_v4_kernel(const BnBwdArgs a, int tpr) {
-  __shared__ float4 sh[2][TRS_BLOCK];
+  __shared__ float4 sh[OUTER ? 3 : 2][TRS_BLOCK];
   const int tc = threadIdx.x % tpr, rl = threadIdx.x / tpr, nrl = TRS_BLOCK / tpr;
   const int col = (blockIdx.x * tpr + tc) * 4;
   const int chunk = blockIdx.y, pass = blockIdx.z;
@@ -554,17 +557,21 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_reduce_v4_kernel(const BnBwd
       be[q] = a.beta[cc + q];
     }
   }
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, s3[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool want_xw = OUTER && a.xw_part != nullptr;
   constexpr int U = 4;
   for (int64_t r = r0 + rl; r < r1; r += (int64_t)nrl * U) {
     float4 yv[U], dv[U];
+    float grv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t rr = r + (int64_t)u * nrl;
       const int64_t rc = rr < r1 ? rr : r1 - 1;
       yv[u] = ld4t<Y16>(a.y, a.y16, (base + rc) * a.ld + cc);
+      grv[u] = 0.f;
       if (OUTER) {
         const float gr = a.og[base + rc];
+        grv[u] = gr;
         dv[u] = make_float4(gr * ow4.x, gr * ow4.y, gr * ow4.z, gr * ow4.w);
       } else {
         dv[u] = ld4t<DX16>(a.dx, a.dx16, (base + rc) * a.ldd + cc);
@@ -581,11 +588,13 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_reduce_v4_kernel(const BnBwd
         const float d = (in && yhat > 0.f) ? d4[q] : 0.f;
         s1[q] += d;
         s2[q] += d * xhat;
+        if (OUTER) s3[q] += (in && yhat > 0.f) ? grv[u] * yhat : 0.f;  // og[r] * relu(bn(y)): the forward's activation
       }
     }
   }
   sh[0][threadIdx.x] = make_float4(s1[0], s1[1], s1[2], s1[3]);
   sh[1][threadIdx.x] = make_float4(s2[0], s2[1], s2[2], s2[3]);
+  if (OUTER) sh[OUTER ? 2 : 0][threadIdx.x] = make_float4(s3[0], s3[1], s3[2], s3[3]);
   __syncthreads();
   if (rl == 0 && live) {
     float4 t1 = sh[0][tc], t2 = sh[1][tc];
@@ -597,6 +606,14 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_reduce_v4_kernel(const BnBwd
     float* o = a.part + (((int64_t)pass * a.n_chunks + chunk) * 2) * a.H;
     *reinterpret_cast<float4*>(o + col) = t1;
     *reinterpret_cast<float4*>(o + a.H + col) = t2;
+    if (want_xw) {
+      float4 t3 = sh[OUTER ? 2 : 0][tc];
+      for (int l = 1; l < nrl; ++l) {
+        const float4 o3 = sh[OUTER ? 2 : 0][l * tpr + tc];
+        t3.x += o3.x; t3.y += o3.y; t3.z += o3.z; t3.w += o3.w;
+      }
+      *reinterpret_cast<float4*>(a.xw_part + ((int64_t)pass * a.n_chunks + chunk) * a.H + col) = t3;
+    }
   }
 }
 
@@ -1117,9 +1134,9 @@ extern "C" int trs_bn_relu_forward(const void* y_dev, int32_t y_bf16, int64_t ro
                                    float* out_dev, void* out_bf16_dev, int64_t ldo, float momentum,
                                    float* running_mean_dev, float* running_var_dev, const float* dot_w_dev,
                                    const float* dot_bias_dev, float* dot_out_dev, void* stream) {
-  TRS_REQUIRE(y_dev && (out_dev || out_bf16_dev), "trs_bn_relu_forward: NULL argument");
-  TRS_REQUIRE((dot_w_dev == nullptr) == (dot_out_dev == nullptr) && (!dot_out_dev || out_dev),
-              "trs_bn_relu_forward: the output-layer dot needs its weights, its output and the fp32 out");
+  TRS_REQUIRE(y_dev && (out_dev || out_bf16_dev || dot_out_dev), "trs_bn_relu_forward: NULL argument");
+  TRS_REQUIRE((dot_w_dev == nullptr) == (dot_out_dev == nullptr),
+              "trs_bn_relu_forward: the output-layer dot needs its weights and its output");
   TRS_REQUIRE((running_mean_dev == nullptr) == (running_var_dev == nullptr), "trs_bn_relu_forward: running stats");
   TRS_REQUIRE(!running_mean_dev || (use_bn && stat_passes == passes),
               "trs_bn_relu_forward: the running update needs the batch statistics of every pass");
@@ -1136,12 +1153,15 @@ extern "C" int trs_bn_relu_forward(const void* y_dev, int32_t y_bf16, int64_t ro
                   (!out_bf16_dev || (ldo % 4 == 0 && ((uintptr_t)out_bf16_dev & 7) == 0));
   TRS_REQUIRE(v4 || (out_dev && !out_bf16_dev && !y_bf16),
               "trs_bn_relu_forward: bf16 images need H %% 4 == 0 and aligned rows");
-  bool dot_fused = false;
+  const V4Shape v = v4_shape(H % 4 == 0 ? H : 4);
+  // the dot inside the launch: a row = adjacent lanes of one wave
+  const bool dot_fused = dot_out_dev && v4 && v.gx == 1 && v.tpr <= TRS_WAVE && 4 * v.tpr == H;
+  TRS_REQUIRE(out_dev || out_bf16_dev || dot_fused,
+              "trs_bn_relu_forward: the dot of this layer (H = %d) is not formed inside the launch: it needs out_dev", H);
+  TRS_REQUIRE(!dot_out_dev || dot_fused || out_dev, "trs_bn_relu_forward: the row-dot kernel reads the fp32 out_dev");
   if (v4) {
-    const V4Shape v = v4_shape(H);
-    if (dot_out_dev && v.gx == 1 && v.tpr <= TRS_WAVE && 4 * v.tpr == H) {  // a row = adjacent lanes of one wave
+    if (dot_fused) {
       a.dot_w = dot_w_dev; a.dot_b = dot_bias_dev; a.dot_out = dot_out_dev;
-      dot_fused = true;
     }
     const dim3 gr(v.gx, (unsigned)((rows_per_pass + FWD_ROWS - 1) / FWD_ROWS), passes);
     if (y_bf16) hipLaunchKernelGGL(bn_relu_fwd_v4_kernel<true>, gr, dim3(TRS_BLOCK), 0, (hipStream_t)stream, a, v.tpr);
@@ -1167,8 +1187,10 @@ extern "C" int trs_bn_relu_backward(const void* y_dev, int32_t y_bf16, const voi
                                     float* dy_dev, void* dy_bf16_dev, float* dgamma_dev, float* dbeta_dev,
                                     float* dy_colsum_dev, float* workspace_dev, int32_t phase, float* sums_dev,
                                     int64_t stat_rows, const float* outer_g_dev, const float* outer_w_dev,
-                                    void* stream) {
+                                    float* outer_xw_dev, void* stream) {
   const bool outer = outer_g_dev != nullptr;
+  TRS_REQUIRE(!outer_xw_dev || (outer && use_bn && phase == 0),
+              "trs_bn_relu_backward: outer_xw comes out of the outer-product form's BatchNorm reduce (phase 0)");
   TRS_REQUIRE((outer_g_dev == nullptr) == (outer_w_dev == nullptr) && (!outer || (!dx_dev && !dx_bf16)),
               "trs_bn_relu_backward: the outer-product form takes (outer_g, outer_w) INSTEAD of dx");
   TRS_REQUIRE(y_dev && (dx_dev || outer) && (dy_dev || dy_bf16_dev || phase == 1) && workspace_dev,
@@ -1183,12 +1205,14 @@ extern "C" int trs_bn_relu_backward(const void* y_dev, int32_t y_bf16, const voi
   hipStream_t s = (hipStream_t)stream;
   float* sums = sums_dev ? sums_dev : workspace_dev + (int64_t)passes * nc * 2 * H;  // (passes,2,H) behind the partials
   float* cs_part = workspace_dev + (int64_t)passes * nc * 2 * H + (int64_t)passes * 2 * H;  // (passes,nc,H) column-sum partials of dy
+  float* xw_part = cs_part + (int64_t)passes * nc * H;  // (passes,nc,H) partials of outer_xw
   const bool h16 = y_bf16 || dx_bf16;
   BnBwdArgs a = {y_bf16 ? nullptr : (const float*)y_dev, dx_bf16 ? nullptr : (const float*)dx_dev, dy_dev,
                  rows_per_pass, ld, ldd, H, passes, use_bn, nc, mean_dev, var_dev, gamma_dev, beta_dev, eps,
                  workspace_dev, sums, dy_colsum_dev ? cs_part : nullptr, (unsigned short*)dy_bf16_dev,
                  y_bf16 ? (const unsigned short*)y_dev : nullptr, dx_bf16 ? (const unsigned short*)dx_dev : nullptr,
-                 1.0f / (float)(stat_rows > 0 ? stat_rows : rows_per_pass), outer_g_dev, outer_w_dev};
+                 1.0f / (float)(stat_rows > 0 ? stat_rows : rows_per_pass), outer_g_dev, outer_w_dev,
+                 outer_xw_dev ? xw_part : nullptr};
   const bool v4in = H % 4 == 0 && ld % 4 == 0 && ldd % 4 == 0 && ((uintptr_t)y_dev & (y_bf16 ? 7 : 15)) == 0 &&
                     ((uintptr_t)dx_dev & (dx_bf16 ? 7 : 15)) == 0 && v4_ok(workspace_dev, H, 4) &&
                     (!outer || ((uintptr_t)outer_w_dev & 15) == 0);
@@ -1220,6 +1244,11 @@ extern "C" int trs_bn_relu_backward(const void* y_dev, int32_t y_bf16, const voi
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((H + FIN_COLS - 1) / FIN_COLS), dim3(TRS_BLOCK), 0, s, workspace_dev, H, nc, passes, sums,
                        dgamma_dev, dbeta_dev);
     TRS_CHECK_LAUNCH("bn_bwd_final_kernel");
+    if (outer_xw_dev) {
+      hipLaunchKernelGGL(colsum_final_kernel, dim3((H + FIN_COLS - 1) / FIN_COLS), dim3(TRS_BLOCK), 0, s, xw_part, H, nc,
+                         passes, outer_xw_dev);
+      TRS_CHECK_LAUNCH("colsum_final_kernel");
+    }
   }
   if (phase == 1) return TRS_OK;  // the caller reduces `sums` over ranks, then calls phase 2 with stat_rows = world * rows
   if (v4a) {
@@ -1245,7 +1274,7 @@ extern "C" int trs_bn_relu_backward(const void* y_dev, int32_t y_bf16, const voi
 }
 
 extern "C" int64_t trs_bn_backward_workspace_floats(int64_t rows_per_pass, int32_t H, int32_t passes) {
-  return (int64_t)passes * n_chunks_of(rows_per_pass) * 3 * H + (int64_t)passes * 2 * H;
+  return (int64_t)passes * n_chunks_of(rows_per_pass) * 4 * H + (int64_t)passes * 2 * H;
 }
 
 extern "C" int trs_colsum(const float* x_dev, int64_t rows_per_pass, int32_t passes, int32_t H, int64_t ld,

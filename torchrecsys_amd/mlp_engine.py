@@ -166,6 +166,12 @@ class MLPCompute:
                 xn = torch.empty(y.shape, dtype=torch.float32, device=dev)
                 if l == L - 1:  # the H -> 1 output layer rides in the last hidden layer's BN + ReLU launch
                     run = dict(run, dot=(net.output_layer.weight.data.reshape(-1), net.output_layer.bias.data, out))
+                    # ... and with BatchNorm the last activations are not stored at all: the backward's reduce kernel
+                    # recomputes them for the output layer's weight gradient (outer_xw); without BatchNorm there is no
+                    # reduce pass, under sync-BN it is a separate phase: those keep x_L
+                    if use_bn and ops.bn_relu_forward_forms_dot(y) and not (training and self.sync_bn
+                                                                              and tdist.world_info()[1] > 1):
+                        xn = None
                 ops.bn_relu_forward(y, B, passes, use_bn, stat_passes, mean, var, gamma, beta, BN_EPS, xn, **run)
             x = xn
             ctx["x"].append(x)
@@ -218,19 +224,25 @@ class MLPCompute:
             grads[p] = t
             return t
 
-        xL = ctx["x"][L]
+        xL = ctx["x"][L]  # None: not stored (forward) — the last hidden layer's backward gives the output layer's dW
         ol = net.output_layer
-        ops.colsum(xL, slot(ol.weight).reshape(-1), row_weight=g, passes=passes)
+        xw = None
+        if xL is None:
+            xw = slot(ol.weight).reshape(-1)
+        else:
+            ops.colsum(xL, slot(ol.weight).reshape(-1), row_weight=g, passes=passes)
         ops.colsum(g.reshape(-1, 1), slot(ol.bias), passes=passes)
         # the output layer's input gradient dx[r][c] = g[r] * w[c]: formed inside the last hidden layer's backward kernels
         # (never stored) when their 4-column form applies; else materialised
         w_out = ol.weight.data.reshape(-1)
-        outer = (g, w_out) if (L > 0 and xL.shape[1] % 4 == 0 and ctx["y"][L - 1].stride(0) % 4 == 0) else None
+        HL = ctx["y"][L - 1].shape[1] if L > 0 else 0
+        outer = (g, w_out) if (L > 0 and HL % 4 == 0 and ctx["y"][L - 1].stride(0) % 4 == 0) else None
+        assert outer is not None or xL is not None
         dx = None
         if outer is None:
             dx = torch.empty_like(xL)
             ops.outer(g, w_out, dx)
-        if on_group_done:
+        if on_group_done and xw is None:  # (with xw the output layer's dW is complete after the last hidden layer's reduce)
             on_group_done(L)
         res = ctx.get("resident", False)
         sync = self.sync_bn and tdist.world_info()[1] > 1
@@ -257,7 +269,9 @@ class MLPCompute:
                 bn = net.bns[l]
                 ops.bn_relu_backward(y, dx, B, passes, True, ctx["mean"][l], ctx["var"][l], bn.weight.data, bn.bias.data,
                                      BN_EPS, dy, slot(bn.weight), slot(bn.bias), dy_colsum=slot(fc.bias), dy16=dy16,
-                                     outer=ou)
+                                     outer=ou, outer_xw=xw if l == L - 1 else None)
+                if on_group_done and xw is not None and l == L - 1:
+                    on_group_done(L)
             else:
                 ops.bn_relu_backward(y, dx, B, passes, False, None, None, None, None, BN_EPS, dy, None, None,
                                      dy_colsum=slot(fc.bias), dy16=dy16, outer=ou)  # db = column sums of dy, same kernel

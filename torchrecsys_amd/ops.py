@@ -596,6 +596,13 @@ def gemm_bf16in(tn, A, B, out=None, bias=None, bn_part=None, out_bf16=False, alp
     return out
 
 
+def bn_relu_forward_forms_dot(y):
+    """trs_bn_relu_forward forms the output-layer dot inside its launch for this pre-activation tensor (a row's columns in
+    one wave: H a power of two in 4..256, 4-element-aligned rows) — the activations then need not be stored."""
+    H = y.shape[1]
+    return 4 <= H <= 256 and (H & (H - 1)) == 0 and y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0
+
+
 def gemm_bf16in_ok(M, N, K):
     """Shapes the bf16-resident kernels take (all tiles interior)."""
     return M % GEMM_TILE_ROWS == 0 and N % 128 == 0 and K % 64 == 0
@@ -631,7 +638,7 @@ def bn_relu_forward(y, rows_per_pass, passes, use_bn, stat_passes, mean, var, ga
     scores): the H -> 1 output layer scores[r] = out[r] . w + bias from the same launch where the layer is narrow enough
     (rowdot on `out` otherwise)."""
     H = y.shape[1]
-    ldo = (out if out is not None else out16).stride(0)
+    ldo = (out if out is not None else out16).stride(0) if (out is not None or out16 is not None) else H
     check(_lib.load().trs_bn_relu_forward(ptr(y), int(y.dtype == torch.bfloat16), rows_per_pass, passes, H, y.stride(0),
                                           int(use_bn), stat_passes,
                                           ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps), ptr(out), ptr(out16),
@@ -641,10 +648,11 @@ def bn_relu_forward(y, rows_per_pass, passes, use_bn, stat_passes, mean, var, ga
 
 
 def bn_relu_backward(y, dx, rows_per_pass, passes, use_bn, mean, var, gamma, beta, eps, dy, dgamma, dbeta,
-                     dy_colsum=None, dy16=None, phase=0, sums=None, stat_rows=0, outer=None):
+                     dy_colsum=None, dy16=None, phase=0, sums=None, stat_rows=0, outer=None, outer_xw=None):
     """phase 0: whole backward on the local batch.  Synchronised BatchNorm: phase 1 (reduce: `sums` (passes,2,H) fp32
     receives sum(d), sum(d*xhat)), all-reduce `sums`, phase 2 (apply with stat_rows = world * rows_per_pass).
-    outer=(g, w) with dx=None: dx[r][c] = g[r] * w[c] formed inside the kernels (the output layer's input gradient)."""
+    outer=(g, w) with dx=None: dx[r][c] = g[r] * w[c] formed inside the kernels (the output layer's input gradient);
+    outer_xw (H): receives sum_r g[r] * relu(bn(y))[r] — the output layer's weight gradient without stored activations."""
     lib = _lib.load()
     H = y.shape[1]
     ws = _workspace(y.device, 4 * lib.trs_bn_backward_workspace_floats(rows_per_pass, H, passes))
@@ -655,7 +663,7 @@ def bn_relu_backward(y, dx, rows_per_pass, passes, use_bn, mean, var, gamma, bet
                                    rows_per_pass, passes, H, y.stride(0), ldd, int(use_bn),
                                    ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps), ptr(dy), ptr(dy16),
                                    ptr(dgamma), ptr(dbeta), ptr(dy_colsum), ptr(ws), int(phase), ptr(sums),
-                                   int(stat_rows), ptr(og), ptr(ow), _stream()), "trs_bn_relu_backward")
+                                   int(stat_rows), ptr(og), ptr(ow), ptr(outer_xw), _stream()), "trs_bn_relu_backward")
 
 
 def colsum(x, out, row_weight=None, passes=1):
