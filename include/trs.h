@@ -494,7 +494,8 @@ int trs_bn_stats_finalize(const float* part_dev, int64_t rows_per_pass, int32_t 
  * running_mean_dev / running_var_dev (both or neither; need use_bn and stat_passes == passes): the momentum update of
  * the running statistics from mean_dev / var_dev, pass by pass — what trs_bn_stats_finalize does when IT is given the
  * running pointers (same arithmetic, bit for bit); pass them to one of the two, not both.  Done by the forward kernel's
- * first row block, which saves the training step one launch per layer.
+ * first row block, which saves the training step one launch per layer.  num_batches_tracked_dev (one int64, may be NULL;
+ * with the running pointers): += passes, BatchNorm1d's batch counter, in the same place.
  * dot_w_dev (H) / dot_bias_dev (1, may be NULL) / dot_out_dev (rows_per_pass * passes): the H -> 1 output layer on the
  * last hidden layer's activations, dot_out[r] = sum_c out[r][c] * dot_w[c] + dot_bias (mlp.py:114); formed from the
  * registers of this launch when a row's columns sit in one wave (H a power of two <= 256, aligned rows) — out_dev and
@@ -506,7 +507,8 @@ int trs_bn_relu_forward(const void* y_dev, int32_t y_bf16, int64_t rows_per_pass
                         int32_t use_bn, int32_t stat_passes, const float* mean_dev, const float* var_dev,
                         const float* gamma_dev, const float* beta_dev, float eps, float* out_dev, void* out_bf16_dev,
                         int64_t ldo, float momentum, float* running_mean_dev, float* running_var_dev,
-                        const float* dot_w_dev, const float* dot_bias_dev, float* dot_out_dev, void* stream);
+                        int64_t* num_batches_tracked_dev, const float* dot_w_dev, const float* dot_bias_dev,
+                        float* dot_out_dev, void* stream);
 
 /* Backward of relu(bn(y)) in train mode from dx = dL/d(out): dy (same shape), dgamma/dbeta (H) summed over both
  * passes.  use_bn = 0: dy = dx * [y > 0].  dy_colsum_dev (H, may be NULL): column sums of dy = the gradient of the

@@ -687,9 +687,11 @@ def test_bn_stats_forward_backward(B, H, passes):
     # the running update riding in the forward launch == the one bn_batch_stats made above, bit for bit; same output
     rm2, rv2 = torch.from_numpy(rm0.copy()).to(DEV), torch.from_numpy(rv0.copy()).to(DEV)
     out2 = torch.empty_like(ty)
+    nbt = torch.tensor(5, dtype=torch.int64, device=DEV)
     ops.bn_relu_forward(ty, B, passes, True, passes, mean, var, tg, tb, 1e-5, out2, momentum=0.1, running_mean=rm2,
-                        running_var=rv2)
+                        running_var=rv2, tracked=nbt)
     assert torch.equal(rm2, rm) and torch.equal(rv2, rv) and torch.equal(out2, out)
+    assert int(nbt.item()) == 5 + passes  # BatchNorm1d.num_batches_tracked rides along
     # the H -> 1 output layer from the same launch (H a power of two <= 256: a row sits in one wave) or by the row-dot
     # kernel behind it (wide / unaligned layers): scores = out . w + bias
     wv = torch.from_numpy(rs.normal(0, 1, H).astype(np.float32)).to(DEV)

@@ -509,7 +509,10 @@ def test_mlp_bf16_resident_step_matches_the_bf16_oracle(use_bn, M, shape):
     W0 = [fc.weight.data.clone() for fc in net.fcs]
     scores2, ctx2 = net.compute.forward(ids, 2, True)
     assert torch.equal(scores2, scores)
-    grads2, dx02 = net.compute.backward(ctx2, torch.cat([gp, gn]), sgd_lr=lrs)
+    grads2, dx02 = net.compute.backward(ctx2, torch.cat([gp, gn]), sgd_lr=lrs, g_antisymmetric=True)
+    # (g_antisymmetric: the output layer's bias gradient written as the exact 0 the two per-pass sums cancel to)
+    assert torch.equal(grads2[net.output_layer.bias], grads[net.output_layer.bias])
+    assert float(grads2[net.output_layer.bias].abs().max()) == 0.0
     for l, fc in enumerate(net.fcs):
         assert fc.weight not in grads2 and fc.bias in grads2
         assert torch.equal(fc.weight.data, W0[l] - lrs[l] * grads[fc.weight]), l

@@ -160,7 +160,7 @@ PROTOTYPES = {
     "trs_bn_workspace_floats": (C.c_int64, [_i64, _i32, _i32]),
     "trs_bn_batch_stats": (C.c_int, [_vp, _i64, _i32, _i64, _i32, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "trs_bn_relu_forward": (C.c_int, [_vp, _i32, _i64, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _f, _vp, _vp,
-                                      _i64, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                      _i64, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "trs_bn_backward_workspace_floats": (C.c_int64, [_i64, _i32, _i32]),
     "trs_bn_relu_backward": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _i32, _i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _f,
                                        _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),

@@ -217,9 +217,11 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_stats_final_kernel(const float* 
 // running statistics: one momentum update per pass, in pass order (the reference's two net.forward calls, mlp.py:88-115)
 __global__ void bn_running_update_kernel(const float* __restrict__ mean, const float* __restrict__ var,
                                          int64_t rows_per_pass, int H, int passes, float momentum,
-                                         float* __restrict__ running_mean, float* __restrict__ running_var) {
+                                         float* __restrict__ running_mean, float* __restrict__ running_var,
+                                         long long* tracked) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= H) return;
+  if (col == 0 && tracked) *tracked += passes;
   const float n = (float)rows_per_pass;
   float rm = running_mean[col], rv = running_var[col];
   for (int pass = 0; pass < passes; ++pass) {
@@ -250,6 +252,7 @@ struct BnFwdArgs {
   float momentum;
   float* running_mean;
   float* running_var;
+  long long* tracked;  // BatchNorm1d.num_batches_tracked (+= passes with the running update), or NULL
   // optional (v4 kernel, H == 4 * threads-per-row <= 256: a row's columns sit in one wave): the H -> 1 output layer
   // dot_out[row] = sum_c out[row][c] * dot_w[c] + dot_b[0] formed from the registers that hold the row; NULL = not here
   const float* dot_w;
@@ -689,6 +692,7 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_relu_fwd_v4_kernel(const BnFwdAr
       a.running_mean[col + q] = rm;
       a.running_var[col + q] = rv;
     }
+    if (col == 0 && a.tracked) *a.tracked += a.passes;
   }
 }
 
@@ -1100,7 +1104,8 @@ extern "C" int trs_bn_batch_stats(const float* y_dev, int64_t rows_per_pass, int
   TRS_CHECK_LAUNCH("bn_stats_final_kernel");
   if (running_mean_dev) {
     hipLaunchKernelGGL(bn_running_update_kernel, dim3((H + TRS_BLOCK - 1) / TRS_BLOCK), dim3(TRS_BLOCK), 0, s,
-                       mean_out_dev, var_out_dev, rows_per_pass, H, passes, momentum, running_mean_dev, running_var_dev);
+                       mean_out_dev, var_out_dev, rows_per_pass, H, passes, momentum, running_mean_dev, running_var_dev,
+                       (long long*)nullptr);
     TRS_CHECK_LAUNCH("bn_running_update_kernel");
   }
   return TRS_OK;
@@ -1122,7 +1127,7 @@ extern "C" int trs_bn_stats_finalize(const float* part_dev, int64_t rows_per_pas
   if (running_mean_dev) {
     hipLaunchKernelGGL(bn_running_update_kernel, dim3((H + TRS_BLOCK - 1) / TRS_BLOCK), dim3(TRS_BLOCK), 0,
                        (hipStream_t)stream, mean_out_dev, var_out_dev, rows_per_pass, H, passes, momentum,
-                       running_mean_dev, running_var_dev);
+                       running_mean_dev, running_var_dev, (long long*)nullptr);
     TRS_CHECK_LAUNCH("bn_running_update_kernel");
   }
   return TRS_OK;
@@ -1132,8 +1137,9 @@ extern "C" int trs_bn_relu_forward(const void* y_dev, int32_t y_bf16, int64_t ro
                                    int64_t ld, int32_t use_bn, int32_t stat_passes, const float* mean_dev,
                                    const float* var_dev, const float* gamma_dev, const float* beta_dev, float eps,
                                    float* out_dev, void* out_bf16_dev, int64_t ldo, float momentum,
-                                   float* running_mean_dev, float* running_var_dev, const float* dot_w_dev,
-                                   const float* dot_bias_dev, float* dot_out_dev, void* stream) {
+                                   float* running_mean_dev, float* running_var_dev, int64_t* num_batches_tracked_dev,
+                                   const float* dot_w_dev, const float* dot_bias_dev, float* dot_out_dev, void* stream) {
+  TRS_REQUIRE(!num_batches_tracked_dev || running_mean_dev, "trs_bn_relu_forward: the batch counter rides with the running update");
   TRS_REQUIRE(y_dev && (out_dev || out_bf16_dev || dot_out_dev), "trs_bn_relu_forward: NULL argument");
   TRS_REQUIRE((dot_w_dev == nullptr) == (dot_out_dev == nullptr),
               "trs_bn_relu_forward: the output-layer dot needs its weights and its output");
@@ -1147,7 +1153,7 @@ extern "C" int trs_bn_relu_forward(const void* y_dev, int32_t y_bf16, int64_t ro
   BnFwdArgs a = {y_bf16 ? nullptr : (const float*)y_dev, out_dev, (unsigned short*)out_bf16_dev, rows_per_pass, ld,
                  ldo, H, passes, stat_passes, use_bn, mean_dev, var_dev, gamma_dev, beta_dev, eps,
                  y_bf16 ? (const unsigned short*)y_dev : nullptr, momentum, running_mean_dev, running_var_dev,
-                 nullptr, nullptr, nullptr};
+                 (long long*)num_batches_tracked_dev, nullptr, nullptr, nullptr};
   const bool v4 = H % 4 == 0 && ld % 4 == 0 && ((uintptr_t)y_dev & (y_bf16 ? 7 : 15)) == 0 &&
                   (!out_dev || v4_ok(out_dev, H, ldo)) &&
                   (!out_bf16_dev || (ldo % 4 == 0 && ((uintptr_t)out_bf16_dev & 7) == 0));
@@ -1172,7 +1178,7 @@ extern "C" int trs_bn_relu_forward(const void* y_dev, int32_t y_bf16, int64_t ro
     if (running_mean_dev)
       hipLaunchKernelGGL(bn_running_update_kernel, dim3((H + TRS_BLOCK - 1) / TRS_BLOCK), dim3(TRS_BLOCK), 0,
                          (hipStream_t)stream, mean_dev, var_dev, rows_per_pass, H, passes, momentum, running_mean_dev,
-                         running_var_dev);
+                         running_var_dev, (long long*)num_batches_tracked_dev);
   }
   TRS_CHECK_LAUNCH("bn_relu_fwd_kernel");
   if (dot_out_dev && !dot_fused)  // wide or unaligned layers: the stand-alone row dot on the fp32 output

@@ -146,14 +146,16 @@ class MLPCompute:
                     sync = self.sync_bn and tdist.world_info()[1] > 1
                     # the running statistics' momentum update rides in the BN+ReLU launch below
                     if not sync:
-                        run = {"momentum": BN_MOMENTUM, "running_mean": bn.running_mean, "running_var": bn.running_var}
+                        run = {"momentum": BN_MOMENTUM, "running_mean": bn.running_mean, "running_var": bn.running_var,
+                               "tracked": bn.num_batches_tracked}
                     if fuse_stats:
                         ops.bn_stats_finalize(part, B, ops.GEMM_TILE_ROWS, H, passes, BN_MOMENTUM, mean, var, None, None)
                     else:
                         ops.bn_batch_stats(y, B, passes, BN_MOMENTUM, mean, var, None, None)
                     if sync:
                         self._sync_stats(mean, var, bn, B)
-                    tracked.append(bn.num_batches_tracked)
+                    if sync:  # (otherwise the counter rides with the running update)
+                        tracked.append(bn.num_batches_tracked)
                     stat_passes = passes
                 else:
                     mean, var = bn.running_mean, bn.running_var
@@ -201,7 +203,7 @@ class MLPCompute:
             bn.running_mean.mul_(1.0 - BN_MOMENTUM).add_(gm[ps].float(), alpha=BN_MOMENTUM)
             bn.running_var.mul_(1.0 - BN_MOMENTUM).add_(unb[ps].float(), alpha=BN_MOMENTUM)
 
-    def backward(self, ctx, g, grad_of=None, on_group_done=None, sgd_lr=None):
+    def backward(self, ctx, g, grad_of=None, on_group_done=None, sgd_lr=None, g_antisymmetric=False):
         """g: (passes*B,) = dL/dscore.  grad_of(param) -> tensor to write that dense parameter's gradient into
         (default: fresh tensors).  on_group_done(i): called once the kernels that write the dense gradients of group i
         are enqueued — i = L for the output layer (first), then L-1 ... 0 for the hidden layers (Linear + BatchNorm
@@ -210,7 +212,9 @@ class MLPCompute:
         sgd_lr (list, one learning rate per hidden Linear layer, or None): plain SGD folded into the weight-gradient
         GEMM on the bf16-resident path — W_l = W_l - lr_l * dW_l written by the GEMM's reduce, dW_l never stored and W_l
         absent from `grads` (single process only: nothing to all-reduce; the input-gradient GEMM reads the W^T image
-        taken in the forward pass, not the master weights)."""
+        taken in the forward pass, not the master weights).
+        g_antisymmetric: the caller guarantees g[B + t] == -g[t] (the pairwise losses: hinge, BPR) — the output layer's bias
+        gradient sum(g) is then the exact +0.0 the two per-pass sums cancel to, and is written as such."""
         net = self.net
         D, M, L, use_bn = self._dims()
         B, passes = ctx["B"], ctx["passes"]
@@ -231,7 +235,10 @@ class MLPCompute:
             xw = slot(ol.weight).reshape(-1)
         else:
             ops.colsum(xL, slot(ol.weight).reshape(-1), row_weight=g, passes=passes)
-        ops.colsum(g.reshape(-1, 1), slot(ol.bias), passes=passes)
+        if g_antisymmetric and passes == 2:
+            slot(ol.bias).zero_()  # (-S) + S of identically ordered per-pass sums: what the colsum below returns, bit for bit
+        else:
+            ops.colsum(g.reshape(-1, 1), slot(ol.bias), passes=passes)
         # the output layer's input gradient dx[r][c] = g[r] * w[c]: formed inside the last hidden layer's backward kernels
         # (never stored) when their 4-column form applies; else materialised
         w_out = ol.weight.data.reshape(-1)
@@ -376,7 +383,7 @@ class MLPTrainer:
         grads, dx0 = net.compute.backward(ctx, g, grad_of=self.bucket.grad_of,
                                           on_group_done=(lambda i: works.append(
                                               self.bucket.allreduce_segment_async(self.segs[i]))) if dp else None,
-                                          sgd_lr=None if dp else self._fused_weight_lrs())
+                                          sgd_lr=None if dp else self._fused_weight_lrs(), g_antisymmetric=True)
         net.compute.dx0_bf16 = False
         tables = []
         if fused_lr is None:  # per-table paths: one index vector per table over the 2B rows of d x0

@@ -632,9 +632,10 @@ def bn_stats_finalize(part, rows_per_pass, chunk_rows, H, passes, momentum, mean
 
 
 def bn_relu_forward(y, rows_per_pass, passes, use_bn, stat_passes, mean, var, gamma, beta, eps, out=None, out16=None,
-                    momentum=0.0, running_mean=None, running_var=None, dot=None):
+                    momentum=0.0, running_mean=None, running_var=None, dot=None, tracked=None):
     """out: fp32 and/or out16: bfloat16 image of relu(bn(y)) (same row stride in elements).  running_mean/var: the
-    momentum update of the running statistics rides in this launch (instead of bn_stats_finalize's).  dot=(w, bias,
+    momentum update of the running statistics rides in this launch (instead of bn_stats_finalize's), and with it
+    tracked (BatchNorm1d.num_batches_tracked, int64 scalar tensor) += passes.  dot=(w, bias,
     scores): the H -> 1 output layer scores[r] = out[r] . w + bias from the same launch where the layer is narrow enough
     (rowdot on `out` otherwise)."""
     H = y.shape[1]
@@ -642,7 +643,7 @@ def bn_relu_forward(y, rows_per_pass, passes, use_bn, stat_passes, mean, var, ga
     check(_lib.load().trs_bn_relu_forward(ptr(y), int(y.dtype == torch.bfloat16), rows_per_pass, passes, H, y.stride(0),
                                           int(use_bn), stat_passes,
                                           ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps), ptr(out), ptr(out16),
-                                          ldo, float(momentum), ptr(running_mean), ptr(running_var),
+                                          ldo, float(momentum), ptr(running_mean), ptr(running_var), ptr(tracked),
                                           *((ptr(t) for t in dot) if dot is not None else (None, None, None)), _stream()),
           "trs_bn_relu_forward")
 
