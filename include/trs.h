@@ -471,6 +471,10 @@ int trs_gemm_bf16in(int tn, int64_t M, int64_t N, int64_t K, float alpha, const 
  * the per-step refresh of the weight images the bf16-resident GEMMs read. */
 int trs_f32_to_bf16(const float* src_dev, int64_t rows, int64_t cols, int64_t ld, void* dst_dev, void* dst_t_dev,
                     void* stream);
+/* The same for n (1..8) matrices in ONE launch — every layer's weight images of an MLP step.  The arrays are host arrays
+ * of n entries (device pointers / sizes per matrix); dst_dev[k] or dst_t_dev[k] may be NULL. */
+int trs_f32_to_bf16_multi(int32_t n, const float* const* src_dev, const int64_t* rows, const int64_t* cols,
+                          const int64_t* ld, void* const* dst_dev, void* const* dst_t_dev, void* stream);
 
 /* Train-mode BatchNorm1d statistics of y (passes*rows_per_pass, H) per pass: mean_out/var_out (passes,H), biased
  * variance (chunked two-pass + Chan combination in fp64).  running_mean/var (H) non-NULL: updated once per pass in

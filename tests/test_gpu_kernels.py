@@ -551,6 +551,21 @@ def test_gemm_bf16_resident_nt_and_tn(M, N, K):
     d, dt = torch.empty((70, 45), dtype=torch.bfloat16, device=DEV), torch.empty((45, 70), dtype=torch.bfloat16, device=DEV)
     ops.f32_to_bf16(w, d, dt)
     assert torch.equal(d, w.to(torch.bfloat16)) and torch.equal(dt, w.to(torch.bfloat16).t().contiguous())
+    # ... of several matrices in one launch (every layer's images of an MLP step)
+    ws = [torch.from_numpy(rs.normal(0, 1, sh).astype(np.float32)).to(DEV) for sh in ((70, 45), (128, 256), (33, 1), (5, 97))]
+    ds = [torch.empty(w_.shape, dtype=torch.bfloat16, device=DEV) for w_ in ws]
+    dts = [torch.empty(w_.shape[::-1], dtype=torch.bfloat16, device=DEV) for w_ in ws]
+    dts[2] = None
+    wi = ops.WeightImages(ws, ds, dts)
+    wi.refresh()
+    for w_, d_, dt_ in zip(ws, ds, dts):
+        assert torch.equal(d_, w_.to(torch.bfloat16))
+        assert dt_ is None or torch.equal(dt_, w_.to(torch.bfloat16).t().contiguous())
+    ws[1].mul_(2.0)
+    wi.refresh()
+    assert torch.equal(ds[1], ws[1].to(torch.bfloat16))
+    with pytest.raises(ValueError):
+        ops.WeightImages(ws * 3, ds * 3, dts * 3)
 
 
 @pytest.mark.parametrize("H,Kin,rows", [(256, 384, 64 * 300), (512, 1024, 64 * 257), (1024, 768, 8192)])

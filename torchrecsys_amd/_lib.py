@@ -156,6 +156,7 @@ PROTOTYPES = {
     "trs_gemm_bf16in": (C.c_int, [_i32, _i64, _i64, _i64, _f, _vp, _i64, _vp, _i64, _f, _vp, _vp, _i64, _vp, _vp, _vp,
                                   _i64, _vp]),
     "trs_f32_to_bf16": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "trs_f32_to_bf16_multi": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "trs_bn_stats_finalize": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _f, _vp, _vp, _vp, _vp, _vp]),
     "trs_bn_workspace_floats": (C.c_int64, [_i64, _i32, _i32]),
     "trs_bn_batch_stats": (C.c_int, [_vp, _i64, _i32, _i64, _i32, _f, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -860,11 +860,11 @@ __global__ __launch_bounds__(512) void gemm32_nt_glds_kernel(const GemmArgs g) {
 
 // fp32 (rows, cols) -> bf16 copy (same layout) and, optionally, the transposed bf16 copy (cols, rows): the per-step
 // refresh of the MLP's weight images (tiny: the weights, not the activations).
-__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, int64_t rows, int64_t cols,
-                                                         int64_t ld, unsigned short* __restrict__ dst,
-                                                         unsigned short* __restrict__ dst_t) {
+__device__ __forceinline__ void f32_to_bf16_tile(const float* __restrict__ src, int64_t rows, int64_t cols, int64_t ld,
+                                                 unsigned short* __restrict__ dst, unsigned short* __restrict__ dst_t,
+                                                 int64_t tile_x, int64_t tile_y) {
   __shared__ float tile[32][33];
-  const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
+  const int64_t r0 = tile_y * 32, c0 = tile_x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   for (int j = ty; j < 32; j += 8) {
     const int64_t r = r0 + j, c = c0 + tx;
@@ -878,6 +878,31 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
       const int64_t c = c0 + j, r = r0 + tx;
       if (r < rows && c < cols) dst_t[c * rows + r] = __builtin_bit_cast(unsigned short, (__bf16)tile[tx][j]);
     }
+}
+
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, int64_t rows, int64_t cols,
+                                                         int64_t ld, unsigned short* __restrict__ dst,
+                                                         unsigned short* __restrict__ dst_t) {
+  f32_to_bf16_tile(src, rows, cols, ld, dst, dst_t, blockIdx.x, blockIdx.y);
+}
+
+// the same for up to TRS_IMG_MAX matrices in one launch (the weight images of every layer of the MLP): workgroup b serves
+// tile b - first[k] of matrix k
+constexpr int TRS_IMG_MAX = 8;
+struct ImgArgs {
+  const float* src[TRS_IMG_MAX];
+  unsigned short* dst[TRS_IMG_MAX];
+  unsigned short* dst_t[TRS_IMG_MAX];
+  int64_t rows[TRS_IMG_MAX], cols[TRS_IMG_MAX], ld[TRS_IMG_MAX];
+  int64_t first[TRS_IMG_MAX + 1];  // first tile of matrix k; first[n] = total
+  int n;
+};
+__global__ __launch_bounds__(256) void f32_to_bf16_multi_kernel(const ImgArgs a) {
+  int k = 0;
+  while (k + 1 < a.n && (int64_t)blockIdx.x >= a.first[k + 1]) ++k;
+  const int64_t t = (int64_t)blockIdx.x - a.first[k];
+  const int64_t tiles_x = (a.cols[k] + 31) / 32;
+  f32_to_bf16_tile(a.src[k], a.rows[k], a.cols[k], a.ld[k], a.dst[k], a.dst_t[k], t % tiles_x, t / tiles_x);
 }
 
 // C = alpha * sum_z slabs[z] + beta * C (+ bias): the launch-boundary reduce of the split-K partial slabs, fixed
@@ -1142,5 +1167,27 @@ extern "C" int trs_f32_to_bf16(const float* src_dev, int64_t rows, int64_t cols,
   hipLaunchKernelGGL(f32_to_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, src_dev, rows, cols, ld,
                      (unsigned short*)dst_dev, (unsigned short*)dst_t_dev);
   TRS_CHECK_LAUNCH("f32_to_bf16_kernel");
+  return TRS_OK;
+}
+
+extern "C" int trs_f32_to_bf16_multi(int32_t n, const float* const* src_dev, const int64_t* rows, const int64_t* cols,
+                                     const int64_t* ld, void* const* dst_dev, void* const* dst_t_dev, void* stream) {
+  TRS_REQUIRE(n >= 1 && n <= TRS_IMG_MAX && src_dev && rows && cols && ld && dst_dev && dst_t_dev,
+              "trs_f32_to_bf16_multi: 1..%d matrices", TRS_IMG_MAX);
+  ImgArgs a = {};
+  a.n = n;
+  int64_t total = 0;
+  for (int k = 0; k < n; ++k) {
+    TRS_REQUIRE(src_dev[k] && (dst_dev[k] || dst_t_dev[k]) && rows[k] > 0 && cols[k] > 0 && ld[k] >= cols[k],
+                "trs_f32_to_bf16_multi: bad arguments for matrix %d", k);
+    a.src[k] = src_dev[k]; a.dst[k] = (unsigned short*)dst_dev[k]; a.dst_t[k] = (unsigned short*)dst_t_dev[k];
+    a.rows[k] = rows[k]; a.cols[k] = cols[k]; a.ld[k] = ld[k];
+    a.first[k] = total;
+    total += ((rows[k] + 31) / 32) * ((cols[k] + 31) / 32);
+  }
+  a.first[n] = total;
+  TRS_REQUIRE(total < ((int64_t)1 << 31), "trs_f32_to_bf16_multi: too many tiles");
+  hipLaunchKernelGGL(f32_to_bf16_multi_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, a);
+  TRS_CHECK_LAUNCH("f32_to_bf16_multi_kernel");
   return TRS_OK;
 }

@@ -57,8 +57,15 @@ class MLPCompute:
             dev = net.fcs[0].weight.device
             self.w16 = [torch.empty(fc.weight.shape, dtype=torch.bfloat16, device=dev) for fc in net.fcs]
             self.w16t = [torch.empty(fc.weight.shape[::-1], dtype=torch.bfloat16, device=dev) for fc in net.fcs]
-        for fc, w, wt in zip(net.fcs, self.w16, self.w16t):
-            ops.f32_to_bf16(fc.weight.data, w, wt)
+        srcs = [fc.weight.data for fc in net.fcs]
+        if len(srcs) > ops.WeightImages.MAX:
+            for src, w, wt in zip(srcs, self.w16, self.w16t):
+                ops.f32_to_bf16(src, w, wt)
+            return
+        wi = getattr(self, "_wimg", None)
+        if wi is None or wi.key != tuple(t.data_ptr() for t in srcs):  # (weights re-allocated: load_state_dict, .to())
+            wi = self._wimg = ops.WeightImages(srcs, self.w16, self.w16t)
+        wi.refresh()  # every layer's two images, one launch
 
     def _gemm16(self, tn, A, B, **kw):
         ev = self.gemm_events

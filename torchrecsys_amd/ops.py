@@ -615,6 +615,31 @@ def f32_to_bf16(src, dst=None, dst_t=None):
           "trs_f32_to_bf16")
 
 
+class WeightImages:
+    """trs_f32_to_bf16_multi with its argument arrays kept: the bf16 (and transposed bf16) images of up to 8 fp32 matrices
+    refreshed by one launch (srcs[k] (rows, cols) -> dsts[k] (rows, cols), dsts_t[k] (cols, rows))."""
+
+    MAX = 8
+
+    def __init__(self, srcs, dsts, dsts_t):
+        n = len(srcs)
+        if not 1 <= n <= self.MAX:
+            raise ValueError(f"WeightImages: 1..{self.MAX} matrices")
+        self.keep = (list(srcs), list(dsts), list(dsts_t))
+        self.key = tuple(t.data_ptr() for t in srcs)
+        self.n = n
+        self.src = (C.c_void_p * n)(*[t.data_ptr() for t in srcs])
+        self.dst = (C.c_void_p * n)(*[ptr(t) for t in dsts])
+        self.dst_t = (C.c_void_p * n)(*[ptr(t) for t in dsts_t])
+        self.rows = (C.c_int64 * n)(*[t.shape[0] for t in srcs])
+        self.cols = (C.c_int64 * n)(*[t.shape[1] for t in srcs])
+        self.ld = (C.c_int64 * n)(*[t.stride(0) for t in srcs])
+
+    def refresh(self):
+        check(_lib.load().trs_f32_to_bf16_multi(self.n, self.src, self.rows, self.cols, self.ld, self.dst, self.dst_t,
+                                                _stream()), "trs_f32_to_bf16_multi")
+
+
 def bn_batch_stats(y, rows_per_pass, passes, momentum, mean_out, var_out, running_mean, running_var):
     lib = _lib.load()
     H = y.shape[1]
