@@ -520,8 +520,9 @@ def test_mlp_bf16_resident_step_matches_the_bf16_oracle(use_bn, M, shape):
     assert torch.equal(grads2[net.output_layer.weight], grads[net.output_layer.weight])
 
 
-def test_mlp_trainer_steps_the_weights_in_the_gradient_gemm(monkeypatch):
-    """MLPTrainer.step on the bf16-resident path: with momentum-free torch.optim.SGD the hidden layers' weights are
+@pytest.mark.parametrize("amp", [True, False])
+def test_mlp_trainer_steps_the_weights_in_the_gradient_gemm(amp, monkeypatch):
+    """MLPTrainer.step (bf16-resident path / fp32 path): with momentum-free torch.optim.SGD the hidden layers' weights are
     stepped by their weight-gradient GEMMs (no .grad, the optimiser skips them) and end where the torch optimiser puts
     them (TRS_MLP_FUSED_DENSE=0: same kernels, dW materialised, torch's foreach step); with momentum, or another
     optimiser, the fold is off."""
@@ -538,11 +539,12 @@ def test_mlp_trainer_steps_the_weights_in_the_gradient_gemm(monkeypatch):
         seed(11)
         with contextlib.redirect_stdout(io.StringIO()):
             model = TorchRecSys.from_tensors(users, items, n_users=n_u, n_items=n_i, n_factors=D, net_type="mlp",
-                                             hidden_layers=[256, 128], use_amp=True, dynamic_neg_sampling=True,
+                                             hidden_layers=[256, 128], use_amp=amp, dynamic_neg_sampling=True,
                                              rng="reference")
         net = model.net
         net.train()
         dev = net.user.weight.device
+        assert net.compute._resident(2 * B, True) == amp
         def groups():  # (fresh dicts: an optimiser writes its defaults into the ones it is given)
             return [{"params": [p for n_, p in net.named_parameters() if not n_.startswith("fcs.0")]},
                     {"params": list(net.fcs[0].parameters()), "lr": 0.02}]

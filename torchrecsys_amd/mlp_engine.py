@@ -217,9 +217,9 @@ class MLPCompute:
         parameters of layer i): the data-parallel trainer starts that group's all-reduce while the layers below are
         still being differentiated.  Returns (grads dict keyed by parameter, d x0).
         sgd_lr (list, one learning rate per hidden Linear layer, or None): plain SGD folded into the weight-gradient
-        GEMM on the bf16-resident path — W_l = W_l - lr_l * dW_l written by the GEMM's reduce, dW_l never stored and W_l
-        absent from `grads` (single process only: nothing to all-reduce; the input-gradient GEMM reads the W^T image
-        taken in the forward pass, not the master weights).
+        GEMM — W_l = W_l - lr_l * dW_l written by the GEMM's reduce, dW_l never stored and W_l absent from `grads` (single
+        process only: nothing to all-reduce; on the bf16-resident path the input-gradient GEMM reads the W^T image taken in
+        the forward pass, on the fp32 path it runs before the weight-gradient GEMM).
         g_antisymmetric: the caller guarantees g[B + t] == -g[t] (the pairwise losses: hinge, BPR) — the output layer's bias
         gradient sum(g) is then the exact +0.0 the two per-pass sums cancel to, and is written as such."""
         net = self.net
@@ -302,7 +302,8 @@ class MLPCompute:
                                   out_bf16=(l > 0 and ctx["y"][l - 1].dtype == torch.bfloat16)
                                   or (l == 0 and self.dx0_bf16))
             else:
-                self._gemm(True, False, dy, ctx["x"][l], out=slot(fc.weight), bf16=net.use_bf16)  # dW = dy^T x (split-K)
+                if sgd_lr is None:
+                    self._gemm(True, False, dy, ctx["x"][l], out=slot(fc.weight), bf16=net.use_bf16)  # dW = dy^T x (split-K)
                 if on_group_done:
                     on_group_done(l)  # before the input-gradient GEMM: the collective overlaps it and the layers below
                 # dx = dy W.  Tile-aligned fp32 shapes go NT through a transposed copy of W (tiny: the weights) so that the
@@ -313,6 +314,9 @@ class MLPCompute:
                     dx = self._gemm(False, True, dy, fc.weight.data.t().contiguous())
                 else:
                     dx = self._gemm(False, False, dy, fc.weight.data, bf16=net.use_bf16)
+                if sgd_lr is not None:  # the weight step AFTER the input gradient read the pre-step weights
+                    self._gemm(True, False, dy, ctx["x"][l], out=fc.weight.data, alpha=-float(sgd_lr[l]), beta=1.0,
+                               bf16=net.use_bf16)
         return grads, dx
 
 
