@@ -85,8 +85,10 @@ typedef struct trs_batch {
 const char* trs_last_error(void);
 /* ABI version of this header; bump on ANY signature or struct-layout change.  The ctypes binding refuses a library
  * whose trs_abi_version() differs (torchrecsys_amd/_lib.py::load), tests/test_abi.py checks the three copies agree.
- *   1: round 1.   2: trs_train_steps_sgd takes a trs_train_args struct; trs_epoch_presort writes item-duplicate flags. */
-#define TRS_ABI_VERSION 2
+ *   1: round 1.   2: trs_train_steps_sgd takes a trs_train_args struct; trs_epoch_presort writes item-duplicate flags.
+ *   3: trs_bn_relu_forward (running statistics, batch counter, output-layer dot) and trs_bn_relu_backward (outer-product
+ *      form, outer_xw) grew arguments; trs_hinge_auc_backward, trs_f32_to_bf16_multi, trs_mlp_embed_sgd_update added. */
+#define TRS_ABI_VERSION 3
 int trs_abi_version(void);
 /* 0 if the current HIP device is gfx950, TRS_E_DEVICE otherwise. */
 int trs_check_device(void);

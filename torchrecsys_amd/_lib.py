@@ -11,7 +11,7 @@ TRS_MAX_META = 8
 TRS_NET_LINEAR = 0
 TRS_NET_FM = 1
 LOSS_ID = {"hinge": 0, "bpr": 1}  # TRS_LOSS_HINGE / TRS_LOSS_BPR
-ABI_VERSION = 2  # == TRS_ABI_VERSION of include/trs.h (tests/test_abi.py)
+ABI_VERSION = 3  # == TRS_ABI_VERSION of include/trs.h (tests/test_abi.py)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtrs_hip.so")
