@@ -674,6 +674,29 @@ def test_mlp_embed_sgd_update_refuses_what_it_cannot_do():
     assert not ops.mlp_embed_sgd_supported(T2)      # D % 4 != 0
 
 
+@pytest.mark.parametrize("B", [300, 128 * 16 * 12 - 5, 128 * 16 * 30, 128 * 16 * 40 + 77])
+def test_bn_statistics_finalise_kernels_agree(B, monkeypatch):
+    """The finalise of the BatchNorm batch statistics: the kernel that keeps a thread's chunk partials in registers (up to
+    8 / 16 / 32 chunks per thread) and the two-sweep kernel (longer chunk lists; forced by TRS_BN_FINAL_TWO_SWEEPS=1) add
+    in the same order — bit-identical mean / variance / running statistics."""
+    ops = _ops()
+    rs = np.random.RandomState(B % 1000)
+    H, passes = 40, 2
+    y = torch.from_numpy((rs.normal(0, 1, (passes * B, H)) * rs.uniform(0.1, 3, H) + rs.normal(0, 5, H)).astype(np.float32)).to(DEV)
+    res = []
+    for two in ("0", "1"):
+        monkeypatch.setenv("TRS_BN_FINAL_TWO_SWEEPS", two)
+        mean, var = torch.empty((passes, H), device=DEV), torch.empty((passes, H), device=DEV)
+        rm, rv = torch.zeros(H, device=DEV), torch.ones(H, device=DEV)
+        ops.bn_batch_stats(y, B, passes, 0.1, mean, var, rm, rv)
+        res.append((mean, var, rm, rv))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    y64 = y.double().reshape(passes, B, H)
+    assert rel_err(res[0][0].cpu().numpy(), y64.mean(1).cpu().numpy()) < 1e-6
+    assert rel_err(res[0][1].cpu().numpy(), y64.var(1, unbiased=False).cpu().numpy()) < 1e-6
+
+
 @pytest.mark.parametrize("B,H", [(64, 32), (1000, 130), (5000, 7), (256, 512), (300, 256), (97, 128)])
 @pytest.mark.parametrize("passes", [1, 2])
 def test_bn_stats_forward_backward(B, H, passes):

@@ -214,6 +214,89 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_stats_final_kernel(const float* 
   }
 }
 
+// The same finalise when a thread's share of the chunk list fits in registers (FIN_KEEP = 8 / 16 / 32 chunks per thread —
+// c3: 32, c5: 16): every (mean, M2) partial is loaded ONCE, all loads issued before the first add; the second sum runs from
+// registers.  Same order of additions as the two-sweep kernel above (bit-identical output), half the dependent round
+// trips to L2 (TRS_BN_FINAL_TWO_SWEEPS=1 forces the two-sweep kernel: tests).
+template <int FIN_KEEP>
+__global__ __launch_bounds__(TRS_BLOCK) void bn_stats_final_regs_kernel(const float* __restrict__ part,
+                                                                       int64_t rows_per_pass, int chunk_rows, int H,
+                                                                       int n_chunks, float* __restrict__ mean_out,
+                                                                       float* __restrict__ var_out) {
+  __shared__ double s_a[FIN_SEGS][FIN_COLS], s_b[FIN_SEGS][FIN_COLS];
+  __shared__ double s_mean[FIN_COLS];
+  const int cl = threadIdx.x % FIN_COLS, seg = threadIdx.x / FIN_COLS;
+  const int col = blockIdx.x * FIN_COLS + cl;
+  const int pass = blockIdx.y;
+  const float* base = part + (int64_t)pass * n_chunks * 2 * H;
+  const int cc = col < H ? col : H - 1;
+  float v[FIN_KEEP], w[FIN_KEEP];
+#pragma unroll
+  for (int k = 0; k < FIN_KEEP; ++k) {
+    const int c = seg + k * FIN_SEGS;
+    const float* o = base + (int64_t)(c < n_chunks ? c : n_chunks - 1) * 2 * H;
+    v[k] = o[cc];
+    w[k] = o[H + cc];
+  }
+  double s1 = 0.0, cnt = 0.0;
+#pragma unroll
+  for (int k = 0; k < FIN_KEEP; ++k) {
+    const int c = seg + k * FIN_SEGS;
+    const int64_t r0 = (int64_t)c * chunk_rows;
+    const double nb = (double)((r0 + chunk_rows < rows_per_pass ? r0 + chunk_rows : rows_per_pass) - r0);
+    if (c < n_chunks && col < H) {
+      s1 += nb * (double)v[k];
+      cnt += nb;
+    }
+  }
+  s_a[seg][cl] = s1; s_b[seg][cl] = cnt;
+  __syncthreads();
+  if (seg == 0) {
+    for (int q = 1; q < FIN_SEGS; ++q) { s1 += s_a[q][cl]; cnt += s_b[q][cl]; }
+    s_mean[cl] = s1 / cnt;
+  }
+  __syncthreads();
+  const double mean = s_mean[cl];
+  const double n = (double)rows_per_pass;
+  double m2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < FIN_KEEP; ++k) {
+    const int c = seg + k * FIN_SEGS;
+    const int64_t r0 = (int64_t)c * chunk_rows;
+    const double nb = (double)((r0 + chunk_rows < rows_per_pass ? r0 + chunk_rows : rows_per_pass) - r0);
+    const double d = (double)v[k] - mean;
+    if (c < n_chunks && col < H) m2 += (double)w[k] + nb * d * d;
+  }
+  __syncthreads();
+  s_a[seg][cl] = m2;
+  __syncthreads();
+  if (seg == 0 && col < H) {
+    for (int q = 1; q < FIN_SEGS; ++q) m2 += s_a[q][cl];
+    const float mu = (float)mean, var = (float)(m2 / n);
+    mean_out[pass * H + col] = mu;
+    var_out[pass * H + col] = var;
+  }
+}
+
+// finalise launcher: the register kernel when a thread's chunks fit, the two-sweep kernel otherwise
+static void launch_bn_stats_final(const float* part, int64_t rows_per_pass, int chunk_rows, int H, int nc, int passes,
+                                  float* mean_out, float* var_out, hipStream_t s) {
+  const dim3 gr((H + FIN_COLS - 1) / FIN_COLS, passes), bl(TRS_BLOCK);
+  const char* e = getenv("TRS_BN_FINAL_TWO_SWEEPS");
+  const int per_thread = (nc + FIN_SEGS - 1) / FIN_SEGS;
+  if (e && atoi(e) != 0) {
+    hipLaunchKernelGGL(bn_stats_final_kernel, gr, bl, 0, s, part, rows_per_pass, chunk_rows, H, nc, mean_out, var_out);
+  } else if (per_thread <= 8) {
+    hipLaunchKernelGGL(bn_stats_final_regs_kernel<8>, gr, bl, 0, s, part, rows_per_pass, chunk_rows, H, nc, mean_out, var_out);
+  } else if (per_thread <= 16) {
+    hipLaunchKernelGGL(bn_stats_final_regs_kernel<16>, gr, bl, 0, s, part, rows_per_pass, chunk_rows, H, nc, mean_out, var_out);
+  } else if (per_thread <= 32) {
+    hipLaunchKernelGGL(bn_stats_final_regs_kernel<32>, gr, bl, 0, s, part, rows_per_pass, chunk_rows, H, nc, mean_out, var_out);
+  } else {
+    hipLaunchKernelGGL(bn_stats_final_kernel, gr, bl, 0, s, part, rows_per_pass, chunk_rows, H, nc, mean_out, var_out);
+  }
+}
+
 // running statistics: one momentum update per pass, in pass order (the reference's two net.forward calls, mlp.py:88-115)
 __global__ void bn_running_update_kernel(const float* __restrict__ mean, const float* __restrict__ var,
                                          int64_t rows_per_pass, int H, int passes, float momentum,
@@ -1099,8 +1182,7 @@ extern "C" int trs_bn_batch_stats(const float* y_dev, int64_t rows_per_pass, int
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(gx, nc, passes), dim3(TRS_BLOCK), 0, s, y_dev, rows_per_pass, H, ld,
                      nc, workspace_dev);
   TRS_CHECK_LAUNCH("bn_stats_partial_kernel");
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((H + FIN_COLS - 1) / FIN_COLS, passes), dim3(TRS_BLOCK), 0, s,
-                     workspace_dev, rows_per_pass, CHUNK_ROWS, H, nc, mean_out_dev, var_out_dev);
+  launch_bn_stats_final(workspace_dev, rows_per_pass, CHUNK_ROWS, H, nc, passes, mean_out_dev, var_out_dev, s);
   TRS_CHECK_LAUNCH("bn_stats_final_kernel");
   if (running_mean_dev) {
     hipLaunchKernelGGL(bn_running_update_kernel, dim3((H + TRS_BLOCK - 1) / TRS_BLOCK), dim3(TRS_BLOCK), 0, s,
@@ -1121,8 +1203,7 @@ extern "C" int trs_bn_stats_finalize(const float* part_dev, int64_t rows_per_pas
               "trs_bn_stats_finalize: a chunk must not straddle the two passes (rows_per_pass %% chunk_rows != 0)");
   TRS_REQUIRE((running_mean_dev == nullptr) == (running_var_dev == nullptr), "trs_bn_stats_finalize: running stats");
   const int nc = (int)((rows_per_pass + chunk_rows - 1) / chunk_rows);
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((H + FIN_COLS - 1) / FIN_COLS, passes), dim3(TRS_BLOCK), 0,
-                     (hipStream_t)stream, part_dev, rows_per_pass, chunk_rows, H, nc, mean_out_dev, var_out_dev);
+  launch_bn_stats_final(part_dev, rows_per_pass, chunk_rows, H, nc, passes, mean_out_dev, var_out_dev, (hipStream_t)stream);
   TRS_CHECK_LAUNCH("bn_stats_final_kernel");
   if (running_mean_dev) {
     hipLaunchKernelGGL(bn_running_update_kernel, dim3((H + TRS_BLOCK - 1) / TRS_BLOCK), dim3(TRS_BLOCK), 0,
