@@ -683,13 +683,22 @@ def test_bn_statistics_finalise_kernels_agree(B, monkeypatch):
     rs = np.random.RandomState(B % 1000)
     H, passes = 40, 2
     y = torch.from_numpy((rs.normal(0, 1, (passes * B, H)) * rs.uniform(0.1, 3, H) + rs.normal(0, 5, H)).astype(np.float32)).to(DEV)
+    dx = torch.from_numpy(rs.normal(0, 1, (passes * B, H)).astype(np.float32)).to(DEV)
+    gam = torch.from_numpy(rs.uniform(0.5, 1.5, H).astype(np.float32)).to(DEV)
+    bet = torch.from_numpy(rs.normal(0, 0.5, H).astype(np.float32)).to(DEV)
+    rw = torch.from_numpy(rs.normal(0, 1, passes * B).astype(np.float32)).to(DEV)
     res = []
     for two in ("0", "1"):
         monkeypatch.setenv("TRS_BN_FINAL_TWO_SWEEPS", two)
         mean, var = torch.empty((passes, H), device=DEV), torch.empty((passes, H), device=DEV)
         rm, rv = torch.zeros(H, device=DEV), torch.ones(H, device=DEV)
         ops.bn_batch_stats(y, B, passes, 0.1, mean, var, rm, rv)
-        res.append((mean, var, rm, rv))
+        # ... and the finalise kernels of the backward sums / column sums (both passes' partials in registers)
+        dy, dg, db, dbias = torch.empty_like(y), torch.empty(H, device=DEV), torch.empty(H, device=DEV), torch.empty(H, device=DEV)
+        ops.bn_relu_backward(y, dx, B, passes, True, mean, var, gam, bet, 1e-5, dy, dg, db, dy_colsum=dbias)
+        cs = torch.empty(H, device=DEV)
+        ops.colsum(y, cs, row_weight=rw, passes=passes)
+        res.append((mean, var, rm, rv, dy, dg, db, dbias, cs))
     for a, b in zip(*res):
         assert torch.equal(a, b)
     y64 = y.double().reshape(passes, B, H)

@@ -483,6 +483,67 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_final_kernel(const float* __
   }
 }
 
+// The same with both passes' partials of a thread loaded at once into registers (KEEP chunks per thread and pass: c5 16,
+// c3 32): one round of loads instead of one per pass and 8-chunk turn; same order of additions (bit-identical).
+template <int KEEP>
+__global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_final_regs_kernel(const float* __restrict__ part, int H, int n_chunks,
+                                                                     int passes, float* __restrict__ sums,
+                                                                     float* __restrict__ dgamma,
+                                                                     float* __restrict__ dbeta) {
+  __shared__ double s_1[2][FIN_SEGS][FIN_COLS], s_2[2][FIN_SEGS][FIN_COLS];
+  const int cl = threadIdx.x % FIN_COLS, seg = threadIdx.x / FIN_COLS;
+  const int col = blockIdx.x * FIN_COLS + cl;
+  const int cc = col < H ? col : H - 1;
+  float v[2][KEEP], w[2][KEEP];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int k = 0; k < KEEP; ++k) {
+      const int c = seg + k * FIN_SEGS;
+      const float* o = part + (((int64_t)(p < passes ? p : passes - 1) * n_chunks + (c < n_chunks ? c : n_chunks - 1)) * 2) * H;
+      v[p][k] = o[cc];
+      w[p][k] = o[H + cc];
+    }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < KEEP; ++k)
+      if (seg + k * FIN_SEGS < n_chunks && col < H) {
+        s1 += v[p][k];
+        s2 += w[p][k];
+      }
+    s_1[p][seg][cl] = s1; s_2[p][seg][cl] = s2;
+  }
+  __syncthreads();
+  if (seg == 0 && col < H) {
+    double g = 0.0, b = 0.0;
+    for (int p = 0; p < passes; ++p) {
+      double s1 = s_1[p][0][cl], s2 = s_2[p][0][cl];
+      for (int q = 1; q < FIN_SEGS; ++q) { s1 += s_1[p][q][cl]; s2 += s_2[p][q][cl]; }
+      sums[(p * 2 + 0) * H + col] = (float)s1;
+      sums[(p * 2 + 1) * H + col] = (float)s2;
+      b += s1;
+      g += s2;
+    }
+    if (dgamma) dgamma[col] = (float)g;
+    if (dbeta) dbeta[col] = (float)b;
+  }
+}
+
+static void launch_bn_bwd_final(const float* part, int H, int nc, int passes, float* sums, float* dgamma, float* dbeta,
+                                hipStream_t s) {
+  const dim3 gr((H + FIN_COLS - 1) / FIN_COLS), bl(TRS_BLOCK);
+  const char* e = getenv("TRS_BN_FINAL_TWO_SWEEPS");
+  const int per_thread = (nc + FIN_SEGS - 1) / FIN_SEGS;
+  if ((e && atoi(e) != 0) || passes > 2 || per_thread > 32)
+    hipLaunchKernelGGL(bn_bwd_final_kernel, gr, bl, 0, s, part, H, nc, passes, sums, dgamma, dbeta);
+  else if (per_thread <= 16)
+    hipLaunchKernelGGL(bn_bwd_final_regs_kernel<16>, gr, bl, 0, s, part, H, nc, passes, sums, dgamma, dbeta);
+  else
+    hipLaunchKernelGGL(bn_bwd_final_regs_kernel<32>, gr, bl, 0, s, part, H, nc, passes, sums, dgamma, dbeta);
+}
+
 __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_apply_kernel(const BnBwdArgs a) {
   const int64_t rows = a.rows_per_pass * a.passes;
   const int64_t total = rows * a.H;
@@ -563,6 +624,54 @@ __global__ __launch_bounds__(TRS_BLOCK) void colsum_final_kernel(const float* __
     __syncthreads();
   }
   if (seg == 0 && col < H) out[col] = (float)tot;
+}
+
+template <int KEEP>
+__global__ __launch_bounds__(TRS_BLOCK) void colsum_final_regs_kernel(const float* __restrict__ part, int H, int n_chunks,
+                                                                     int passes, float* __restrict__ out) {
+  // both passes' partials of a thread in registers, one round of loads; additions in colsum_final_kernel's order
+  __shared__ double s_s[2][FIN_SEGS][FIN_COLS];
+  const int cl = threadIdx.x % FIN_COLS, seg = threadIdx.x / FIN_COLS;
+  const int col = blockIdx.x * FIN_COLS + cl;
+  const int cc = col < H ? col : H - 1;
+  float v[2][KEEP];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int k = 0; k < KEEP; ++k) {
+      const int c = seg + k * FIN_SEGS;
+      v[p][k] = part[((int64_t)(p < passes ? p : passes - 1) * n_chunks + (c < n_chunks ? c : n_chunks - 1)) * H + cc];
+    }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    double sm = 0.0;
+#pragma unroll
+    for (int k = 0; k < KEEP; ++k)
+      if (seg + k * FIN_SEGS < n_chunks && col < H) sm += v[p][k];
+    s_s[p][seg][cl] = sm;
+  }
+  __syncthreads();
+  if (seg == 0 && col < H) {
+    double tot = 0.0;
+    for (int p = 0; p < passes; ++p) {
+      double sm = s_s[p][0][cl];
+      for (int q = 1; q < FIN_SEGS; ++q) sm += s_s[p][q][cl];
+      tot += sm;
+    }
+    out[col] = (float)tot;
+  }
+}
+
+static void launch_colsum_final(const float* part, int H, int nc, int passes, float* out, hipStream_t s) {
+  const dim3 gr((H + FIN_COLS - 1) / FIN_COLS), bl(TRS_BLOCK);
+  const char* e = getenv("TRS_BN_FINAL_TWO_SWEEPS");
+  const int per_thread = (nc + FIN_SEGS - 1) / FIN_SEGS;
+  if ((e && atoi(e) != 0) || passes > 2 || per_thread > 32)
+    hipLaunchKernelGGL(colsum_final_kernel, gr, bl, 0, s, part, H, nc, passes, out);
+  else if (per_thread <= 16)
+    hipLaunchKernelGGL(colsum_final_regs_kernel<16>, gr, bl, 0, s, part, H, nc, passes, out);
+  else
+    hipLaunchKernelGGL(colsum_final_regs_kernel<32>, gr, bl, 0, s, part, H, nc, passes, out);
 }
 
 // ------------------------------------------------------------------------------------------- output layer H -> 1
@@ -1328,12 +1437,10 @@ extern "C" int trs_bn_relu_backward(const void* y_dev, int32_t y_bf16, const voi
       hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(gx, nc, passes), dim3(TRS_BLOCK), 0, s, a);
     }
     TRS_CHECK_LAUNCH("bn_bwd_reduce_kernel");
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((H + FIN_COLS - 1) / FIN_COLS), dim3(TRS_BLOCK), 0, s, workspace_dev, H, nc, passes, sums,
-                       dgamma_dev, dbeta_dev);
+    launch_bn_bwd_final(workspace_dev, H, nc, passes, sums, dgamma_dev, dbeta_dev, s);
     TRS_CHECK_LAUNCH("bn_bwd_final_kernel");
     if (outer_xw_dev) {
-      hipLaunchKernelGGL(colsum_final_kernel, dim3((H + FIN_COLS - 1) / FIN_COLS), dim3(TRS_BLOCK), 0, s, xw_part, H, nc,
-                         passes, outer_xw_dev);
+      launch_colsum_final(xw_part, H, nc, passes, outer_xw_dev, s);
       TRS_CHECK_LAUNCH("colsum_final_kernel");
     }
   }
@@ -1353,8 +1460,7 @@ extern "C" int trs_bn_relu_backward(const void* y_dev, int32_t y_bf16, const voi
   }
 #undef TRS_BWD
   if (dy_colsum_dev) {
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((H + FIN_COLS - 1) / FIN_COLS), dim3(TRS_BLOCK), 0, s, cs_part, H, nc,
-                       passes, dy_colsum_dev);
+    launch_colsum_final(cs_part, H, nc, passes, dy_colsum_dev, s);
     TRS_CHECK_LAUNCH("colsum_final_kernel");
   }
   return TRS_OK;
@@ -1380,7 +1486,7 @@ extern "C" int trs_colsum(const float* x_dev, int64_t rows_per_pass, int32_t pas
                        row_weight_dev, nc, workspace_dev);
   }
   TRS_CHECK_LAUNCH("colsum_partial_kernel");
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((H + FIN_COLS - 1) / FIN_COLS), dim3(TRS_BLOCK), 0, s, workspace_dev, H, nc, passes, out_dev);
+  launch_colsum_final(workspace_dev, H, nc, passes, out_dev, s);
   TRS_CHECK_LAUNCH("colsum_final_kernel");
   return TRS_OK;
 }
