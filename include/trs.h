@@ -87,8 +87,9 @@ const char* trs_last_error(void);
  * whose trs_abi_version() differs (torchrecsys_amd/_lib.py::load), tests/test_abi.py checks the three copies agree.
  *   1: round 1.   2: trs_train_steps_sgd takes a trs_train_args struct; trs_epoch_presort writes item-duplicate flags.
  *   3: trs_bn_relu_forward (running statistics, batch counter, output-layer dot) and trs_bn_relu_backward (outer-product
- *      form, outer_xw) grew arguments; trs_hinge_auc_backward, trs_f32_to_bf16_multi, trs_mlp_embed_sgd_update added. */
-#define TRS_ABI_VERSION 3
+ *      form, outer_xw) grew arguments; trs_hinge_auc_backward, trs_f32_to_bf16_multi, trs_mlp_embed_sgd_update added.
+ *   4: trs_sampler.seen_users (bounds of the seen CSR). */
+#define TRS_ABI_VERSION 4
 int trs_abi_version(void);
 /* 0 if the current HIP device is gfx950, TRS_E_DEVICE otherwise. */
 int trs_check_device(void);
@@ -120,6 +121,7 @@ typedef struct trs_sampler {
   const int32_t* seen_items;
   const int32_t* pop_items;
   int64_t pop_n;
+  int64_t seen_users; /* rows of the seen CSR = n_users; a user id outside [0, seen_users) has seen nothing */
 } trs_sampler;
 
 /* Counter-based dynamic negative sampler: neg[t] uniform over {0..n_items-1} \ {pos[t]} — the distribution of the

@@ -20,8 +20,10 @@ def mm(a, b):
     return (a.to(WIDE) @ b.to(WIDE)).float()
 
 
-def train_step_bf16(P, ids, y_bf16=True, wide=torch.float64, dx0_bf16=False):
+def train_step_bf16(P, ids, y_bf16=True, wide=torch.float64, dx0_bf16=False, score_grad=None):
     """wide: accumulation dtype of the reductions (float64 = the judge; float32 = the calibration run).
+    score_grad: optional (g_pos, g_neg), each (B,): d loss / d score driving the backward instead of the hinge's (the
+    hinge VALUE is still returned as loss) — MLPTrainer.step(score_grad=...).
     P: dict name -> fp32 GPU tensor (state_dict layout; embedding tables may be compacted); ids: dict user/pos/neg
     [/pos_meta/neg_meta] of int64 GPU tensors.  Returns (pos, neg, loss, grads, dx0 rows per pass) — running statistics
     in P are updated in place."""
@@ -106,7 +108,8 @@ def train_step_bf16(P, ids, y_bf16=True, wide=torch.float64, dx0_bf16=False):
     B = h.shape[0]
     act = (h >= 0).float() / B
     loss = torch.clamp(h, min=0).mean()
-    gp, dxp = backward(-act, cp)
-    gn, dxn = backward(act, cn)
+    g_pos, g_neg = (-act, act) if score_grad is None else (score_grad[0].float(), score_grad[1].float())
+    gp, dxp = backward(g_pos, cp)
+    gn, dxn = backward(g_neg, cn)
     grads = {k: gp[k] + gn[k] for k in gp}  # (absbound.*: the two passes' bounds add up as well)
     return sp, sn, loss, grads, (dxp, dxn)

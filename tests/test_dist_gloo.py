@@ -68,36 +68,54 @@ def _worker(rank, world, port, ret):
         works = [bucket.allreduce_segment_async(sg) for sg in reversed(segs)]
         bucket.finish_segments(works)
         assert torch.allclose(bucket.flat, torch.full_like(bucket.flat, 1.5))
-        # --- user-partitioned replicas: every rank owns the rows r, r+world, ...; one all-gather makes the table whole
-        tab = torch.full((7, 3), -1.0)
-        tab[rank::world] = torch.arange(7.0)[rank::world, None] * 10 + rank
-        tdist.gather_owned_rows_(tab)
-        want = torch.arange(7.0)[:, None] * 10 + (torch.arange(7) % world)[:, None].float()
-        assert torch.equal(tab, want.expand(7, 3))
+        # --- user-partitioned replicas: every rank owns the rows r, r+world, ...; all-gathers make the table whole, in
+        # place and in bounded pieces (chunk_bytes = 24 -> 2 rows of 3 floats per rank and block: 7 rows = 2 blocks, the
+        # second one ragged; 12 -> 1 row per block; default: one block)
+        for nrows, chunk in ((7, 24), (7, 12), (7, 64 << 20), (8, 24), (1, 24), (0, 24)):
+            tab = torch.full((nrows, 3), -1.0)
+            tab[rank::world] = torch.arange(float(nrows))[rank::world, None] * 10 + rank
+            tdist.gather_owned_rows_(tab, chunk_bytes=chunk)
+            want = torch.arange(float(nrows))[:, None] * 10 + (torch.arange(nrows) % world)[:, None].float()
+            assert torch.equal(tab, want.expand(nrows, 3)), (nrows, chunk)
+        vec = torch.full((9,), -1.0)  # 1-wide tables stored as vectors work too
+        vec[rank::world] = float(rank)
+        tdist.gather_owned_rows_(vec, chunk_bytes=8)
+        assert torch.equal(vec, (torch.arange(9) % world).float())
         assert tdist.allreduce_min_int(10 + rank, torch.device("cpu")) == 10
-        # --- the model's per-rank view of a split: cut by user (default) or in contiguous blocks, always truncated to
-        # the shortest rank's length; a caller's own shards (pre_sharded) are only truncated
+        # --- the model's per-rank view of a split: cut by user (default) or in contiguous blocks; NO row is dropped
+        # (Linear / FM steps hold no collective; the MLP's lock-step is FitRunner's MIN over the ranks' step counts)
         from torchrecsys_amd.model import TorchRecSys
         data = {"user_id": torch.tensor([0, 1, 2, 3, 4, 5, 6, 8, 10, 12]), "pos_item_id": torch.arange(10)}
         m = TorchRecSys.__new__(TorchRecSys)
         m._dev_cache = {}
         m.dp_partition = "user"
-        mine = m._rank_rows(data)  # even users: 0 2 4 6 8 10 12 (7 rows), odd users: 1 3 5 (3 rows) -> 3 rows each
-        assert ((mine["user_id"] % world) == rank).all() and mine["user_id"].numel() == 3
-        assert torch.equal(mine["pos_item_id"], torch.arange(10)[(data["user_id"] % world) == rank][:3])
-        assert m._rank_rows(data) is mine  # cached: the MIN all-reduce runs once per split
+        mine = m._rank_rows(data)  # even users: 0 2 4 6 8 10 12 (7 rows), odd users: 1 3 5 (3 rows)
+        assert ((mine["user_id"] % world) == rank).all() and mine["user_id"].numel() == (7, 3)[rank]
+        assert torch.equal(mine["pos_item_id"], torch.arange(10)[(data["user_id"] % world) == rank])
+        assert m._rank_rows(data) is mine  # cached per split
         m2 = TorchRecSys.__new__(TorchRecSys)
         m2._dev_cache = {}
         m2.dp_partition = "contiguous"
         data11 = {"user_id": torch.arange(11), "pos_item_id": torch.arange(11)}
         assert torch.equal(m2._rank_rows(data11)["user_id"], torch.arange(11)[rank * 5:rank * 5 + 5])
         assert tdist.equal_shard_bounds(11, rank, world) == (rank * 5, rank * 5 + 5)  # same length on every rank
+        # a caller's own shards (pre_sharded): kept whole, of any length — but under dp_partition 'user' they must BE
+        # the cut by user_id % world (fit() never averages user tables then and gathers rows r::world from rank r);
+        # any other cut raises on EVERY rank (the verdict is all-reduced), 'contiguous' accepts it
         m3 = TorchRecSys.__new__(TorchRecSys)
         m3._dev_cache = {}
         m3.dp_partition = "user"
-        m3.pre_sharded = True  # unequal shards handed in by the caller: every rank keeps the common 7 rows
-        own = {"user_id": torch.arange(10 - 3 * rank), "pos_item_id": torch.arange(10 - 3 * rank)}
-        assert m3._rank_rows(own)["user_id"].numel() == 7
+        m3.pre_sharded = True
+        own = {"user_id": torch.arange(10 - 3 * rank) * world + rank, "pos_item_id": torch.arange(10 - 3 * rank)}
+        assert m3._rank_rows(own)["user_id"].numel() == 10 - 3 * rank
+        bad = {"user_id": torch.arange(6) if rank == 1 else torch.arange(6) * world, "pos_item_id": torch.arange(6)}
+        with pytest.raises(ValueError, match="user_id % world == rank"):  # rank 0's shard is fine: it raises too
+            m3._rank_rows(bad)
+        m4 = TorchRecSys.__new__(TorchRecSys)
+        m4._dev_cache = {}
+        m4.dp_partition = "contiguous"
+        m4.pre_sharded = True
+        assert m4._rank_rows(bad)["user_id"].numel() == 6
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()

@@ -58,15 +58,21 @@ def _worker(rank, world, port, net_type, n, ret, partition="user"):
         losses = [float(x.split(":")[-1]) for x in buf.getvalue().splitlines() if "Training Loss" in x]
         assert len(losses) == 2 and losses[1] < losses[0] + 1e-3
         n_train = n - int(np.ceil(0.2 * n))
-        mine = model.make_runner(opt, 256).n_train  # equally long shards: same step count on every rank
-        both = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
-        dist.all_gather(both, torch.tensor([mine]))
-        assert int(both[0]) == int(both[1]) and 0.4 * n_train <= mine <= n_train // world + (partition == "user") * 200
-        if partition == "user":  # the rank trains only its own users, and those rows really moved
+        r = model.make_runner(opt, 256)
+        both = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(both, torch.tensor([r.n_train, r.num_batches, r.own_batches]))
+        # no row is dropped by the cut itself (contiguous blocks: the n % world last rows); the MLP, whose steps hold a
+        # collective, runs the common (minimum) number of steps per epoch, Linear / FM every rank its own
+        assert int(both[0][0]) + int(both[1][0]) == (n_train if partition == "user" else 2 * (n_train // world))
+        if net_type == "mlp":
+            assert int(both[0][1]) == int(both[1][1]) == min(int(both[0][2]), int(both[1][2]))
+        else:
+            assert r.num_batches == r.own_batches
+        if partition == "user":  # the rank trains only its own users
             users = model._rank_rows(model.data_processor.train_data)["user_id"]
             assert bool(((users % world) == rank).all())
         else:
-            assert mine == n_train // world
+            assert r.n_train == n_train // world
         ret[rank] = losses
     finally:
         dist.destroy_process_group()

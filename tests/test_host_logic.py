@@ -142,6 +142,35 @@ def test_tensor_ingest_matches_dataframe_ingest():
         assert torch.equal(a.train_data[k], b.train_data[k]) and torch.equal(a.test_data[k], b.test_data[k])
 
 
+def test_tensor_ingest_remaps_arbitrary_ids():
+    """remap_ids=True (SURVEY 8f-2): arbitrary ids -> dense 0..n-1 by rank, original ids kept in user_index / item_index;
+    without it a non-dense id raises at ingest like the reference's first embedding lookup would (dataset.py:30-31,
+    268-269)."""
+    df = dummy_df()
+    u, i = torch.from_numpy(df["user_id"].values), torch.from_numpy(df["item_id"].values)
+    with pytest.raises(IndexError, match="remap_ids"):
+        TensorProcessData(u * 3 + 1, i, n_users=N_USERS, n_items=N_ITEMS)
+    np.random.seed(1)
+    a = TensorProcessData(u, i, split_ratio=0.8)
+    a.prepare_data()
+    np.random.seed(1)
+    b = TensorProcessData(u * 3 + 1, i * 1000 + 7, split_ratio=0.8, remap_ids=True)
+    b.prepare_data()
+    assert b.config == a.config
+    assert torch.equal(b.user_index, torch.arange(N_USERS) * 3 + 1)
+    assert torch.equal(b.item_index, torch.arange(N_ITEMS) * 1000 + 7)
+    for k in ("user_id", "pos_item_id", "neg_item_id"):
+        assert torch.equal(a.train_data[k], b.train_data[k]) and torch.equal(a.test_data[k], b.test_data[k])
+    # the original ids come back through the index
+    assert torch.equal(b.user_index[b.train_data["user_id"]], a.train_data["user_id"] * 3 + 1)
+    # ids missing from the stream leave no hole: 3 distinct users -> 3 rows
+    c = TensorProcessData(torch.tensor([10, 500, 10, 7]), torch.tensor([2, 2, 9, 9]), split_ratio=1.0, remap_ids=True,
+                          dynamic_neg_sampling=True)
+    c.prepare_data()
+    assert c.config["num_users"] == 3 and c.config["num_items"] == 2
+    assert c.train_data["user_id"].tolist() == [1, 2, 1, 0] and c.train_data["pos_item_id"].tolist() == [0, 0, 1, 1]
+
+
 def test_optimizer_dispatch():
     from torchrecsys_amd.engine import classify_optimizer
     ps = [torch.nn.Parameter(torch.zeros(4, 2)), torch.nn.Parameter(torch.zeros(3, 2))]

@@ -11,7 +11,7 @@ TRS_MAX_META = 8
 TRS_NET_LINEAR = 0
 TRS_NET_FM = 1
 LOSS_ID = {"hinge": 0, "bpr": 1}  # TRS_LOSS_HINGE / TRS_LOSS_BPR
-ABI_VERSION = 3  # == TRS_ABI_VERSION of include/trs.h (tests/test_abi.py)
+ABI_VERSION = 4  # == TRS_ABI_VERSION of include/trs.h (tests/test_abi.py)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtrs_hip.so")
@@ -81,7 +81,8 @@ class TrsMetaStage(C.Structure):
 class TrsSampler(C.Structure):
     """struct trs_sampler (include/trs.h): sampler options beyond the reference's."""
     _fields_ = [("k_neg", C.c_int32), ("popularity", C.c_int32), ("max_tries", C.c_int32), ("reserved", C.c_int32),
-                ("seen_off", C.c_void_p), ("seen_items", C.c_void_p), ("pop_items", C.c_void_p), ("pop_n", C.c_int64)]
+                ("seen_off", C.c_void_p), ("seen_items", C.c_void_p), ("pop_items", C.c_void_p), ("pop_n", C.c_int64),
+                ("seen_users", C.c_int64)]
 
 
 class TrsTrainArgs(C.Structure):

@@ -1,5 +1,5 @@
 // loader.hip — device side of FastDataLoader (reference dataset/dataset.py:319-458): epoch shuffle, batch slice,
-// dynamic negative sampler.  Integer work: results are bit-exact against oracle/philox.py.
+// dynamic negative sampler.  Integer work: results are bit-exact against oracle/loader.py.
 #include "trs_common.h"
 
 namespace {

@@ -53,7 +53,7 @@ __device__ __forceinline__ void trs_st_idx(void* p, int idx_bytes, int64_t t, in
 }
 
 // ------------------------------------------------------------------------------------------ Philox4x32-10
-// Counter-based generator (Salmon et al., SC'11).  Restated bit-for-bit in oracle/philox.py.
+// Counter-based generator (Salmon et al., SC'11).  Restated bit-for-bit in oracle/loader.py.
 struct trs_u4 {
   uint32_t x, y, z, w;
 };
@@ -117,9 +117,10 @@ struct TrsSampler {  // trs_sampler by value, for kernel arguments
   const int32_t* seen_items;
   const int32_t* pop_items;
   int64_t pop_n;
+  int64_t seen_users;  // rows of the seen CSR (seen_off has seen_users + 1 entries)
 };
 static inline TrsSampler trs_sampler_args(const trs_sampler* s) {
-  TrsSampler r = {1, 0, 0, nullptr, nullptr, nullptr, 0};
+  TrsSampler r = {1, 0, 0, nullptr, nullptr, nullptr, 0, 0};
   if (s) {
     r.k_neg = s->k_neg < 1 ? 1 : s->k_neg;
     r.popularity = s->popularity;
@@ -128,10 +129,13 @@ static inline TrsSampler trs_sampler_args(const trs_sampler* s) {
     r.seen_items = s->seen_items;
     r.pop_items = s->pop_items;
     r.pop_n = s->pop_n;
+    r.seen_users = s->seen_users;
   }
   return r;
 }
 __device__ __forceinline__ bool trs_user_has_item(const TrsSampler& S, int64_t u, int64_t item) {
+  // a user id outside the CSR (reported by the scorer's id check later) has seen nothing: no read beyond seen_off
+  if ((uint64_t)u >= (uint64_t)S.seen_users) return false;
   int64_t lo = S.seen_off[u], hi = S.seen_off[u + 1];
   while (lo < hi) {  // binary search in the user's sorted positives
     const int64_t mid = (lo + hi) >> 1;
@@ -164,7 +168,7 @@ __device__ __forceinline__ int64_t trs_sample_neg_opt(uint64_t seed, uint64_t ct
 
 // ------------------------------------------------------------------------------------------ Feistel shuffle
 // Keyed bijection of [0,N): 4-round balanced Feistel network on 2*hb bits (2*hb >= ceil(log2 N)), cycle-walked back
-// into range.  Restated in oracle/philox.py::feistel_perm.
+// into range.  Restated in oracle/loader.py::feistel_perm.
 __host__ __device__ __forceinline__ uint32_t trs_mix32(uint32_t x, uint32_t k) {
   x ^= k;
   x *= 0x9E3779B1u;

@@ -127,26 +127,40 @@ def allreduce_min_int(value, device):
     return int(t.item())
 
 
-def gather_owned_rows_(table, group=None):
+def gather_owned_rows_(table, group=None, chunk_bytes=64 << 20):
     """User-partitioned data parallelism (stream sharded by user_id % world): rank r is the only writer of the rows
-    r, r + world, r + 2*world, ... of a user table; every other row of its replica is stale.  One all-gather of the
-    owned rows (1/world of the table sent per rank — half the bytes per link of an all-reduce of masked tables) makes
+    r, r + world, r + 2*world, ... of a user table; every other row of its replica is stale.  All-gathers of the
+    owned rows (1/world of the table sent per rank — half the bytes per link of an all-reduce of masked tables) make
     every replica whole again.  Called once at the end of fit(), not per epoch: nobody reads a foreign user row in
-    between."""
+    between.
+
+    In place, in bounded pieces: the table is walked in blocks of C*world consecutive rows; of each block every rank
+    sends its C owned rows (a contiguous staging copy of at most `chunk_bytes`) into ONE all_gather_into_tensor whose
+    (world, C, ...) result is written back through the block's (C, world, ...) view with a single strided copy.  Peak
+    extra memory = (world + 1) * chunk_bytes whatever the table size (c5's 10.2 GB user table: 0.6 GB at 8 ranks, where a
+    list of per-rank receive buffers was a second copy of the table)."""
     rank, world = world_info()
-    if world == 1:
-        return
     n = table.shape[0]
-    per = (n + world - 1) // world
-    mine = table[rank::world]
-    send = torch.zeros((per,) + tuple(table.shape[1:]), dtype=table.dtype, device=table.device)
-    send[:mine.shape[0]].copy_(mine)
-    recv = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(recv, send, group=group)
-    for r in range(world):
-        if r != rank:
-            dst = table[r::world]
-            dst.copy_(recv[r][:dst.shape[0]])
+    if world == 1 or n == 0:
+        return
+    tail = tuple(table.shape[1:])
+    row_bytes = max(table[0].numel() * table.element_size(), 1) if n else 1
+    C = max(1, int(chunk_bytes) // row_bytes)
+    send = torch.empty((min(C, (n + world - 1) // world),) + tail, dtype=table.dtype, device=table.device)
+    C = send.shape[0]
+    recv_flat = torch.empty((world * C,) + tail, dtype=table.dtype, device=table.device)  # rank-major (gloo wants 2-D+)
+    recv = recv_flat.view((world, C) + tail)
+    for r0 in range(0, n, C * world):  # block = rows [r0, r0 + C*world); its row r0 + c*world + k belongs to rank k
+        rows = min(C * world, n - r0)
+        full = rows // world          # whole (c, all ranks) groups of the block
+        c_mine = (rows - rank + world - 1) // world if rows > rank else 0
+        if c_mine:
+            send[:c_mine].copy_(table[r0 + rank:r0 + rows:world])
+        dist.all_gather_into_tensor(recv_flat, send, group=group)
+        if full:
+            table[r0:r0 + full * world].view((full, world) + tail).copy_(recv[:, :full].transpose(0, 1))
+        for k in range(rows - full * world):  # the ragged last group of the table: ranks 0 .. rem-1 own one row more
+            table[r0 + full * world + k].copy_(recv[k, full])
 
 
 def average_tables_(tables, group=None):

@@ -112,6 +112,9 @@ class MLPCompute:
         # use_amp on shapes the bf16-resident kernels take: layer inputs x_l live in HBM as bf16 only (what the forward
         # and weight-gradient GEMMs read), pre-BN outputs y_l stay fp32 (statistics, backward recompute)
         res = self._resident(rows, training)
+        # decided ONCE per forward and recorded in ctx: the backward must branch on what the forward did (x_L stored or
+        # not, statistics of the global batch or of the replica), not on flags that may have changed since
+        sync_fwd = bool(training and use_bn and self.sync_bn and tdist.world_info()[1] > 1)
         if res:
             self._refresh_weight_images()
             x = torch.empty((rows, net.input_shape), dtype=torch.bfloat16, device=dev)
@@ -120,7 +123,7 @@ class MLPCompute:
             x = torch.empty((rows, net.input_shape), dtype=torch.float32, device=dev)
             ops.mlp_gather_concat(net.tables(), Bt, passes, x)
         ctx = {"ids": ids, "B": B, "passes": passes, "x": [x], "y": [], "mean": [], "var": [], "training": training,
-               "resident": res, "Bt": (Bt, keep)}
+               "resident": res, "Bt": (Bt, keep), "sync": sync_fwd}
         tracked = []
         out = torch.empty(rows, dtype=torch.float32, device=dev)  # the scores
         for l in range(L):
@@ -150,7 +153,7 @@ class MLPCompute:
                     H = y.shape[1]
                     mean = torch.empty((passes, H), dtype=torch.float32, device=dev)
                     var = torch.empty((passes, H), dtype=torch.float32, device=dev)
-                    sync = self.sync_bn and tdist.world_info()[1] > 1
+                    sync = sync_fwd
                     # the running statistics' momentum update rides in the BN+ReLU launch below
                     if not sync:
                         run = {"momentum": BN_MOMENTUM, "running_mean": bn.running_mean, "running_var": bn.running_var,
@@ -178,8 +181,7 @@ class MLPCompute:
                     # ... and with BatchNorm the last activations are not stored at all: the backward's reduce kernel
                     # recomputes them for the output layer's weight gradient (outer_xw); without BatchNorm there is no
                     # reduce pass, under sync-BN it is a separate phase: those keep x_L
-                    if use_bn and ops.bn_relu_forward_forms_dot(y) and not (training and self.sync_bn
-                                                                              and tdist.world_info()[1] > 1):
+                    if use_bn and ops.bn_relu_forward_forms_dot(y) and not sync_fwd:
                         xn = None
                 ops.bn_relu_forward(y, B, passes, use_bn, stat_passes, mean, var, gamma, beta, BN_EPS, xn, **run)
             x = xn
@@ -259,7 +261,8 @@ class MLPCompute:
         if on_group_done and xw is None:  # (with xw the output layer's dW is complete after the last hidden layer's reduce)
             on_group_done(L)
         res = ctx.get("resident", False)
-        sync = self.sync_bn and tdist.world_info()[1] > 1
+        sync = ctx["sync"]  # the forward's decision (ctx), not the live flag
+        assert not (sync and xw is not None), "sync-BN keeps x_L: the output layer's dW is a column sum, not outer_xw"
         for l in reversed(range(L)):
             fc = net.fcs[l]
             y = ctx["y"][l]
@@ -376,16 +379,26 @@ class MLPTrainer:
         self.kernel_events = None
         self.loss_id = 0  # _lib.LOSS_ID: hinge (the reference) | bpr; set by fit(loss=...)
 
-    def step(self, ids, loss_slot, auc_slot=None):
+    def step(self, ids, loss_slot, auc_slot=None, score_grad=None):
+        """One training step.  score_grad (optional, (2B,) fp32: d loss / d score of the positive rows, then of the
+        negative rows) replaces the gradient of the built-in pairwise loss — a caller's own loss, and what the full-size
+        parity tests drive the backward with; the built-in loss value is still accumulated into loss_slot."""
         net, opt = self.net, self.opt
         B = ids["user"].shape[0]
         D, M = net.n_factors, net.n_meta_tables()
+        self.kind = classify_optimizer(opt, self.emb_params)  # every step: param_groups may have changed
+        if self.kind in ("sparse_adam", "adagrad") and not self.row_state:
+            self.row_state = {id(p): RowState(p) for p in self.emb_params}
         fused_lr = self._fused_embed_lr() if self.kind == "sgd" else None
         net.compute.dx0_bf16 = fused_lr is not None  # (only read on the bf16-resident path)
         scores, ctx = net.compute.forward(ids, 2, True)
         pos, neg = scores[:B], scores[B:]
         gp, gn = ops.hinge_auc_backward(pos, neg, loss_slot, auc_slot, loss=self.loss_id)
         g = gp._base  # (2B,): positive half, negative half
+        antisym = score_grad is None  # hinge / BPR: g[B + t] == -g[t]
+        if score_grad is not None:
+            assert score_grad.shape == (2 * B,) and score_grad.dtype == torch.float32 and score_grad.is_contiguous()
+            g = score_grad
         # ---- dense parameters under data parallelism: RCCL all-reduce per layer, started as the backward produces the
         # layer's gradients (it runs on the collective stream beside the remaining backward GEMMs and the embedding-row
         # updates below) and awaited right before the user's optimiser steps the dense parameters
@@ -394,7 +407,7 @@ class MLPTrainer:
         grads, dx0 = net.compute.backward(ctx, g, grad_of=self.bucket.grad_of,
                                           on_group_done=(lambda i: works.append(
                                               self.bucket.allreduce_segment_async(self.segs[i]))) if dp else None,
-                                          sgd_lr=None if dp else self._fused_weight_lrs(), g_antisymmetric=True)
+                                          sgd_lr=None if dp else self._fused_weight_lrs(), g_antisymmetric=antisym)
         net.compute.dx0_bf16 = False
         tables = []
         if fused_lr is None:  # per-table paths: one index vector per table over the 2B rows of d x0
@@ -437,9 +450,8 @@ class MLPTrainer:
         if os.environ.get("TRS_MLP_FUSED_DENSE", "1") == "0":
             return None
         ws = [fc.weight for fc in self.net.fcs]
-        if getattr(self, "_w_kind", None) is None:
-            self._w_kind = classify_optimizer(self.opt, ws) if ws else "generic"
-        if self._w_kind != "sgd":
+        # classified every step (a few dict look-ups): a caller may change param_groups between steps (momentum, decay)
+        if not ws or classify_optimizer(self.opt, ws) != "sgd":
             return None
         return [_group_of(self.opt, w)["lr"] for w in ws]
 

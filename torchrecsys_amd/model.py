@@ -229,10 +229,15 @@ class TorchRecSys(torch.nn.Module):
         """This rank's rows of a split under data parallelism (the whole split in a single process).
         dp_partition 'user' (default): the rows whose user_id % world == rank — every user row then has exactly ONE
         writer, so the largest table never drifts between replicas and only item / metadata rows need the periodic
-        average.  'contiguous': equal contiguous blocks.  pre_sharded: the caller's own cut.
-        In every case the shard is then truncated to the MINIMUM length over ranks (one MIN all-reduce per split): all
-        ranks run the same number of steps — a rank with one batch more would wait forever in the MLP's per-step
-        gradient all-reduce (at most a few rows per rank are left out)."""
+        average.  'contiguous': equal contiguous blocks.  pre_sharded: the caller's own cut — under
+        dp_partition 'user' it is CHECKED to be the cut by user_id % world (one reduction per split, agreed over ranks so
+        that every rank raises together): fit() never averages the user tables under that partition and its final
+        gather_owned_rows_ takes rows r::world from rank r, so any other cut would silently replace trained user rows
+        by another replica's stale ones.
+        Rows are never dropped here: shards may differ in length.  Linear / FM steps contain no collective, so every
+        rank simply runs its own number of steps; the MLP's lock-step (one gradient all-reduce per step) is kept by
+        FitRunner, which runs the MINIMUM number of steps over ranks per epoch and leaves the shard whole — the rows
+        beyond are a different set every epoch (the epoch shuffle), not a fixed tail.  evaluate() covers every row."""
         rank, world = tdist.world_info()
         if world == 1:
             return data
@@ -241,18 +246,22 @@ class TorchRecSys(torch.nn.Module):
         if key not in cache:
             if getattr(self, "pre_sharded", False):
                 shard = data
+                if getattr(self, "dp_partition", "user") == "user":
+                    u = data['user_id']
+                    ok = bool(((u % world) == rank).all()) if u.numel() else True
+                    import torch.distributed as _d
+                    dev = _device() if _d.get_backend() == 'nccl' else torch.device('cpu')
+                    if tdist.allreduce_min_int(int(ok), dev) == 0:
+                        raise ValueError(
+                            "pre_sharded=True with dp_partition='user': every rank's interactions must satisfy "
+                            f"user_id % world == rank (rank {rank}: {'ok' if ok else 'violated'}); pass "
+                            "dp_partition='contiguous' for shards cut any other way (every table is then averaged)")
             elif getattr(self, "dp_partition", "user") == "user":
                 keep = (data['user_id'] % world) == rank
                 shard = {k: v[keep] for k, v in data.items()}
             else:
                 s, e = tdist.equal_shard_bounds(data['user_id'].shape[0], rank, world)
                 shard = {k: v[s:e] for k, v in data.items()}
-            n = shard['user_id'].shape[0]
-            import torch.distributed as _d
-            dev = _device() if _d.get_backend() == 'nccl' else torch.device('cpu')
-            n_min = tdist.allreduce_min_int(n, dev)
-            if n_min < n:
-                shard = {k: v[:n_min] for k, v in shard.items()}
             cache[key] = (data, shard)  # keeps `data` alive: its id() is the key
         return cache[key][1]
 
@@ -508,6 +517,18 @@ class FitRunner:
                                      item_to_metadata_map=model.data_processor.item_meta_table,
                                      metadata_id_cols=model.metadata_name) if model.rng == 'reference' else None
         self.num_batches = int(math.ceil(self.n_train / batch_size)) if self.n_train > 0 else 0
+        self.own_batches = self.num_batches
+        if model.net_type == 'mlp' and tdist.world_info()[1] > 1:
+            # the MLP all-reduces its dense gradients every step: all ranks run the common (minimum) number of steps per
+            # epoch; the shard stays whole, so the positions beyond are other rows every epoch (the epoch shuffle)
+            import torch.distributed as _d
+            dev = self.dev if _d.get_backend() == 'nccl' else torch.device('cpu')
+            self.num_batches = tdist.allreduce_min_int(self.num_batches, dev)
+            if self.num_batches < self.own_batches:
+                print(f'|--- data parallel: rank {tdist.world_info()[0]} runs {self.num_batches} of its '
+                      f'{self.own_batches} steps per epoch (about '
+                      f'{self.n_train - min(self.n_train, self.num_batches * batch_size)} of {self.n_train} positions '
+                      'wait for another epoch\'s shuffle)')
         self.trainer = model._make_trainer(optimizer, min(batch_size, max(self.n_train, 1)))
         if getattr(self.trainer, "M", 0) > 0:
             self.trainer.item_meta = model._item_meta_dev()  # metadata scorers: the presort groups each column too

@@ -171,7 +171,7 @@ class Sampler:
             off, items = seen
             _dev(off, "seen offsets", torch.int64)
             _dev(items, "seen items", torch.int32)
-            self.c.seen_off, self.c.seen_items = ptr(off), ptr(items)
+            self.c.seen_off, self.c.seen_items, self.c.seen_users = ptr(off), ptr(items), off.numel() - 1
         if popularity:
             _dev(stream_item, "stream items", torch.int32)
             self.c.pop_items, self.c.pop_n = ptr(stream_item), stream_item.numel()
