@@ -20,10 +20,14 @@ def mm(a, b):
     return (a.to(WIDE) @ b.to(WIDE)).float()
 
 
-def train_step_bf16(P, ids, y_bf16=True, wide=torch.float64, dx0_bf16=False, score_grad=None):
+def train_step_bf16(P, ids, y_bf16=True, wide=torch.float64, dx0_bf16=False, score_grad=None, relu_masks=None):
     """wide: accumulation dtype of the reductions (float64 = the judge; float32 = the calibration run).
     score_grad: optional (g_pos, g_neg), each (B,): d loss / d score driving the backward instead of the hinge's (the
     hinge VALUE is still returned as loss) — MLPTrainer.step(score_grad=...).
+    relu_masks: optional {(pass, layer): bool (B, H)} — the ReLU decisions to take instead of this function's own
+    `pre-activation > 0` (the decisions of the implementation under test: at a pre-activation within rounding of the
+    kink either subgradient is valid, and one flipped element moves a gradient by 1/sqrt(rows) at full size); the number
+    of elements where the given decision differs from this function's own is returned in grads["relu_mask_diffs"].
     P: dict name -> fp32 GPU tensor (state_dict layout; embedding tables may be compacted); ids: dict user/pos/neg
     [/pos_meta/neg_meta] of int64 GPU tensors.  Returns (pos, neg, loss, grads, dx0 rows per pass) — running statistics
     in P are updated in place."""
@@ -39,11 +43,13 @@ def train_step_bf16(P, ids, y_bf16=True, wide=torch.float64, dx0_bf16=False, sco
     u = ids["user"]
     W = [rnd(P[f"fcs.{l}.weight"]) for l in range(L)]
 
-    def forward(item, meta):
+    diffs = [0]
+
+    def forward(item, meta, ps):
         cols = [P["user.weight"][u], P["item.weight"][item]] + [P[f"metadata_embeddings.{m}.weight"][meta[:, m]]
                                                                 for m in range(M)]
         x = rnd(torch.cat(cols, dim=1))
-        c = {"x": [x], "y": [], "mu": [], "invstd": []}
+        c = {"x": [x], "y": [], "mu": [], "invstd": [], "mask": []}
         B = x.shape[0]
         for l in range(L):
             y = mm(x, W[l].T) + P[f"fcs.{l}.bias"]
@@ -62,7 +68,12 @@ def train_step_bf16(P, ids, y_bf16=True, wide=torch.float64, dx0_bf16=False, sco
             c["mu"].append(mu)
             c["invstd"].append(invstd)
             h = ((y - mu) * invstd * P[f"bns.{l}.weight"] + P[f"bns.{l}.bias"]) if use_bn else y
-            x = torch.relu(h)
+            mask = h > 0
+            if relu_masks is not None:
+                diffs[0] += int((mask != relu_masks[(ps, l)]).sum())
+                mask = relu_masks[(ps, l)]
+            c["mask"].append(mask)
+            x = torch.where(mask, h, torch.zeros_like(h))
             if l < L - 1:
                 x = rnd(x)
             c["x"].append(x)
@@ -83,7 +94,7 @@ def train_step_bf16(P, ids, y_bf16=True, wide=torch.float64, dx0_bf16=False, sco
             if use_bn:
                 mu, invstd, gamma = c["mu"][l], c["invstd"][l], P[f"bns.{l}.weight"]
                 xhat = (y - mu) * invstd
-                d = torch.where(xhat * gamma + P[f"bns.{l}.bias"] > 0, dx, torch.zeros_like(dx))
+                d = torch.where(c["mask"][l], dx, torch.zeros_like(dx))
                 s1 = d.to(WIDE).sum(0).float()
                 s2 = (d.to(WIDE) * xhat.to(WIDE)).sum(0).float()
                 gr[f"bns.{l}.weight"], gr[f"bns.{l}.bias"] = s2, s1
@@ -91,7 +102,7 @@ def train_step_bf16(P, ids, y_bf16=True, wide=torch.float64, dx0_bf16=False, sco
                 gr[f"absbound.bns.{l}.weight"] = (d.to(WIDE) * xhat.to(WIDE)).abs().sum(0).float()
                 dy = (gamma * invstd) * (d - s1 / B - xhat * (s2 / B))
             else:
-                dy = torch.where(y > 0, dx, torch.zeros_like(dx))
+                dy = torch.where(c["mask"][l], dx, torch.zeros_like(dx))
             gr[f"fcs.{l}.bias"] = dy.to(WIDE).sum(0).float()
             dy16 = rnd(dy)
             gr[f"fcs.{l}.weight"] = mm(dy16.T, c["x"][l])
@@ -102,8 +113,8 @@ def train_step_bf16(P, ids, y_bf16=True, wide=torch.float64, dx0_bf16=False, sco
                 dx = rnd(dx)
         return gr, dx
 
-    sp, cp = forward(ids["pos"], ids.get("pos_meta"))
-    sn, cn = forward(ids["neg"], ids.get("neg_meta"))
+    sp, cp = forward(ids["pos"], ids.get("pos_meta"), 0)
+    sn, cn = forward(ids["neg"], ids.get("neg_meta"), 1)
     h = sn - sp + 1.0
     B = h.shape[0]
     act = (h >= 0).float() / B
@@ -112,4 +123,6 @@ def train_step_bf16(P, ids, y_bf16=True, wide=torch.float64, dx0_bf16=False, sco
     gp, dxp = backward(g_pos, cp)
     gn, dxn = backward(g_neg, cn)
     grads = {k: gp[k] + gn[k] for k in gp}  # (absbound.*: the two passes' bounds add up as well)
+    if relu_masks is not None:
+        grads["relu_mask_diffs"] = diffs[0]
     return sp, sn, loss, grads, (dxp, dxn)

@@ -81,7 +81,8 @@ def test_remap_ids_trains_and_predicts_in_original_ids(net_type):
 
     with pytest.raises(IndexError, match="remap_ids"):
         with contextlib.redirect_stdout(io.StringIO()):
-            TorchRecSys.from_tensors(raw_u, raw_i, n_factors=16, net_type=net_type, dynamic_neg_sampling=True)
+            TorchRecSys.from_tensors(raw_u, raw_i, n_users=300, n_items=120, n_factors=16, net_type=net_type,
+                                     dynamic_neg_sampling=True)  # (tables sized by the caller: 300 users, 120 items)
     dense, lines_d = run(dense_u, dense_i)
     remap, lines_r = run(raw_u, raw_i, remap_ids=True)
     assert remap.n_users == dense.n_users == 300 and remap.n_items == dense.n_items == 120

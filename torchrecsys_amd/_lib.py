@@ -99,7 +99,8 @@ class TrsTrainArgs(C.Structure):
                 ("ustage_buf_dev", C.c_void_p), ("sorted_ukeys_dev", C.c_void_p), ("sorted_uvals_dev", C.c_void_p),
                 ("slice_pos0", C.c_int64),
                 ("opt", C.POINTER(TrsOpt)), ("meta", C.POINTER(TrsMetaStage)),
-                ("events", C.POINTER(C.c_void_p))]
+                ("events", C.POINTER(C.c_void_p)), ("sync_dev", C.c_void_p),
+                ("sync_count_host", C.POINTER(C.c_uint32))]
 
 
 _vp, _i32, _i64, _u64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float

@@ -66,6 +66,11 @@ struct FastArgs {
   const uint8_t* idup_pos;
   float* ustage;            // (B,D) pre-update user rows, read by the sorted item update
   OptArgs o;                // update rule of the presorted mode (kind OPT_SGD: lr above)
+  // INL 3 (flag mode, one launch per step): ONE monotonic arrival counter (never reset, wraps mod 2^32); a launch
+  // counts its workgroups in and waits until the counter has reached sync_target = arrivals of all earlier launches +
+  // its own grid (wrap-safe signed compare)
+  uint32_t* sync;
+  uint32_t sync_base, sync_target;
 };
 
 struct RawIds {   // loads issued, nothing consumed yet
@@ -172,10 +177,32 @@ __device__ __forceinline__ void load_rows(TripleRows<VEC, K>& r, const trs_table
 // too — item[i] += (-lr*gz) * u with the same two roundings as the sorted run of length one it replaces — and the old
 // user row is staged only when one of the triple's item references still goes through the runs.  At c4 (65 536
 // references over 1M items per step) 94 % of the references are alone: the step becomes one read and one write per row.
+// INL 3 (flag mode as ONE launch per step; launch_fwd_stage picks it when every workgroup of the grid is resident at
+// once): INL 2, and the flagged references are applied by this same launch instead of flagged_update_kernel.  Every wave
+// lists its flagged references in LDS — (triple, which) | table row | coefficient | coefficient of the 1-wide term, no
+// atomics: slots come from ballots — and stages their rows in global memory as in INL 2.  After its last triple a
+// workgroup waits for its loads and stores (s_waitcnt vmcnt(0) + barrier), counts itself in on the step's arrival
+// counter and waits until ALL workgroups of the launch have done so: from then on no row of the tables is read any more
+// by this step, so the float atomics of the flagged references — each workgroup re-reads the rows IT staged (same CU:
+// its own stores are visible to it) — may land.  What this replaces: a kernel boundary, a ramp, and the second launch's
+// detection pass over all 3B ids and flags for the 6 % of references that are flagged.  The wait is bounded (0.2 s of
+// s_memrealtime): a grid that cannot become resident raises err bit 2 instead of hanging.
+constexpr int DEFER_ITERS = 8;  // iterations per lane group the per-wave list is sized for (launch_fwd_stage keeps to it)
+struct DeferEntry {
+  uint32_t tw;   // (t << 2) | which      which: 0 user (row staged in du), 1 positive, 2 negative (row staged in ustage)
+  int32_t row;   // table row
+  float c;       // coefficient of the staged row
+  float clin;    // increment of the row's 1-wide term
+};
+
 template <int NET, int VEC, int G, int K, int SRC, bool FULL, int INL, int OPT = OPT_SGD>
 __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) {
   constexpr int N = K * VEC;
   constexpr int TPW = TRS_WAVE / G;
+  constexpr bool DEFER = INL == 3;
+  constexpr int LIST_CAP = DEFER ? DEFER_ITERS * TPW * 3 : 1;
+  __shared__ DeferEntry s_list[TRS_BLOCK / TRS_WAVE][LIST_CAP];
+  int n_list = 0;  // wave-uniform: entries of this wave's list
   const trs_tables& T = a.T;
   const int D = T.D;
   const int64_t B = a.B;
@@ -231,13 +258,25 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
       gp = gp * ((1.0f - sp) * sp);
       gn = gn * ((1.0f - sn) * sn);
     }
+    if (DEFER) {  // list the flagged references of the wave's triples (one lane per group speaks for its triple); outside
+      // every divergent branch: the ballots and the wave-uniform counter need all lanes
+      const bool lead = lig == 0 && live;
+      const uint64_t mu = __ballot(lead && id.dup), mp = __ballot(lead && id.pdup), mn = __ballot(lead && id.ndup);
+      const uint64_t below = ((uint64_t)1 << lane) - 1;
+      DeferEntry* L = s_list[threadIdx.x >> 6];
+      const int bu = n_list, bp = bu + __popcll(mu), bn = bp + __popcll(mp);
+      if (lead && id.dup) L[bu + __popcll(mu & below)] = {(uint32_t)tt << 2, id.u, -a.lr, -a.lr * (gp + gn)};
+      if (lead && id.pdup) L[bp + __popcll(mp & below)] = {((uint32_t)tt << 2) | 1u, id.p, -a.lr * gp, -a.lr * gp};
+      if (lead && id.ndup) L[bn + __popcll(mn & below)] = {((uint32_t)tt << 2) | 2u, id.n, -a.lr * gn, -a.lr * gn};
+      n_list = bn + __popcll(mn);
+    }
     if (id.valid) {
       RowReg<VEC, K> g;
 #pragma unroll
       for (int n = 0; n < N; ++n) g.v[n] = gp * r.pi.v[n] + gn * r.ni.v[n];
       if (INL) {
-        if (INL != 2 || id.pdup || id.ndup) row_store<VEC, G, K>(r.u, a.ustage + tt * (int64_t)D, D, lig);
-        if (INL == 2 && live) {
+        if (INL < 2 || id.pdup || id.ndup) row_store<VEC, G, K>(r.u, a.ustage + tt * (int64_t)D, D, lig);
+        if (INL >= 2 && live) {
           const float cp = -a.lr * gp, cn = -a.lr * gn;  // the coefficient the sorted run forms from gz
           if (!id.pdup) {
             RowReg<VEC, K> o;
@@ -280,8 +319,10 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
         row_store<VEC, G, K>(g, a.du + tt * (int64_t)D, D, lig);
       }
       if (lig == 0) {
-        a.gz[tt] = gp;
-        a.gz[B + tt] = gn;
+        if (!DEFER) {  // (INL 3: the coefficients travel in the list)
+          a.gz[tt] = gp;
+          a.gz[B + tt] = gn;
+        }
         if (SRC != 0) {  // the batch this step was derived from, for K1b / K2 / K3 (and for the caller)
           a.user[tt] = id.u;
           a.pos[tt] = id.p;
@@ -325,12 +366,62 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
   __shared__ float s_loss[TRS_BLOCK / TRS_WAVE];
   const float wl = trs_wave_sum(loss_acc);
   if (lane == 0) s_loss[threadIdx.x >> 6] = wl;
+  if (DEFER) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's row loads and staging stores are done
   __syncthreads();
   if (threadIdx.x == 0) {
     float L = 0.f;
 #pragma unroll
     for (int w = 0; w < TRS_BLOCK / TRS_WAVE; ++w) L += s_loss[w];
     if (L != 0.f) atomicAdd(a.loss_sum, L);
+  }
+  if (DEFER) {
+    if (threadIdx.x == 0) {
+      uint32_t* ctr = a.sync;
+      __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint64_t t_start = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+      while ((int32_t)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.sync_target) < 0) {
+        __builtin_amdgcn_s_sleep(4);
+        if (__builtin_amdgcn_s_memrealtime() - t_start > 20000000ull) {  // 0.2 s: the grid is not resident at once
+          if (a.err) atomicOr(a.err, 4);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    // every row read of the step is behind us, chip-wide: this wave's flagged references, FLG_U at a time — staged rows
+    // loaded together (L2: written by this CU a moment ago), then one float atomic per element, a row = adjacent dwords
+    constexpr int DU = 4, KDD = (N * G + TRS_WAVE - 1) / TRS_WAVE;
+    const DeferEntry* L = s_list[threadIdx.x >> 6];
+    for (int e0 = 0; e0 < n_list; e0 += DU) {
+      float x[DU][KDD], cc[DU];
+      float* dst[DU];
+      bool has[DU];
+#pragma unroll
+      for (int k = 0; k < DU; ++k) {
+        has[k] = e0 + k < n_list;
+        const DeferEntry en = L[has[k] ? e0 + k : e0];  // same address in every lane: one LDS broadcast
+        const int which = (int)(en.tw & 3u);
+        const int64_t tk = (int64_t)(en.tw >> 2);
+        cc[k] = en.c;
+        const float* src = (which == 0 ? a.du : a.ustage) + tk * (int64_t)D;
+        dst[k] = (which == 0 ? T.user : T.item) + (int64_t)en.row * (int64_t)D;
+#pragma unroll
+        for (int q = 0; q < KDD; ++q) {
+          const int e = q * TRS_WAVE + lane;
+          x[k][q] = __hip_atomic_load(src + (e < D ? e : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // past L1
+        }
+        if (lane == 0 && has[k]) atomicAdd((which == 0 ? T.user_lin : T.item_lin) + en.row, en.clin);
+      }
+#pragma unroll
+      for (int k = 0; k < DU; ++k) {
+        if (!has[k]) continue;
+#pragma unroll
+        for (int q = 0; q < KDD; ++q) {
+          const int e = q * TRS_WAVE + lane;
+          if (e < D) atomicAdd(dst[k] + e, cc[k] * x[k][q]);
+        }
+      }
+    }
   }
 }
 
@@ -1109,8 +1200,22 @@ static int launch_meta_stage(const ScoreArgs& a, hipStream_t s) {
   }
 }
 
+// Workgroups of fwd_stage_kernel<..., INL 3> that are certainly resident at once: (occupancy - 1) per CU (one below the
+// API's answer, which can be one too high — MI355X_MICROARCH.md "Residency and cooperative launch"), at most 2 per CU.
+template <typename KernelT>
+static int64_t defer_resident_cap(KernelT kernel) {
+  int occ = 0, dev = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, TRS_BLOCK, 0) != hipSuccess) return 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    return 0;
+  const int per_cu = occ - 1 < 2 ? occ - 1 : 2;
+  return per_cu > 0 ? (int64_t)per_cu * cus : 0;
+}
+
 template <int NET>
-static int launch_fwd_stage(const FastArgs& a, hipStream_t s) {
+static int launch_fwd_stage(const FastArgs& a, hipStream_t s, uint32_t* deferred = nullptr) {
+  if (deferred) *deferred = 0;  // > 0: INL 3 was launched with that many workgroups (= arrivals on a.sync)
   RowCfg c;
   if (!pick_row_cfg(a.T.D, c)) {
     trs_set_error("unsupported n_factors D=%d", a.T.D);
@@ -1136,7 +1241,16 @@ static int launch_fwd_stage(const FastArgs& a, hipStream_t s) {
       hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL, 1, OPT_ADAM>), gr, bl, 0, s, a);              \
     else if (src == 0 && a.udup_pos && a.o.kind == OPT_ADAGRAD)                                                  \
       hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL, 1, OPT_ADAGRAD>), gr, bl, 0, s, a);           \
-    else if (src == 0 && a.udup_pos && a.idup_pos)                                                               \
+    else if (src == 0 && a.udup_pos && a.idup_pos && a.sync && deferred && iters <= DEFER_ITERS) {               \
+      static const int64_t cap = defer_resident_cap(fwd_stage_kernel<NET, V, GG, KK, 0, FULL, 3>);                \
+      if (grid <= cap) {                                                                                        \
+        FastArgs b = a;                                                                                         \
+        b.sync_target = a.sync_base + (uint32_t)grid;                                                           \
+        hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL, 3>), gr, bl, 0, s, b);                      \
+        *deferred = (uint32_t)grid;                                                                             \
+      } else                                                                                                    \
+        hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL, 2>), gr, bl, 0, s, a);                      \
+    } else if (src == 0 && a.udup_pos && a.idup_pos)                                                             \
       hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL, 2>), gr, bl, 0, s, a);                        \
     else if (src == 0 && a.udup_pos) hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL, 1>), gr, bl, 0, s, a); \
     else if (src == 0) hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL, 0>), gr, bl, 0, s, a);      \
@@ -1460,6 +1574,8 @@ extern "C" int trs_train_steps_sgd(const trs_train_args* args, void* stream) {
       a.udup_pos = user_dup_flags_dev + (int64_t)st * batch;
       a.idup_pos = args->item_dup_flags_dev + (int64_t)st * 2 * batch;
       a.ustage = ustage_buf_dev;
+      a.sync = args->sync_count_host ? args->sync_dev : nullptr;
+      a.sync_base = a.sync ? *args->sync_count_host : 0u;
     }
     if (adaptive) {  // this step's effective learning rate, in double like the Python floats of torch.optim
       OptArgs& o = a.o;
@@ -1486,6 +1602,7 @@ extern "C" int trs_train_steps_sgd(const trs_train_args* args, void* stream) {
     if (ev && !ev[0]) ev = nullptr;  // a step whose four handles are NULL is not timed (sampled timing)
     if (ev) (void)hipEventRecord(ev[0], s);
     int rc;
+    uint32_t deferred = 0;
     if (meta) {  // K1 = the generic scorer in its staging mode (score_kernels.h MODE 2)
       ScoreArgs sa = {};
       sa.T = *tables;
@@ -1516,12 +1633,14 @@ extern "C" int trs_train_steps_sgd(const trs_train_args* args, void* stream) {
       if (rc > 0)  // more than 3 columns / odd D / no id arrays: the generic scorer's staging mode
         rc = net == TRS_NET_FM ? launch_score<TRS_NET_FM, 2>(sa, s) : launch_score<TRS_NET_LINEAR, 2>(sa, s);
     } else {
-      rc = net == TRS_NET_FM ? launch_fwd_stage<TRS_NET_FM>(a, s) : launch_fwd_stage<TRS_NET_LINEAR>(a, s);
+      rc = net == TRS_NET_FM ? launch_fwd_stage<TRS_NET_FM>(a, s, &deferred)
+                             : launch_fwd_stage<TRS_NET_LINEAR>(a, s, &deferred);
     }
     if (rc) return rc;
     if (ev) (void)hipEventRecord(ev[1], s);
     if (flgm) {  // the flagged references: float atomics into the tables (every read of the step is behind us)
-      rc = launch_flagged_update(a, s);
+      if (deferred) *args->sync_count_host += deferred;  // K1's own workgroups did it after their grid-wide wait
+      else rc = launch_flagged_update(a, s);
       if (rc) return rc;
       if (ev) {
         (void)hipEventRecord(ev[2], s);

@@ -157,6 +157,16 @@ class SparseScorerTrainer:
         gl = self.grad_lin.view(-1)[: self.R * B].view(self.R, B)
         return gr, gl
 
+    def _sync(self):
+        """(device arrival counter, host count of scheduled arrivals) of the one-launch flag-mode step
+        (trs_train_args.sync_dev / sync_count_host), or None: TRS_FLAG_ONE_LAUNCH=0."""
+        if os.environ.get("TRS_FLAG_ONE_LAUNCH", "1") == "0":
+            return None
+        if getattr(self, "sync", None) is None:
+            import ctypes
+            self.sync = (torch.zeros(1, dtype=torch.int32, device=self.dev), ctypes.c_uint32(0))
+        return self.sync
+
     def _stamps(self, n):
         """First of n consecutive step stamps of the duplicate-detection scratch (never 0, re-zeroed before wrapping)."""
         if self.stamp + n >= 0xFFFFFFF0:
@@ -346,14 +356,14 @@ class SparseScorerTrainer:
             fc = getattr(self, "_flag_call", None)
             if fc is None or fc.batch != batch or fc.sig != sig:
                 fc = self._flag_call = ops.FlagStepCall(self.net.NET, T, batch, self.fast_lr, self.gz, self.du, self.err,
-                                                        self.scratch, self.ustage, self.loss_id)
+                                                        self.scratch, self.ustage, self.loss_id, self._sync())
             fc(ps, b_in_slice, n_steps, loss_sums, self._stamps(n_steps))
             return
         if isinstance(ps, ops.EpochFlags):  # sparse regime: flags only, the flagged references follow K1 with atomics
             ids, udup, idup = ps.step_args(b_in_slice)
             ops.train_steps_sgd(self.net.NET, self.net.tables(), None, None, 0, 0, 0, batch, n_steps, self.fast_lr, *ids,
                                 self.gz, self.du, loss_sums, self.err, self.scratch, self._stamps(n_steps), evs,
-                                user_dup=udup, item_dup=idup, ustage=self.ustage, loss=self.loss_id)
+                                user_dup=udup, item_dup=idup, ustage=self.ustage, loss=self.loss_id, sync=self._sync())
             if te is not None:
                 self._collect_events(te, ns, ("fwd_stage_kernel", "flagged_update_kernel", "event_overhead"))
             return

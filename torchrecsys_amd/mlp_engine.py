@@ -378,6 +378,8 @@ class MLPTrainer:
         self.row_state = {id(p): RowState(p) for p in self.emb_params} if self.kind in ("sparse_adam", "adagrad") else {}
         self.kernel_events = None
         self.loss_id = 0  # _lib.LOSS_ID: hinge (the reference) | bpr; set by fit(loss=...)
+        self.keep_ctx = False  # tests: keep the last step's forward context (y_l, batch statistics) in self.last_ctx
+        self.last_ctx = None
 
     def step(self, ids, loss_slot, auc_slot=None, score_grad=None):
         """One training step.  score_grad (optional, (2B,) fp32: d loss / d score of the positive rows, then of the
@@ -392,6 +394,7 @@ class MLPTrainer:
         fused_lr = self._fused_embed_lr() if self.kind == "sgd" else None
         net.compute.dx0_bf16 = fused_lr is not None  # (only read on the bf16-resident path)
         scores, ctx = net.compute.forward(ids, 2, True)
+        self.last_ctx = ctx if self.keep_ctx else None
         pos, neg = scores[:B], scores[B:]
         gp, gn = ops.hinge_auc_backward(pos, neg, loss_slot, auc_slot, loss=self.loss_id)
         g = gp._base  # (2B,): positive half, negative half

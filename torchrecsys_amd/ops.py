@@ -348,13 +348,17 @@ class EpochFlags:
 def train_steps_sgd(net, T, stream_ui, neg_static, shuffle_key, sample_seed, first_pos, batch, n_steps,
                     lr, user_buf, pos_buf, neg_buf, gz_buf, du_buf, loss_sums, err_flag, scratch=None, first_stamp=1,
                     events=None, sorted_keys=None, sorted_vals=None, key_bytes=0, user_dup=None, ustage=None,
-                    user_sorted=None, opt=None, meta=None, item_dup=None, loss=0):
+                    user_sorted=None, opt=None, meta=None, item_dup=None, loss=0, sync=None):
     """n_steps fused steps driven from C (trs_train_steps_sgd).  stream_ui None: the steps' ids are already in
     user/pos/neg_buf.  events: optional flat list of 4*n_steps raw hipEvent_t handles.  opt: None (SGD with lr) or a
     _lib.TrsOpt (SparseAdam / Adagrad on the presorted path; keep the tensors it points to alive).  item_dup: the
     presort's item-duplicate flags (plain SGD without metadata): K1 also updates item rows referenced once.  Flag mode
-    (sparse regime): user_dup + item_dup from an EpochFlags, ustage, and no sorted references."""
+    (sparse regime): user_dup + item_dup from an EpochFlags, ustage, and no sorted references; sync = (zeroed int32
+    device tensor, ctypes c_uint32 host counter): the flagged references are applied by K1's own launch whenever its
+    grid is resident at once."""
     a = _lib.TrsTrainArgs()
+    if sync is not None:
+        a.sync_dev, a.sync_count_host = ptr(sync[0]), C.pointer(sync[1])
     a.net, a.n_steps, a.tables, a.batch, a.lr = NET_ID[net], int(n_steps), C.pointer(T), int(batch), float(lr)
     a.first_stamp = int(first_stamp)
     a.loss = int(loss)
@@ -383,9 +387,11 @@ class FlagStepCall:
     fields that change (step count, stamp, the slice offsets of ids / flags, the loss slot).  The generic wrapper above
     rebuilds ~40 ctypes fields per call — 50-80 us of host time that a short timed window sees as start-up latency."""
 
-    def __init__(self, net, T, batch, lr, gz_buf, du_buf, err_flag, scratch, ustage, loss):
+    def __init__(self, net, T, batch, lr, gz_buf, du_buf, err_flag, scratch, ustage, loss, sync=None):
         a = self.a = _lib.TrsTrainArgs()
-        self.keep = (T, gz_buf, du_buf, err_flag, scratch, ustage)
+        self.keep = (T, gz_buf, du_buf, err_flag, scratch, ustage, sync)
+        if sync is not None:
+            a.sync_dev, a.sync_count_host = ptr(sync[0]), C.pointer(sync[1])
         a.net, a.tables, a.batch, a.lr, a.loss = NET_ID[net], C.pointer(T), int(batch), float(lr), int(loss)
         a.gz_buf_dev, a.du_buf_dev = ptr(gz_buf), ptr(du_buf)
         a.err_flag_dev, a.scratch_dev, a.ustage_buf_dev = ptr(err_flag), ptr(scratch), ptr(ustage)
