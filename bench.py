@@ -95,6 +95,7 @@ def slice_fractions(runner):
         return None
     n = ps.n_batches * ps.batch
     return {"k1_takes_lone_items": ps.key_bytes == 0,  # EpochFlags (accumulate mode); the sorted runs take every item reference
+            "one_launch": bool(getattr(tr, "one_launch", False)),  # flag mode with the flagged references applied by K1's launch
             "users_alone": 1.0 - float(ps.user_dup[:n].float().mean()),
             # (the sorted-run presort computes item flags only when K1 reads them: None = not computed)
             "item_refs_alone": (1.0 - float(ps.item_dup[:n].float().mean())) if getattr(ps, "item_flags", True) else None,
@@ -112,11 +113,17 @@ def kernel_algorithmic_bytes(R, row, state_rows, seen, frac):
     # an upper bound of the distinct rows) and the user rows of duplicated users
     k2 = 12 + ((2 * (1 - ia)) * 2 + (1 - ua) * 2) * (1 + state_rows) * row
     acc_apply = 0.0
-    if "flagged_update_kernel" in seen:  # flag mode (sparse regime): K1 reads the triple's R rows and writes the rows of
-        # the references that are alone in the batch; the second launch reads + writes (atomically) one table row per
-        # flagged reference.  Staging (gz, the old user row / gradient row of flagged references) is not credited.
+    if "flagged_update_kernel" in seen or (frac and frac.get("one_launch")):
+        # flag mode (sparse regime): K1 reads the triple's R rows and writes the rows of the references that are alone in
+        # the batch; the second launch reads + writes (atomically) one table row per flagged reference.  Staging (gz,
+        # the old user row / gradient row of flagged references) is not credited.
         k1 = 16 + R * row + (ua + 2 * ia) * row
         acc_apply = 15 + ((1 - ua) + 2 * (1 - ia)) * 2 * row
+        if frac and frac.get("one_launch"):  # ... or K1's own workgroups do, after their grid-wide wait: the whole step.
+            # Every row read once and written once = SURVEY 8d's step figure; the flagged rows' second access (the atomic
+            # read-modify-write at the memory side) is not credited
+            k1 = 16 + R * row + R * row
+            acc_apply = 0.0
     return {"score_kernel<fwd_bwd>": 16 + R * row + 8, "score_sgd_update_kernel": 12 + R * row,
             "fwd_stage_kernel": k1, "item_update_kernel": 12 + 3 * row, "sorted_item_update_kernel": 12 + 3 * row,
             "sorted_updates_fused_kernel": k2, "user_update_kernel": 4 + row, "sorted_user_dup_update_kernel": 4 + row,
@@ -292,13 +299,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    timeline = None
+    if os.environ.get("TRS_BENCH_TIMELINE") == "1":  # diagnostic: host time stamps of every C call of the timed region
+        from torchrecsys_amd import ops as _ops
+        timeline = []
+        _orig_call = _ops.FlagStepCall.__call__
+
+        def _stamped(self_, *a_, **k_):
+            timeline.append(("call", time.perf_counter()))
+            r_ = _orig_call(self_, *a_, **k_)
+            timeline.append(("ret", time.perf_counter()))
+            return r_
+        _ops.FlagStepCall.__call__ = _stamped
     run(args.warmup)
     barrier()
+    if timeline is not None:
+        del timeline[:]
     t0 = time.perf_counter()
     run(args.steps)
     enqueued = time.perf_counter() - t0  # host time to enqueue the K steps (the GPU is still running them)
     barrier()
     elapsed = time.perf_counter() - t0
+    if timeline is not None:
+        _ops.FlagStepCall.__call__ = _orig_call
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -348,6 +371,8 @@ def main():
                    "rng": "device (Feistel epoch shuffle + Philox4x32-10 negative sampler)"},
     }
     out["host_enqueue_ms"] = 1e3 * enqueued  # of the timed region's `1e3 * elapsed` ms: the launches run ahead of the GPU
+    if timeline is not None:
+        out["host_timeline_us"] = [(k_, round(1e6 * (t_ - t0), 1)) for k_, t_ in timeline] + [("synced", round(1e6 * elapsed, 1))]
     if not is_mlp:
         out["step_algorithmic_GBps_per_gpu"] = step_bytes * B * args.steps / elapsed / 1e9
         out["step_frac_of_hbm_peak"] = out["step_algorithmic_GBps_per_gpu"] / HBM_PEAK_GBS
@@ -386,6 +411,8 @@ def main():
         ev_ms = raw_ms.pop("event_overhead", 0.0)
         n_samples.pop("event_overhead", None)
         med_ms.pop("event_overhead", None)
+        for d_ in (raw_ms, n_samples, med_ms):  # (one-launch flag mode: the second interval is an event record too)
+            d_.pop("event_overhead_2", None)
         mean_ms = dict(raw_ms)
         # dominant = the kernel with the longest MEDIAN interval (a sample that overlaps a presort burst on the side
         # stream can be 20x a normal one and would decide a mean over 37 samples); `achieved` uses that kernel's MEAN

@@ -90,6 +90,7 @@ const char* trs_last_error(void);
  *      form, outer_xw) grew arguments; trs_hinge_auc_backward, trs_f32_to_bf16_multi, trs_mlp_embed_sgd_update added.
  *   4: trs_sampler.seen_users (bounds of the seen CSR); trs_train_args.sync_dev (flag mode as one launch per step). */
 #define TRS_ABI_VERSION 4
+#define TRS_SYNC_WORDS 288
 int trs_abi_version(void);
 /* 0 if the current HIP device is gfx950, TRS_E_DEVICE otherwise. */
 int trs_check_device(void);
@@ -300,11 +301,12 @@ typedef struct trs_train_args {
   const trs_opt* opt;        /* NULL: plain SGD */
   const trs_meta_stage* meta;/* NULL iff tables->M == 0 */
   void** events;             /* NULL, or 4*n_steps hipEvent_t handles (a step whose handles are NULL is not timed) */
-  uint32_t* sync_dev;        /* NULL, or ONE uint32 in device memory, zeroed once by the caller, and */
+  uint32_t* sync_dev;        /* NULL, or TRS_SYNC_WORDS (288) uint32 in device memory (an arrival counter and eight flag
+                                lines, 128 B apart), zeroed once by the caller, and */
   uint32_t* sync_count_host; /* ... ONE uint32 in HOST memory, zero at that time and owned by this entry point from
                                 then on (the arrivals it has scheduled on sync_dev, mod 2^32).  FLAG MODE with both
                                 given: whenever every workgroup of K1's grid is resident at once, the step is ONE
-                                launch — K1's workgroups count themselves in on *sync_dev once their row reads are
+                                launch — K1's workgroups count themselves in on sync_dev[0] once their row reads are
                                 done, wait for the whole grid, and add the flagged references' contributions
                                 themselves (no second launch).  err bit 2: the grid did not become resident within
                                 0.2 s (that step's results are not exact). */

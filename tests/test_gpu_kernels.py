@@ -968,11 +968,15 @@ def test_gemm_fused_bn_statistics(B, passes, K, H, bf16):
 @pytest.mark.parametrize("net,D,skew", [("fm", 64, False), ("fm", 64, True), ("fm", 16, True), ("linear", 32, True),
                                         ("fm", 80, False), ("fm", 10, True), ("fm", 128, False)])
 @pytest.mark.parametrize("n_users", [300, 3_000_000])
-def test_flag_mode_matches_oracle(net, D, skew, n_users):
+@pytest.mark.parametrize("one_launch", [False, True])
+def test_flag_mode_matches_oracle(net, D, skew, n_users, one_launch):
     """The sparse regime's step (trs_epoch_flags + K1 taking every lone reference + flagged_update_kernel): rows
     referenced once in the batch updated in place by K1, the flagged references added with float atomics afterwards — 3
     batches in one C call == oracle SGD steps.  n_users = 3M: more rows than bitmap bits, so the user flags are
-    hashed (conservative) — flagged lone rows must still be exact.  Flags: exact where the table fits the bitmap."""
+    hashed (conservative) — flagged lone rows must still be exact.  Flags: exact where the table fits the bitmap.
+    one_launch: the same step as ONE launch (trs_train_args.sync_dev): K1's workgroups count themselves in on the
+    arrival counter after their last row read, wait for the whole grid and apply the flagged references themselves;
+    the library reports the arrivals it scheduled (3 launches x grid), and a second call continues the counter."""
     ops = _ops()
     rs = np.random.RandomState(D + skew)
     NU, NI, B, nb, lr = n_users, 57 if n_users == 300 else 5000, 512, 3, 0.05
@@ -1011,10 +1015,18 @@ def test_flag_mode_matches_oracle(net, D, skew, n_users):
         assert np.array_equal(idup[sl].cpu().numpy().astype(bool), want_i)
     gz, du = torch.empty((2, B), device=DEV), torch.empty((B, D), device=DEV)
     losses = torch.zeros(nb, device=DEV)
-    ops.train_steps_sgd(net, T, None, None, 0, 0, 0, B, nb, lr, *ids, gz, du, losses, err,
-                        ops.train_scratch(NU, NI, B, D, DEV), 1, None, user_dup=udup, item_dup=idup,
-                        ustage=torch.empty((B, D), device=DEV))
+    import ctypes
+    sync = (torch.zeros(288, dtype=torch.int32, device=DEV), ctypes.c_uint32(0)) if one_launch else None
+    scratch, ustage = ops.train_scratch(NU, NI, B, D, DEV), torch.empty((B, D), device=DEV)
+    # (two C calls, 2 + 1 steps: the arrival counter carries over from call to call)
+    ops.train_steps_sgd(net, T, None, None, 0, 0, 0, B, 2, lr, *ids, gz, du, losses, err, scratch, 1, None,
+                        user_dup=udup, item_dup=idup, ustage=ustage, sync=sync)
+    ids2, udup2, idup2 = ef.step_args(2)
+    ops.train_steps_sgd(net, T, None, None, 0, 0, 0, B, 1, lr, *ids2, gz, du, losses[2:], err, scratch, 3, None,
+                        user_dup=udup2, item_dup=idup2, ustage=ustage, sync=sync)
     torch.cuda.synchronize()
+    if one_launch:  # every launch counted all its workgroups in, and the library knows how many it scheduled
+        assert sync[1].value > 0 and sync[1].value % 3 == 0 and int(sync[0][0].item()) == sync[1].value
     ref = {k: v.copy() for k, v in p.items()}
     for b in range(nb):
         batch = {"user_id": u_small[b * B:(b + 1) * B], "pos_item_id": i[b * B:(b + 1) * B], "neg_item_id": j[b * B:(b + 1) * B]}

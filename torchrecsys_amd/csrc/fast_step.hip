@@ -66,9 +66,10 @@ struct FastArgs {
   const uint8_t* idup_pos;
   float* ustage;            // (B,D) pre-update user rows, read by the sorted item update
   OptArgs o;                // update rule of the presorted mode (kind OPT_SGD: lr above)
-  // INL 3 (flag mode, one launch per step): ONE monotonic arrival counter (never reset, wraps mod 2^32); a launch
-  // counts its workgroups in and waits until the counter has reached sync_target = arrivals of all earlier launches +
-  // its own grid (wrap-safe signed compare)
+  // INL 3 (flag mode, one launch per step): sync[0] = ONE monotonic arrival counter (never reset, wraps mod 2^32); a
+  // launch counts its workgroups in and waits until the counter has reached sync_target = arrivals of all earlier
+  // launches + its own grid (wrap-safe signed compare); sync[32 * (1 + g)], g < 8: flag lines that carry the last
+  // completed target (TRS_SYNC_WORDS uint32 in all)
   uint32_t* sync;
   uint32_t sync_base, sync_target;
 };
@@ -375,43 +376,34 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
     if (L != 0.f) atomicAdd(a.loss_sum, L);
   }
   if (DEFER) {
-    if (threadIdx.x == 0) {
-      uint32_t* ctr = a.sync;
-      __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const uint64_t t_start = __builtin_amdgcn_s_memrealtime();  // 100 MHz
-      while ((int32_t)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.sync_target) < 0) {
-        __builtin_amdgcn_s_sleep(4);
-        if (__builtin_amdgcn_s_memrealtime() - t_start > 20000000ull) {  // 0.2 s: the grid is not resident at once
-          if (a.err) atomicOr(a.err, 4);
-          break;
-        }
-      }
-    }
-    __syncthreads();
-    // every row read of the step is behind us, chip-wide: this wave's flagged references, FLG_U at a time — staged rows
-    // loaded together (L2: written by this CU a moment ago), then one float atomic per element, a row = adjacent dwords
+    // this wave's flagged references, DU at a time: the staged rows of a round are loaded together (L2: written by this
+    // CU a moment ago), then one float atomic per element, a row = adjacent dwords (the full-rate atomic shape)
     constexpr int DU = 4, KDD = (N * G + TRS_WAVE - 1) / TRS_WAVE;
     const DeferEntry* L = s_list[threadIdx.x >> 6];
-    for (int e0 = 0; e0 < n_list; e0 += DU) {
-      float x[DU][KDD], cc[DU];
-      float* dst[DU];
-      bool has[DU];
+    float x[DU][KDD], cc[DU], cl[DU];
+    float *dst[DU], *dlin[DU];
+    bool has[DU];
+    auto load_round = [&](int e0) {
 #pragma unroll
       for (int k = 0; k < DU; ++k) {
         has[k] = e0 + k < n_list;
-        const DeferEntry en = L[has[k] ? e0 + k : e0];  // same address in every lane: one LDS broadcast
+        const DeferEntry en = L[has[k] ? e0 + k : 0];  // same address in every lane: one LDS broadcast
         const int which = (int)(en.tw & 3u);
-        const int64_t tk = (int64_t)(en.tw >> 2);
+        const int64_t tk = has[k] ? (int64_t)(en.tw >> 2) : 0;
+        const int64_t rk = has[k] ? (int64_t)en.row : 0;
         cc[k] = en.c;
+        cl[k] = en.clin;
         const float* src = (which == 0 ? a.du : a.ustage) + tk * (int64_t)D;
-        dst[k] = (which == 0 ? T.user : T.item) + (int64_t)en.row * (int64_t)D;
+        dst[k] = (which == 0 ? T.user : T.item) + rk * (int64_t)D;
+        dlin[k] = (which == 0 ? T.user_lin : T.item_lin) + rk;
 #pragma unroll
         for (int q = 0; q < KDD; ++q) {
           const int e = q * TRS_WAVE + lane;
           x[k][q] = __hip_atomic_load(src + (e < D ? e : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // past L1
         }
-        if (lane == 0 && has[k]) atomicAdd((which == 0 ? T.user_lin : T.item_lin) + en.row, en.clin);
       }
+    };
+    auto apply_round = [&]() {
 #pragma unroll
       for (int k = 0; k < DU; ++k) {
         if (!has[k]) continue;
@@ -420,7 +412,41 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
           const int e = q * TRS_WAVE + lane;
           if (e < D) atomicAdd(dst[k] + e, cc[k] * x[k][q]);
         }
+        if (lane == 0) atomicAdd(dlin[k], cl[k]);
       }
+    };
+    // the first round's staged rows travel to registers WHILE the workgroup waits for the grid (they are this
+    // workgroup's own data, complete since the barrier above; typical: 2-3 flagged references per wave = one round)
+    load_round(0);
+    if (threadIdx.x == 0) {
+      // Arrivals are returning atomics on the counter's line: the workgroup whose add completes the grid publishes the
+      // target on eight flag lines (128 B apart); everybody else polls only its flag line (blockIdx % 8), which nobody
+      // writes meanwhile.  (All 512 workgroups polling the counter itself queued their reads between the arrivals on one
+      // memory channel: + 30 us per launch; one designated poller on the counter + flags: 33.4 us per launch.)
+      uint32_t* ctr = a.sync;
+      const uint32_t before = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((int32_t)(before + 1u - a.sync_target) >= 0) {  // the last workgroup of the launch: publish
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+          __hip_atomic_store(a.sync + 32 * (1 + g), a.sync_target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        const uint64_t t_start = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+        uint32_t* line = a.sync + 32 * (1 + (blockIdx.x & 7u));
+        while ((int32_t)(__hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.sync_target) < 0) {
+          __builtin_amdgcn_s_sleep(6);
+          if (__builtin_amdgcn_s_memrealtime() - t_start > 20000000ull) {  // 0.2 s: the grid is not resident at once
+            if (a.err) atomicOr(a.err, 4);
+            break;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // every row read of the step is behind us, chip-wide
+    apply_round();
+    for (int e0 = DU; e0 < n_list; e0 += DU) {
+      load_round(e0);
+      apply_round();
     }
   }
 }

@@ -164,7 +164,7 @@ class SparseScorerTrainer:
             return None
         if getattr(self, "sync", None) is None:
             import ctypes
-            self.sync = (torch.zeros(1, dtype=torch.int32, device=self.dev), ctypes.c_uint32(0))
+            self.sync = (torch.zeros(288, dtype=torch.int32, device=self.dev), ctypes.c_uint32(0))
         return self.sync
 
     def _stamps(self, n):
@@ -361,11 +361,18 @@ class SparseScorerTrainer:
             return
         if isinstance(ps, ops.EpochFlags):  # sparse regime: flags only, the flagged references follow K1 with atomics
             ids, udup, idup = ps.step_args(b_in_slice)
+            sy = self._sync()
+            arrivals = sy[1].value if sy else 0
             ops.train_steps_sgd(self.net.NET, self.net.tables(), None, None, 0, 0, 0, batch, n_steps, self.fast_lr, *ids,
                                 self.gz, self.du, loss_sums, self.err, self.scratch, self._stamps(n_steps), evs,
                                 user_dup=udup, item_dup=idup, ustage=self.ustage, loss=self.loss_id, sync=self._sync())
             if te is not None:
-                self._collect_events(te, ns, ("fwd_stage_kernel", "flagged_update_kernel", "event_overhead"))
+                # one launch per step (K1's own workgroups applied the flagged references: the library scheduled arrivals
+                # on the counter): the second interval holds no kernel either
+                one = sy is not None and sy[1].value != arrivals
+                self.one_launch = one
+                self._collect_events(te, ns, ("fwd_stage_kernel", "event_overhead_2" if one else "flagged_update_kernel",
+                                              "event_overhead"))
             return
         ids, sk, sv, udup, usorted, idup = ps.step_args(b_in_slice)
         idup = None  # dense regime / adaptive rules / metadata scorers: every item reference goes through the runs
