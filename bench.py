@@ -193,6 +193,94 @@ def time_pass(model, runner, B, D, R, dev):
     return res
 
 
+def build_model(config, n_inter, dev, rank=0, world=1):
+    """TorchRecSys over full-size tables of BASELINE configuration `config` with `n_inter` synthetic interactions of this
+    rank's shard resident in HBM."""
+    import contextlib
+    import io
+    from torchrecsys_amd.model import TorchRecSys
+    cfg = CONFIGS[config]
+    net, n_users, n_items, D = cfg["net"], cfg["n_users"], cfg["n_items"], cfg["D"]
+    users, items = synth_stream(n_users, n_items, n_inter, dev, seed=1000 + rank, rank=rank, world=world)
+    meta = None
+    if cfg["meta"]:  # one categorical id per item and column, every category present (SURVEY 8d)
+        g = torch.Generator(device=dev)
+        g.manual_seed(5)
+        cols = []
+        for nc in cfg["meta"]:
+            c = torch.randint(0, nc, (n_items,), device=dev, dtype=torch.int32, generator=g)
+            c[:nc] = torch.arange(nc, device=dev, dtype=torch.int32)
+            cols.append(c)
+        meta = torch.stack(cols, dim=1).contiguous()
+    with contextlib.redirect_stdout(io.StringIO()):
+        torch.manual_seed(7)
+        kw = dict(hidden_layers=cfg["hidden"]) if net == "mlp" else {}
+        model = TorchRecSys.from_tensors(users, items, n_users=n_users, n_items=n_items, item_metadata=meta,
+                                         n_factors=D, net_type=net, split_ratio=0.8, dynamic_neg_sampling=config != "c1",
+                                         use_amp=cfg["amp"], rng="device", seed=7 + rank, pre_sharded=True,
+                                         dp_partition="user", **kw)
+        # pre_sharded: every rank generated its own interaction shard, cut by user (each user row has one writer)
+    return model
+
+
+def mlp_gemm_roofline(cfg, gemm_events, timed_steps, ms_per_step):
+    """`roofline` of an MLP configuration: the GEMMs are the dominant kernels, bound by the matrix cores."""
+    M = len(cfg["meta"])
+    dims = [(2 + M) * cfg["D"]] + list(cfg["hidden"])
+    P = sum(a_ * b_ for a_, b_ in zip(dims[:-1], dims[1:])) + dims[-1]  # MACs per sample (SURVEY 8d)
+    ms = sum(e0.elapsed_time(e1) for e0, e1, _ in gemm_events)
+    fl = sum(f for _, _, f in gemm_events)
+    ach = fl / (ms * 1e-3) / 1e12
+    dtype = "bf16" if cfg["amp"] else "f32"
+    peak = MFMA_PEAK_TFLOPS[dtype]
+    return {"bound": "mfma", "kernel": ("gemm16_nt_glds_kernel (forward / input-gradient GEMMs) + gemm_bf16in_kernel (weight-gradient GEMMs)"
+                                        if cfg["amp"] else "gemm32_nt_glds_kernel / gemm_f32_kernel"),
+            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+            "gemm_launches_per_step": len(gemm_events) / timed_steps,
+            "gemm_ms_per_step": ms / timed_steps,
+            "gemm_share_of_step": (ms / timed_steps) / ms_per_step,
+            "timed_steps": timed_steps,
+            "algorithmic_flops_per_triple": 12 * P,
+            "whole_step_TFLOPs": 12.0 * P * cfg["B"] / (ms_per_step * 1e-3) / 1e12,
+            "note": "event intervals around the GEMM launches (HIP events on the launch stream) in an "
+                    "instrumented window right after the timed region; they include one event record each"}
+
+
+def mlp_leg(config, dev, steps=24, warmup=6, n_inter=6_000_000):
+    """MFMA evidence beside the HBM-bound default line (north_star: "MFMA utilisation (MLP GEMM) against gfx950 peak"): a
+    short window of BASELINE's MLP configuration `config` on full-size tables — `steps` timed steps through
+    FitRunner.run_steps (same bracket as the main line: synchronise on both sides), then an instrumented window with HIP
+    events around the GEMM launches.  The interaction shard is short (the step's cost does not depend on its length)."""
+    cfg = CONFIGS[config]
+    model = build_model(config, n_inter, dev)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+    runner = model.make_runner(opt, cfg["B"])
+    model.net.train()
+    full = runner.n_train // cfg["B"]
+    assert full >= warmup + steps + 16, "interaction shard too short for the MLP window"
+    runner.begin_epoch()
+    runner.run_steps(warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    runner.run_steps(steps)
+    torch.cuda.synchronize()
+    ms_per_step = 1e3 * (time.perf_counter() - t0) / steps
+    comp = model.net.compute
+    comp.gemm_events, comp.gemm_steps_seen, comp.gemm_steps_timed = [], 0, 0
+    runner.run_steps(15)  # one step in 5 carries events
+    torch.cuda.synchronize()
+    ev, timed = comp.gemm_events, max(comp.gemm_steps_timed, 1)
+    comp.gemm_events = None
+    runner.end_epoch()
+    r = mlp_gemm_roofline(cfg, ev, timed, ms_per_step)
+    peak = MFMA_PEAK_TFLOPS["bf16" if cfg["amp"] else "f32"]
+    return {"config": cfg["desc"], "dtype": "bf16" if cfg["amp"] else "f32", "steps": steps, "warmup": warmup,
+            "ms_per_step": ms_per_step, "interactions_per_s": 2.0 * cfg["B"] / (ms_per_step * 1e-3),
+            "gemm_TFLOPs": r["achieved"], "peak_TFLOPs": peak, "gemm_frac": r["frac"],
+            "whole_step_TFLOPs": r["whole_step_TFLOPs"], "whole_step_frac": r["whole_step_TFLOPs"] / peak,
+            "gemm_ms_per_step": r["gemm_ms_per_step"], "gemm_launches_per_step": r["gemm_launches_per_step"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,6 +294,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the instrumented window (no roofline)")
     ap.add_argument("--no-pass", action="store_true", help="skip the north-star pass measurement (no roofline_pass)")
+    ap.add_argument("--no-mlp", action="store_true",
+                    help="skip the MLP legs (roofline_mlp: short c5-shard and c3 windows after the default c4 line)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -232,28 +322,7 @@ def main():
     cfg = CONFIGS[args.config]
     net, n_users, n_items, n_inter, D, B, desc = (cfg[k] for k in ("net", "n_users", "n_items", "n", "D", "B", "desc"))
     dynamic = args.config != "c1"
-    users, items = synth_stream(n_users, n_items, n_inter, dev, seed=1000 + rank, rank=rank, world=world)
-    meta = None
-    if cfg["meta"]:  # one categorical id per item and column, every category present
-        g = torch.Generator(device=dev)
-        g.manual_seed(5)
-        cols = []
-        for nc in cfg["meta"]:
-            c = torch.randint(0, nc, (n_items,), device=dev, dtype=torch.int32, generator=g)
-            c[:nc] = torch.arange(nc, device=dev, dtype=torch.int32)
-            cols.append(c)
-        meta = torch.stack(cols, dim=1).contiguous()
-    import contextlib
-    import io
-    with contextlib.redirect_stdout(io.StringIO()):
-        torch.manual_seed(7)
-        kw = dict(hidden_layers=cfg["hidden"]) if net == "mlp" else {}
-        model = TorchRecSys.from_tensors(users, items, n_users=n_users, n_items=n_items, item_metadata=meta,
-                                         n_factors=D, net_type=net, split_ratio=0.8, dynamic_neg_sampling=dynamic,
-                                         use_amp=cfg["amp"], rng="device", seed=7 + rank, pre_sharded=True,
-                                         dp_partition="user", **kw)
-        # pre_sharded: every rank generated its own interaction shard, cut by user (each user row has one writer)
-    del users, items
+    model = build_model(args.config, n_inter, dev, rank, world)
     if args.optimizer == "sgd":
         opt = torch.optim.SGD(model.parameters(), lr=1e-2)
     elif args.optimizer == "sparse_adam":
@@ -379,24 +448,8 @@ def main():
         out["step_algorithmic_bytes_per_triple"] = step_bytes
     # ---- MLP: the GEMMs are the dominant kernels, bound by the matrix cores ----
     if gemm_events:
-        dims = [(2 + M) * D] + list(cfg["hidden"])
-        P = sum(a_ * b_ for a_, b_ in zip(dims[:-1], dims[1:])) + dims[-1]  # MACs per sample
-        timed_steps = max(model.net.compute.gemm_steps_timed, 1)  # the GEMMs of one step in 5 carry events
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in gemm_events)
-        fl = sum(f for _, _, f in gemm_events)
-        ach = fl / (ms * 1e-3) / 1e12
-        peak = MFMA_PEAK_TFLOPS[dtype]
-        out["roofline"] = {"bound": "mfma", "kernel": ("gemm16_nt_glds_kernel (forward / input-gradient GEMMs) + gemm_bf16in_kernel (weight-gradient GEMMs)"
-                                      if cfg["amp"] else "gemm_f32_kernel"),
-                           "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-                           "gemm_launches_per_step": len(gemm_events) / timed_steps,
-                           "gemm_ms_per_step": ms / timed_steps,
-                           "gemm_share_of_step": (ms / timed_steps) / (1e3 * elapsed / args.steps),
-                           "timed_steps": timed_steps,
-                           "algorithmic_flops_per_triple": 12 * P,
-                           "whole_step_TFLOPs": 12.0 * P * B * args.steps / elapsed / 1e12,
-                           "note": "event intervals around the GEMM launches (HIP events on the launch stream) in an "
-                                   "instrumented window right after the timed region; they include one event record each"}
+        out["roofline"] = mlp_gemm_roofline(cfg, gemm_events, max(model.net.compute.gemm_steps_timed, 1),
+                                            1e3 * elapsed / args.steps)
     # ---- roofline of the dominant kernel: algorithmic bytes per launch / mean launch duration (HIP events) ----
     if events:
         def _ms(rec):  # (TimingEvents, i, j) from the C step loop, or (torch start, torch end) from the generic path
@@ -478,6 +531,17 @@ def main():
                                "kind": "port",
                                "sample": f"{res['steps']} steps of batch {B} ({res['seconds']:.1f} s) on full-size "
                                          f"tables, {n_rows} synthetic interactions, oracle/cpu_fit.py"}
+    # ---- MFMA evidence in the same line (N = 1, default workload only): short windows of the two MLP configurations ----
+    if rank == 0 and world == 1 and args.config == "c4" and args.optimizer == "sgd" and not args.no_mlp:
+        del runner, opt, model
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        out["roofline_mlp"] = {}
+        for name in ("c5", "c3"):
+            out["roofline_mlp"][name] = mlp_leg(name, dev)
+            gc.collect()
+            torch.cuda.empty_cache()
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -23,6 +23,7 @@ def _free_port():
 
 
 def _worker(rank, world, port, net_type, n, ret, partition="user"):
+    os.environ["TRS_FLAG_ONE_LAUNCH"] = "0"  # two processes on one GPU (see test_bench_two_ranks_rehearsal_on_one_gpu)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
@@ -169,7 +170,9 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, TRS_BENCH_SHARE_DEVICE="1", TRS_DIST_BACKEND="gloo")
+    # (two processes computing on ONE GPU: the one-launch flag-mode step needs its whole grid resident at once, which two
+    # such grids plus their presort kernels are not — the documented setting for shared devices)
+    env = dict(os.environ, TRS_BENCH_SHARE_DEVICE="1", TRS_DIST_BACKEND="gloo", TRS_FLAG_ONE_LAUNCH="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "24",
            "--warmup", "8"]

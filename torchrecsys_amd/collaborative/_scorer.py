@@ -121,7 +121,14 @@ class SparseScorer(torch.nn.Module):
 
 
 def check_err_flag(err, what):
-    if int(err.item()) != 0:
+    code = int(err.item())
+    if code & 4:  # bit 2: csrc/fast_step.hip, the one-launch flag-mode step
+        err.zero_()
+        raise RuntimeError(f"{what}: the one-launch training step could not get all its workgroups resident on the GPU "
+                           "at once within 50 ms (another process is computing on the same device?); the step that "
+                           "timed out is not exact.  Set TRS_FLAG_ONE_LAUNCH=0 to run the step as two launches when "
+                           "several processes share one GPU.")
+    if code != 0:
         raise IndexError(f"index out of range in self ({what}: an id is outside its embedding table; ids must be "
                          f"dense 0..n-1 as in the reference, dataset/dataset.py:30-31,268-269)")
 

@@ -186,8 +186,8 @@ __device__ __forceinline__ void load_rows(TripleRows<VEC, K>& r, const trs_table
 // counter and waits until ALL workgroups of the launch have done so: from then on no row of the tables is read any more
 // by this step, so the float atomics of the flagged references — each workgroup re-reads the rows IT staged (same CU:
 // its own stores are visible to it) — may land.  What this replaces: a kernel boundary, a ramp, and the second launch's
-// detection pass over all 3B ids and flags for the 6 % of references that are flagged.  The wait is bounded (0.2 s of
-// s_memrealtime): a grid that cannot become resident raises err bit 2 instead of hanging.
+// detection pass over all 3B ids and flags for the 6 % of references that are flagged.  The wait is bounded (50 ms of
+// s_memrealtime): a grid that cannot become resident (another process on the same GPU) raises err bit 2 instead of hanging.
 constexpr int DEFER_ITERS = 8;  // iterations per lane group the per-wave list is sized for (launch_fwd_stage keeps to it)
 struct DeferEntry {
   uint32_t tw;   // (t << 2) | which      which: 0 user (row staged in du), 1 positive, 2 negative (row staged in ustage)
@@ -432,9 +432,12 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
       } else {
         const uint64_t t_start = __builtin_amdgcn_s_memrealtime();  // 100 MHz
         uint32_t* line = a.sync + 32 * (1 + (blockIdx.x & 7u));
+        // bounded wait: 50 ms — and none at all once a launch has timed out (err bit 2 is sticky until the host reads it:
+        // a run whose grids cannot be resident fails at its next error check, it does not spin 50 ms per step)
+        const uint64_t limit = (a.err && (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4)) ? 0ull : 5000000ull;
         while ((int32_t)(__hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.sync_target) < 0) {
           __builtin_amdgcn_s_sleep(6);
-          if (__builtin_amdgcn_s_memrealtime() - t_start > 20000000ull) {  // 0.2 s: the grid is not resident at once
+          if (__builtin_amdgcn_s_memrealtime() - t_start > limit) {  // the grid is not resident at once
             if (a.err) atomicOr(a.err, 4);
             break;
           }
