@@ -246,13 +246,13 @@ def mlp_gemm_roofline(cfg, gemm_events, timed_steps, ms_per_step):
                     "instrumented window right after the timed region; they include one event record each"}
 
 
-def mlp_leg(config, dev, steps=24, warmup=6, n_inter=6_000_000):
+def mlp_leg(config, dev, steps=24, warmup=6, n_extra=6_000_000):
     """MFMA evidence beside the HBM-bound default line (north_star: "MFMA utilisation (MLP GEMM) against gfx950 peak"): a
     short window of BASELINE's MLP configuration `config` on full-size tables — `steps` timed steps through
     FitRunner.run_steps (same bracket as the main line: synchronise on both sides), then an instrumented window with HIP
     events around the GEMM launches.  The interaction shard is short (the step's cost does not depend on its length)."""
     cfg = CONFIGS[config]
-    model = build_model(config, n_inter, dev)
+    model = build_model(config, cfg["n_users"] + n_extra, dev)  # (every user once + n_extra uniform interactions)
     opt = torch.optim.SGD(model.parameters(), lr=1e-2)
     runner = model.make_runner(opt, cfg["B"])
     model.net.train()
@@ -371,7 +371,7 @@ def main():
     timeline = None
     if os.environ.get("TRS_BENCH_TIMELINE") == "1":  # diagnostic: host time stamps of every C call of the timed region
         from torchrecsys_amd import ops as _ops
-        timeline = []
+        timeline = _ops.TIMELINE = []
         _orig_call = _ops.FlagStepCall.__call__
 
         def _stamped(self_, *a_, **k_):
@@ -380,6 +380,18 @@ def main():
             timeline.append(("ret", time.perf_counter()))
             return r_
         _ops.FlagStepCall.__call__ = _stamped
+        _orig_rs, _orig_ps = type(runner).run_steps, type(runner.trainer).presort_slice
+
+        def _rs(self_, *a_, **k_):
+            timeline.append(("run_steps", time.perf_counter()))
+            return _orig_rs(self_, *a_, **k_)
+
+        def _ps(self_, *a_, **k_):
+            timeline.append(("presort_slice", time.perf_counter()))
+            r_ = _orig_ps(self_, *a_, **k_)
+            timeline.append(("presort_ret", time.perf_counter()))
+            return r_
+        type(runner).run_steps, type(runner.trainer).presort_slice = _rs, _ps
     run(args.warmup)
     barrier()
     if timeline is not None:

@@ -88,7 +88,8 @@ const char* trs_last_error(void);
  *   1: round 1.   2: trs_train_steps_sgd takes a trs_train_args struct; trs_epoch_presort writes item-duplicate flags.
  *   3: trs_bn_relu_forward (running statistics, batch counter, output-layer dot) and trs_bn_relu_backward (outer-product
  *      form, outer_xw) grew arguments; trs_hinge_auc_backward, trs_f32_to_bf16_multi, trs_mlp_embed_sgd_update added.
- *   4: trs_sampler.seen_users (bounds of the seen CSR); trs_train_args.sync_dev (flag mode as one launch per step). */
+ *   4: trs_sampler.seen_users (bounds of the seen CSR); trs_train_args.sync_dev (flag mode as one launch per step);
+ *      trs_mlp_gather_gemm1_fwd added. */
 #define TRS_ABI_VERSION 4
 #define TRS_SYNC_WORDS 288
 int trs_abi_version(void);
@@ -430,6 +431,22 @@ int trs_topk(const float* scores_dev, int64_t n, int32_t k, int64_t* idx_out_dev
  * x_bf16_dev (bf16, RNE: the operand image of the bf16-resident GEMMs) — either may be NULL. */
 int trs_mlp_gather_concat(const trs_tables* tables, const trs_batch* batch, int32_t passes, float* x_dev,
                           void* x_bf16_dev, int64_t ld, void* stream);
+
+/* MLP layer 0 as ONE launch — the "concat-GEMM": y = [user[u] | item[i] | meta_m[..]] W^T + bias with the embedding gather
+ * inside the GEMM's A-operand load (replaces the gathers and the two torch.cat of collaborative/mlp.py:93-105 AND
+ * fcs[0] of :107; trs_mlp_gather_concat + trs_gemm_* remain for the shapes this entry point does not take).  Rows as in
+ * trs_mlp_gather_concat (passes == 2: positive pass then negative pass).  bf16 = 0: W (N, (2+M)D) fp32, y fp32 — the
+ * fp32-MFMA LDS-DMA kernel whose A pieces are addressed by id; bf16 = 1: W = the bf16 image of the weight, y fp32
+ * (y_dev) or bf16 (y_bf16_dev), fp32 accumulation — table rows rounded to bf16 (RNE) while they are staged.  bn_part as
+ * in trs_gemm_f32 (per 128-row chunk).  x_dev / x_bf16_dev (optional, row stride ldx): the x0 image (fp32 for bf16 = 0,
+ * bf16 for bf16 = 1) that the weight-gradient GEMM of the backward pass reads, written as a by-product by the workgroups
+ * of column block 0 — bit for bit what trs_mlp_gather_concat writes.
+ * Returns 0, a negative error, or 1 = shape not taken (int32 ids, B and N multiples of 256, D a multiple of 64 (bf16) /
+ * 32 (fp32), at least 256 tiles of 256 x 256, 16-byte aligned operands): nothing was launched. */
+int trs_mlp_gather_gemm1_fwd(const trs_tables* tables, const trs_batch* batch, int32_t passes, int32_t bf16,
+                             const void* W_dev, int64_t ldw, const float* bias_dev, int64_t N, float* y_dev,
+                             void* y_bf16_dev, int64_t ldy, float* bn_part_dev, float* x_dev, void* x_bf16_dev,
+                             int64_t ldx, void* stream);
 
 /* SGD on every embedding table of an MLP step, straight from d x0 = the input gradient of the first layer ((2B, ld);
  * rows [0,B) positive pass, [B,2B) negative pass; column block f = field f of x0; fp32 OR bf16 — exactly one of

@@ -1370,3 +1370,78 @@ def test_presort_generates_the_same_batches_as_batch_prepare():
         assert (np.diff(items) >= 0).all()
         exp = np.sort(np.concatenate([ps.ids[1][b * B:(b + 1) * B].cpu().numpy(), ps.ids[2][b * B:(b + 1) * B].cpu().numpy()]))
         assert np.array_equal(items, exp)
+
+
+@pytest.mark.parametrize("bf16,D,M,N,B,passes,out16", [(False, 64, 1, 1024, 8192, 2, False), (False, 128, 0, 512, 16384, 2, False),
+                                                       (True, 64, 1, 1024, 8192, 2, True), (True, 128, 2, 512, 16384, 2, False),
+                                                       (True, 256, 0, 1024, 16384, 1, True)])
+def test_gather_fused_first_layer_gemm_equals_gather_then_gemm(bf16, D, M, N, B, passes, out16):
+    """trs_mlp_gather_gemm1_fwd (the "concat-GEMM": embedding gather inside the first layer's A-operand load, reference
+    collaborative/mlp.py:93-107) == trs_mlp_gather_concat followed by the GEMM of the same family, BIT FOR BIT: y, the
+    BatchNorm chunk partials, and the x0 image written as a by-product (fp32 / bf16 RNE).  Ids with duplicates, both
+    passes, metadata columns with a stride; an id outside its table raises the error flag without touching memory
+    outside the tables."""
+    ops = _ops()
+    g = torch.Generator(device=DEV)
+    g.manual_seed(D + N + M)
+    NU, NI, cats = 50_000, 20_000, [997, 31][:M]
+    tabs = [torch.randn(NU, D, device=DEV, generator=g), torch.randn(NI, D, device=DEV, generator=g)] + \
+           [torch.randn(c, D, device=DEV, generator=g) for c in cats]
+    K = (2 + M) * D
+    W = torch.randn(N, K, device=DEV, generator=g) / K ** 0.5
+    bias = torch.randn(N, device=DEV, generator=g)
+    ids = {"user": torch.randint(0, NU, (B,), device=DEV, dtype=torch.int32, generator=g),
+           "pos": torch.randint(0, NI, (B,), device=DEV, dtype=torch.int32, generator=g),
+           "neg": torch.randint(0, NI, (B,), device=DEV, dtype=torch.int32, generator=g)}
+    ids["user"][:100] = 7  # duplicates
+    pm = nm = None
+    if M:
+        pm = torch.stack([torch.randint(0, c, (B,), device=DEV, dtype=torch.int32, generator=g) for c in cats], 1).contiguous()
+        nm = torch.stack([torch.randint(0, c, (B,), device=DEV, dtype=torch.int32, generator=g) for c in cats], 1).contiguous()
+    T, keep = ops.make_tables(tabs[0], tabs[1], None, None, tabs[2:], [])
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    Bt, keep2 = ops.make_batch(ids["user"], ids["pos"], ids["neg"] if passes == 2 else None, pm, nm if passes == 2 else None, err)
+    rows = passes * B
+    part_a = torch.zeros((rows // 128, 2, N), device=DEV)
+    part_b = torch.zeros_like(part_a)
+    if bf16:
+        W16 = W.bfloat16()
+        x_ref = torch.empty((rows, K), dtype=torch.bfloat16, device=DEV)
+        ops.mlp_gather_concat(T, Bt, passes, x16=x_ref)
+        y_ref = ops.gemm_bf16in(False, x_ref, W16, bias=bias, bn_part=part_a, out_bf16=out16)
+        x_img = torch.zeros_like(x_ref)
+        y = torch.zeros((rows, N), dtype=torch.bfloat16 if out16 else torch.float32, device=DEV)
+        assert ops.mlp_gather_gemm1(T, Bt, passes, W16, bias, y, part_b, x_img)
+    else:
+        x_ref = torch.empty((rows, K), device=DEV)
+        ops.mlp_gather_concat(T, Bt, passes, x_ref)
+        y_ref = ops.gemm(False, True, x_ref, W, bias=bias, bn_part=part_a)
+        x_img = torch.zeros_like(x_ref)
+        y = torch.zeros((rows, N), device=DEV)
+        assert ops.mlp_gather_gemm1(T, Bt, passes, W, bias, y, part_b, x_img)
+    torch.cuda.synchronize()
+    assert err.item() == 0
+    # x0 itself against torch indexing (the gather the reference does with nn.Embedding + torch.cat)
+    cols = [tabs[0][ids["user"].long()].repeat(passes, 1),
+            torch.cat([tabs[1][ids["pos"].long()]] + ([tabs[1][ids["neg"].long()]] if passes == 2 else []))]
+    for m in range(M):
+        cols.append(torch.cat([tabs[2 + m][pm[:, m].long()]] + ([tabs[2 + m][nm[:, m].long()]] if passes == 2 else [])))
+    want_x = torch.cat(cols, 1)
+    assert torch.equal(x_img, want_x.to(x_img.dtype)) and torch.equal(x_img, x_ref)
+    assert torch.equal(y, y_ref) and torch.equal(part_a, part_b)
+    # without the image (eval): the same y
+    y2 = torch.zeros_like(y)
+    assert ops.mlp_gather_gemm1(T, Bt, passes, W16 if bf16 else W, bias, y2, None, None)
+    assert torch.equal(y2, y)
+    # shapes the fused kernels do not take are refused without a launch (False), not run wrong
+    Bt_small, keep3 = ops.make_batch(ids["user"][:384], ids["pos"][:384], ids["neg"][:384] if passes == 2 else None,
+                                     None if pm is None else pm[:384].contiguous(),
+                                     None if (nm is None or passes == 1) else nm[:384].contiguous(), err)
+    assert not ops.mlp_gather_gemm1(T, Bt_small, passes, W16 if bf16 else W, bias, y[:passes * 384], None, None)
+    # an id outside its table: flagged, clamped (no fault)
+    bad = ids["pos"].clone()
+    bad[5] = NI + 3
+    Bt_bad, keep4 = ops.make_batch(ids["user"], bad, ids["neg"] if passes == 2 else None, pm, nm if passes == 2 else None, err)
+    assert ops.mlp_gather_gemm1(T, Bt_bad, passes, W16 if bf16 else W, bias, y2, None, None)
+    torch.cuda.synchronize()
+    assert err.item() == 1

@@ -147,6 +147,8 @@ PROTOTYPES = {
     "trs_topk_workspace_bytes": (C.c_int64, [_i64, _i32]),
     "trs_topk": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _i64, _vp]),
     "trs_mlp_gather_concat": (C.c_int, [_T, _Bp, _i32, _vp, _vp, _i64, _vp]),
+    "trs_mlp_gather_gemm1_fwd": (C.c_int, [_T, _Bp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64,
+                                           _vp]),
     "trs_mlp_embed_sgd_update_supported": (C.c_int, [_T]),
     "trs_mlp_embed_sgd_update": (C.c_int, [_T, _Bp, _vp, _vp, _i64, _f, _vp, _vp, _vp]),
     "trs_gemm_f32_workspace_bytes": (C.c_int64, [_i64, _i64, _i64]),

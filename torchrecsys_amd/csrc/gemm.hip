@@ -603,57 +603,13 @@ __device__ __forceinline__ void g3_piece(const unsigned short* __restrict__ A, c
   __builtin_amdgcn_global_load_lds((g3_gptr)src, (g3_lptr)(lds_buf + (isb ? G3_TILE : 0) + piece * 1024), 16, 0, 0);
 }
 
+// Epilogue of the 256 x 256 bf16 NT kernels (gemm16_nt_glds_kernel, gemm16_gather_nt_kernel): alpha * acc + bias, fp32 or
+// bf16 rows through the wave's own 16 KB of the dead operand buffers, BatchNorm partials per 128-row chunk.
 template <bool OUT16>
-__global__ __launch_bounds__(512) void gemm16_nt_glds_kernel(const Gemm16Args g) {
-  __shared__ __attribute__((aligned(1024))) char lds[4 * G3_TILE];  // [buffer][A | B], the only LDS object
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ void g3_epilogue(const Gemm16Args& g, f32x16 (&acc)[4][2], char* lds, int64_t m0, int64_t n0,
+                                            int by, int wave, int lane) {
   const int wm = wave >> 2, wn = wave & 3;
-  int64_t lid = blockIdx.x;
-  const int64_t nwg = gridDim.x;
-  if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);  // XCD-aware tile order (see gemm_f32_kernel)
-  const int bx = (int)(lid % g.gx), by = (int)(lid / g.gx);
-  const int64_t m0 = (int64_t)by * 256, n0 = (int64_t)bx * 256;
-  const int nk = (int)(g.K / BK2);
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int lr = lane & 31, lk = lane >> 5;
-  g3_stage(g.A, g.lda, m0, 0, lds, wave, lane);
-  g3_stage(g.B, g.ldb, n0, 0, lds + G3_TILE, wave, lane);
-  const int f = (lr >> 1) & 7;
-  for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();  // (drains this wave's LDS-DMA: vmcnt(0)) tile kt is in LDS, tile kt - 1 has been read by everyone
-    const int cur = kt & 1;
-    const bool more = kt + 1 < nk;
-    char* nxt = lds + (cur ^ 1) * 2 * G3_TILE;
-    const int64_t kn = (int64_t)(kt + 1) * BK2;
-    const char* ta = lds + cur * 2 * G3_TILE + (wm * 128 + lr) * 128;
-    const char* tb = lds + cur * 2 * G3_TILE + G3_TILE + (wn * 64 + lr) * 128;
-#pragma unroll
-    for (int ks = 0; ks < BK2 / 16; ++ks) {
-      const int sw = ((ks * 2 + lk) ^ f) << 4;
-      bf16x8 a[4], b[2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(ta + i * 32 * 128 + sw);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 128 + sw);
-      // the next tile's 8 LDS-DMA pieces of this wave go out two per k-step, behind the step's fragment reads: all 8 right
-      // after the barrier keep every wave's first reads and MFMAs waiting behind ~1000 cycles of DMA issue (fwd 1280 ->
-      // 1024: 181 -> 163 us; tools/micro/gemm16_bench.hip)
-      if (more) {
-        g3_piece(g.A, g.B, g.lda, g.ldb, m0, n0, kn, nxt, wave, lane, 2 * ks);
-        g3_piece(g.A, g.B, g.lda, g.ldb, m0, n0, kn, nxt, wave, lane, 2 * ks + 1);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-  }
   // Epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) — a lane holds
   // ONE column of 16 rows, so storing from the accumulators would issue 128 stores of 64-byte row pieces per wave.  The
   // operand buffers are dead: each wave transposes its tile through its own 16 KB of LDS, 64 rows at a time, and leaves
@@ -728,6 +684,187 @@ __global__ __launch_bounds__(512) void gemm16_nt_glds_kernel(const Gemm16Args g)
   }
 }
 
+template <bool OUT16>
+__global__ __launch_bounds__(512) void gemm16_nt_glds_kernel(const Gemm16Args g) {
+  __shared__ __attribute__((aligned(1024))) char lds[4 * G3_TILE];  // [buffer][A | B], the only LDS object
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  int64_t lid = blockIdx.x;
+  const int64_t nwg = gridDim.x;
+  if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);  // XCD-aware tile order (see gemm_f32_kernel)
+  const int bx = (int)(lid % g.gx), by = (int)(lid / g.gx);
+  const int64_t m0 = (int64_t)by * 256, n0 = (int64_t)bx * 256;
+  const int nk = (int)(g.K / BK2);
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int lr = lane & 31, lk = lane >> 5;
+  g3_stage(g.A, g.lda, m0, 0, lds, wave, lane);
+  g3_stage(g.B, g.ldb, n0, 0, lds + G3_TILE, wave, lane);
+  const int f = (lr >> 1) & 7;
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();  // (drains this wave's LDS-DMA: vmcnt(0)) tile kt is in LDS, tile kt - 1 has been read by everyone
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk;
+    char* nxt = lds + (cur ^ 1) * 2 * G3_TILE;
+    const int64_t kn = (int64_t)(kt + 1) * BK2;
+    const char* ta = lds + cur * 2 * G3_TILE + (wm * 128 + lr) * 128;
+    const char* tb = lds + cur * 2 * G3_TILE + G3_TILE + (wn * 64 + lr) * 128;
+#pragma unroll
+    for (int ks = 0; ks < BK2 / 16; ++ks) {
+      const int sw = ((ks * 2 + lk) ^ f) << 4;
+      bf16x8 a[4], b[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(ta + i * 32 * 128 + sw);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 128 + sw);
+      // the next tile's 8 LDS-DMA pieces of this wave go out two per k-step, behind the step's fragment reads: all 8 right
+      // after the barrier keep every wave's first reads and MFMAs waiting behind ~1000 cycles of DMA issue (fwd 1280 ->
+      // 1024: 181 -> 163 us; tools/micro/gemm16_bench.hip)
+      if (more) {
+        g3_piece(g.A, g.B, g.lda, g.ldb, m0, n0, kn, nxt, wave, lane, 2 * ks);
+        g3_piece(g.A, g.B, g.lda, g.ldb, m0, n0, kn, nxt, wave, lane, 2 * ks + 1);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  g3_epilogue<OUT16>(g, acc, lds, m0, n0, by, wave, lane);
+}
+
+// ---- MLP layer 0 with the embedding gather INSIDE the GEMM's A-operand load (the "concat-GEMM" of BASELINE.json's
+// north_star; reference collaborative/mlp.py:93-105: three / five nn.Embedding gathers, two torch.cat, then fcs[0]).
+// Row r of the virtual A = x0 is [user[u] | item[i] | meta_1[..] ...]: a k-tile lies inside ONE field (D a multiple of the
+// tile depth), so the tile's rows come straight from that field's table, addressed by the ids of the workgroup's 256
+// rows (validated once, kept in LDS).  No gather kernel, no read of a materialised x0 by this GEMM; the x0 image the
+// weight-gradient GEMM reads later is written by the column-block-0 workgroups from what they staged anyway.
+constexpr int GATHER_FIELDS = 2 + TRS_MAX_META;
+struct GatherSrc {
+  const float* tab[GATHER_FIELDS];
+  const int32_t* ids[2][GATHER_FIELDS];  // [pass][field]: int32 ids of the pass's B rows
+  int32_t stride[GATHER_FIELDS];         // id stride (metadata ids are (B, M) row-major)
+  int64_t n_rows[GATHER_FIELDS];
+  int64_t B;
+  int32_t D, F;
+  int32_t* err;
+};
+
+// ids of the workgroup's 256 rows (row r of the stacked passes: pass = r >= B) -> LDS, out-of-range ids clamped to row 0
+// and reported; table base pointers -> LDS (a field index that changes with the k-tile would otherwise index the kernel
+// argument struct dynamically)
+__device__ __forceinline__ void gather_ids_to_lds(const GatherSrc& S, int64_t m0, int32_t* s_ids, const float** s_tab,
+                                                  int tid) {
+  for (int i = tid; i < S.F * 256; i += 512) {
+    const int f = i >> 8, row = i & 255;
+    const int64_t r = m0 + row;
+    const int pass = r >= S.B;
+    const int64_t t = pass ? r - S.B : r;
+    int32_t id = S.ids[pass][f][t * S.stride[f]];
+    if ((uint64_t)(int64_t)id >= (uint64_t)S.n_rows[f]) {
+      id = 0;
+      if (S.err) atomicOr(S.err, 1);
+    }
+    s_ids[i] = id;
+  }
+  if (tid < S.F) s_tab[tid] = S.tab[tid];
+}
+
+// bf16-resident form: B (the bf16 weight image) by LDS-DMA as in gemm16_nt_glds_kernel; A register-staged — a thread
+// loads the 32 bytes of fp32 behind each of its four 16-byte bf16 chunks of the next k-tile at the top of the current
+// tile (in flight under the MFMAs), rounds them (RNE: v_cvt_pk_bf16_f32, the rounding of the gather kernel it replaces)
+// and writes them into the swizzled LDS image the fragment reads expect — and, in column block 0, into the x0 image.
+template <bool OUT16>
+__global__ __launch_bounds__(512) void gemm16_gather_nt_kernel(const Gemm16Args g, const GatherSrc S,
+                                                              unsigned short* __restrict__ x16, int64_t ldx) {
+  __shared__ __attribute__((aligned(1024))) char lds[4 * G3_TILE];
+  __shared__ int32_t s_ids[GATHER_FIELDS * 256];
+  __shared__ const float* s_tab[GATHER_FIELDS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  int64_t lid = blockIdx.x;
+  const int64_t nwg = gridDim.x;
+  if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);  // XCD-aware tile order (see gemm_f32_kernel)
+  const int bx = (int)(lid % g.gx), by = (int)(lid / g.gx);
+  const int64_t m0 = (int64_t)by * 256, n0 = (int64_t)bx * 256;
+  const int nk = (int)(g.K / BK2);
+  gather_ids_to_lds(S, m0, s_ids, s_tab, tid);
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int lr = lane & 31, lk = lane >> 5;
+  const int D = S.D;
+  const bool image = x16 != nullptr && bx == 0;
+  // chunk c = tid + 512 * it: row = c >> 3 = (tid >> 3) + 64 * it, 16-byte bf16 chunk kc = c & 7 = tid & 7 of the row's 64 k
+  const int kc = tid & 7, r0 = tid >> 3;
+  f32x4 ra[4][2];
+  auto a_issue = [&](int kt) {
+    const int k0 = kt * BK2, f = k0 / D, off = k0 - f * D + kc * 8;
+    const float* tab = s_tab[f];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const float* p = tab + (int64_t)s_ids[f * 256 + r0 + 64 * it] * D + off;
+      ra[it][0] = *reinterpret_cast<const f32x4*>(p);
+      ra[it][1] = *reinterpret_cast<const f32x4*>(p + 4);
+    }
+  };
+  auto a_commit = [&](char* tile, int kt) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = r0 + 64 * it;
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = (__bf16)ra[it][0][e];
+        v[4 + e] = (__bf16)ra[it][1][e];
+      }
+      *reinterpret_cast<bf16x8*>(tile + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4)) = v;
+      if (image) *reinterpret_cast<bf16x8*>(x16 + (m0 + row) * ldx + (int64_t)kt * BK2 + kc * 8) = v;
+    }
+  };
+  __syncthreads();  // ids and table pointers are in LDS
+  a_issue(0);
+  g3_stage(g.B, g.ldb, n0, 0, lds + G3_TILE, wave, lane);
+  a_commit(lds, 0);
+  const int fsw = (lr >> 1) & 7;
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();  // tile kt is in LDS (A: ds_write, B: LDS-DMA), tile kt - 1 has been read by everyone
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk;
+    char* nxt = lds + (cur ^ 1) * 2 * G3_TILE;
+    const int64_t kn = (int64_t)(kt + 1) * BK2;
+    const char* ta = lds + cur * 2 * G3_TILE + (wm * 128 + lr) * 128;
+    const char* tb = lds + cur * 2 * G3_TILE + G3_TILE + (wn * 64 + lr) * 128;
+    a_issue(more ? kt + 1 : kt);  // (unconditional: a load under a branch drains the queue at the join)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < BK2 / 16; ++ks) {
+      const int sw = ((ks * 2 + lk) ^ fsw) << 4;
+      bf16x8 a[4], b[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(ta + i * 32 * 128 + sw);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 128 + sw);
+      if (more) g3_piece(g.A, g.B, g.lda, g.ldb, m0, n0, kn, nxt, wave, lane, 4 + ks);  // B: one DMA piece per k-step
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) a_commit(nxt, kt + 1);
+  }
+  g3_epilogue<OUT16>(g, acc, lds, m0, n0, by, wave, lane);
+}
+
 // ---- fp32 NT form on the LDS-DMA structure: C(M,N) = alpha * A(M,K) B(N,K)^T (+ bias), both operands k-contiguous
 // (forward y = x W^T; input gradient dx = dy W through a transposed copy of W).  A tile row = 32 floats = 128 bytes — the
 // byte geometry of the bf16 kernel above, so the DMA pieces, the swizzle and the epilogue are the same; a fragment read
@@ -743,8 +880,21 @@ __device__ __forceinline__ void g32_piece(const float* __restrict__ P, int64_t l
   __builtin_amdgcn_global_load_lds((g3_gptr)src, (g3_lptr)(lds_tile + piece * 1024), 16, 0, 0);
 }
 
-template <int BNT>
-__global__ __launch_bounds__(512) void gemm32_nt_glds_kernel(const GemmArgs g) {
+// GATHER: A = the concatenated embedding rows of MLP layer 0, fetched by id from the tables (GatherSrc above) — the DMA
+// piece of a tile row takes its source address from the row's id instead of a row stride; the column-block-0 workgroups
+// copy every landed A tile to the fp32 x0 image the weight-gradient GEMM reads (four ds_read_b128 + 16-byte stores per
+// wave and k-tile).
+__device__ __forceinline__ void g32_piece_gather(const float* const* s_tab, const int32_t* s_ids, int D, int k0,
+                                                 char* lds_tile, int piece, int lane) {
+  const int row = piece * 8 + (lane >> 3);
+  const int f = k0 / D, off = k0 - f * D;
+  const float* src = s_tab[f] + (int64_t)s_ids[f * 256 + row] * D + off + (((lane & 7) ^ ((row >> 1) & 7)) << 2);
+  __builtin_amdgcn_global_load_lds((g3_gptr)src, (g3_lptr)(lds_tile + piece * 1024), 16, 0, 0);
+}
+
+template <int BNT, bool GATHER = false>
+__global__ __launch_bounds__(512) void gemm32_nt_glds_kernel(const GemmArgs g, const GatherSrc S, float* __restrict__ ximg,
+                                                            int64_t ldx) {
   constexpr int WN = BNT / 64, WM = 8 / WN, TM = 256 / WM, MI = TM / 32;  // 2 x 4 of 128 x 64 | 4 x 2 of 64 x 64
   constexpr int TILE_A = 256 * 128, TILE_B = BNT * 128, STAGE = TILE_A + TILE_B;
   constexpr int PA = 32 / 8, PB = (BNT / 8) / 8;  // DMA pieces per wave and tile: A 4, B 4 | 2
@@ -766,8 +916,18 @@ __global__ __launch_bounds__(512) void gemm32_nt_glds_kernel(const GemmArgs g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int lr = lane & 31, lk = lane >> 5;
   const int f = (lr >> 1) & 7;
+  __shared__ int32_t s_ids[GATHER ? GATHER_FIELDS * 256 : 1];
+  __shared__ const float* s_tab[GATHER ? GATHER_FIELDS : 1];
+  if (GATHER) {
+    gather_ids_to_lds(S, m0, s_ids, s_tab, tid);
+    __syncthreads();
+  }
+  const bool image = GATHER && ximg != nullptr && bx == 0;
 #pragma unroll
-  for (int q = 0; q < PA; ++q) g32_piece(g.A, g.lda, m0, 0, lds, wave * PA + q, lane);
+  for (int q = 0; q < PA; ++q) {
+    if (GATHER) g32_piece_gather(s_tab, s_ids, S.D, 0, lds, wave * PA + q, lane);
+    else g32_piece(g.A, g.lda, m0, 0, lds, wave * PA + q, lane);
+  }
 #pragma unroll
   for (int q = 0; q < PB; ++q) g32_piece(g.B, g.ldb, n0, 0, lds + TILE_A, wave * PB + q, lane);
   for (int kt = 0; kt < nk; ++kt) {
@@ -778,6 +938,14 @@ __global__ __launch_bounds__(512) void gemm32_nt_glds_kernel(const GemmArgs g) {
     const int64_t kn = (int64_t)(kt + 1) * 32;
     const char* ta = lds + cur * STAGE + (wm * TM + lr) * 128;
     const char* tb = lds + cur * STAGE + TILE_A + (wn * 64 + lr) * 128;
+    if (image) {  // the landed A tile -> x0 image: LDS slot (lane & 7) of a row holds source chunk slot ^ ((row >> 1) & 7)
+#pragma unroll
+      for (int q = 0; q < PA; ++q) {
+        const int piece = wave * PA + q, row = piece * 8 + (lane >> 3);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(lds + cur * STAGE + piece * 1024 + lane * 16);
+        *reinterpret_cast<f32x4*>(ximg + (m0 + row) * ldx + (int64_t)kt * 32 + (((lane & 7) ^ ((row >> 1) & 7)) << 2)) = v;
+      }
+    }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {  // 16-byte chunk = 4 k
       const int sw = (c ^ f) << 4;
@@ -787,8 +955,10 @@ __global__ __launch_bounds__(512) void gemm32_nt_glds_kernel(const GemmArgs g) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f32x4*>(tb + j * 32 * 128 + sw);
       if (more) {  // the next tile's DMA pieces, one or two per chunk step, behind the fragment reads
-        if (c < PA) g32_piece(g.A, g.lda, m0, kn, nxt, wave * PA + c, lane);
-        else if (c - PA < PB) g32_piece(g.B, g.ldb, n0, kn, nxt + TILE_A, wave * PB + (c - PA), lane);
+        if (c < PA) {
+          if (GATHER) g32_piece_gather(s_tab, s_ids, S.D, (int)kn, nxt, wave * PA + c, lane);
+          else g32_piece(g.A, g.lda, m0, kn, nxt, wave * PA + c, lane);
+        } else if (c - PA < PB) g32_piece(g.B, g.ldb, n0, kn, nxt + TILE_A, wave * PB + (c - PA), lane);
       }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -1010,8 +1180,9 @@ static int gemm_impl(bool bf16, int transA, int transB, int64_t M, int64_t N, in
         (!bias_dev || true)) {
       g.gx = (int)(N / bnt); g.gy = (int)(M / 256);
       const dim3 grid3((unsigned)((int64_t)g.gx * g.gy));
-      if (bnt == 256) hipLaunchKernelGGL(gemm32_nt_glds_kernel<256>, grid3, dim3(512), 0, s, g);
-      else hipLaunchKernelGGL(gemm32_nt_glds_kernel<128>, grid3, dim3(512), 0, s, g);
+      const GatherSrc none = {};
+      if (bnt == 256) hipLaunchKernelGGL((gemm32_nt_glds_kernel<256, false>), grid3, dim3(512), 0, s, g, none, (float*)nullptr, (int64_t)0);
+      else hipLaunchKernelGGL((gemm32_nt_glds_kernel<128, false>), grid3, dim3(512), 0, s, g, none, (float*)nullptr, (int64_t)0);
       TRS_CHECK_LAUNCH("gemm32_nt_glds_kernel");
       return TRS_OK;
     }
@@ -1156,6 +1327,65 @@ extern "C" int trs_gemm_bf16in(int tn, int64_t M, int64_t N, int64_t K, float al
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(trs_grid((M * N + 3) / 4, 256)), dim3(256), 0, s, g.slabs, splits, M, N,
                        C_dev, ldc, alpha, beta, bias_dev);
     TRS_CHECK_LAUNCH("splitk_reduce_kernel");
+  }
+  return TRS_OK;
+}
+
+// MLP layer 0 forward with the gather fused into the GEMM (include/trs.h).  Returns 1 (not an error) when the shape is
+// not one the fused kernels take: the caller then runs trs_mlp_gather_concat + trs_gemm_*.
+extern "C" int trs_mlp_gather_gemm1_fwd(const trs_tables* tables, const trs_batch* batch, int32_t passes, int32_t bf16,
+                                        const void* W_dev, int64_t ldw, const float* bias_dev, int64_t N, float* y_dev,
+                                        void* y_bf16_dev, int64_t ldy, float* bn_part_dev, float* x_dev,
+                                        void* x_bf16_dev, int64_t ldx, void* stream) {
+  TRS_REQUIRE(tables && batch && W_dev && (y_dev || y_bf16_dev), "trs_mlp_gather_gemm1_fwd: NULL argument");
+  TRS_REQUIRE(passes == 1 || passes == 2, "trs_mlp_gather_gemm1_fwd: passes must be 1 or 2");
+  TRS_REQUIRE(tables->M >= 0 && tables->M <= TRS_MAX_META, "trs_mlp_gather_gemm1_fwd: bad M");
+  const int64_t B = batch->B, rows = (int64_t)passes * B;
+  const int D = tables->D, F = 2 + tables->M;
+  const int64_t K = (int64_t)F * D;
+  const int tile_k = bf16 ? BK2 : 32;
+  if (batch->idx_bytes != 4 || B <= 0 || B % 256 != 0 || D % tile_k != 0 || N % 256 != 0 ||
+      (rows / 256) * (N / 256) < 256 || !tables->user || !tables->item || (passes == 2 && !batch->neg) ||
+      (tables->M > 0 && (!batch->pos_meta || (passes == 2 && !batch->neg_meta))))
+    return 1;
+  if (bf16 ? (!y_bf16_dev && !y_dev) || (y_bf16_dev && y_dev) || x_dev : (!y_dev || y_bf16_dev || x_bf16_dev)) return 1;
+  const void* yp = bf16 && y_bf16_dev ? y_bf16_dev : (void*)y_dev;
+  if ((((uintptr_t)W_dev | (uintptr_t)yp | (uintptr_t)x_dev | (uintptr_t)x_bf16_dev) & 15) != 0 || ldw < K ||
+      ldw % 8 != 0 || ldy < N || ldy % 8 != 0 || ((x_dev || x_bf16_dev) && (ldx < K || ldx % 8 != 0)))
+    return 1;
+  GatherSrc S = {};
+  S.B = B; S.D = D; S.F = F; S.err = batch->err_flag_dev;
+  S.tab[0] = tables->user; S.n_rows[0] = tables->n_users; S.stride[0] = 1;
+  S.tab[1] = tables->item; S.n_rows[1] = tables->n_items; S.stride[1] = 1;
+  S.ids[0][0] = S.ids[1][0] = (const int32_t*)batch->user;
+  S.ids[0][1] = (const int32_t*)batch->pos;
+  S.ids[1][1] = (const int32_t*)batch->neg;
+  for (int m = 0; m < tables->M; ++m) {
+    if (!tables->meta[m] || ((uintptr_t)tables->meta[m] & 15) != 0) return 1;
+    S.tab[2 + m] = tables->meta[m]; S.n_rows[2 + m] = tables->n_meta[m]; S.stride[2 + m] = tables->M;
+    S.ids[0][2 + m] = (const int32_t*)batch->pos_meta + m;
+    S.ids[1][2 + m] = batch->neg_meta ? (const int32_t*)batch->neg_meta + m : nullptr;
+  }
+  if ((((uintptr_t)tables->user | (uintptr_t)tables->item) & 15) != 0) return 1;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)((rows / 256) * (N / 256)));
+  if (bf16) {
+    Gemm16Args g = {};
+    g.B = (const unsigned short*)W_dev; g.C = y_dev; g.bias = bias_dev;
+    g.M = rows; g.N = N; g.K = K; g.ldb = ldw; g.ldc = ldy; g.alpha = 1.f; g.beta = 0.f;
+    g.k_per_split = K; g.gx = (int)(N / 256); g.gy = (int)(rows / 256); g.splits = 1;
+    g.bn_part = bn_part_dev; g.C16 = (unsigned short*)y_bf16_dev;
+    if (g.C16) hipLaunchKernelGGL((gemm16_gather_nt_kernel<true>), grid, dim3(512), 0, s, g, S, (unsigned short*)x_bf16_dev, ldx);
+    else hipLaunchKernelGGL((gemm16_gather_nt_kernel<false>), grid, dim3(512), 0, s, g, S, (unsigned short*)x_bf16_dev, ldx);
+    TRS_CHECK_LAUNCH("gemm16_gather_nt_kernel");
+  } else {
+    GemmArgs g = {};
+    g.B = (const float*)W_dev; g.C = y_dev; g.bias = bias_dev;
+    g.M = rows; g.N = N; g.K = K; g.ldb = ldw; g.ldc = ldy; g.alpha = 1.f; g.beta = 0.f;
+    g.k_per_split = K; g.gx = (int)(N / 256); g.gy = (int)(rows / 256); g.splits = 1; g.vecA = g.vecB = 1;
+    g.bn_part = bn_part_dev;
+    hipLaunchKernelGGL((gemm32_nt_glds_kernel<256, true>), grid, dim3(512), 0, s, g, S, x_dev, ldx);
+    TRS_CHECK_LAUNCH("gemm32_nt_glds_kernel<gather>");
   }
   return TRS_OK;
 }

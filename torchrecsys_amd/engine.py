@@ -357,6 +357,7 @@ class SparseScorerTrainer:
             if fc is None or fc.batch != batch or fc.sig != sig:
                 fc = self._flag_call = ops.FlagStepCall(self.net.NET, T, batch, self.fast_lr, self.gz, self.du, self.err,
                                                         self.scratch, self.ustage, self.loss_id, self._sync())
+            ops.stamp("fast_sorted_steps:before_call")
             fc(ps, b_in_slice, n_steps, loss_sums, self._stamps(n_steps))
             return
         if isinstance(ps, ops.EpochFlags):  # sparse regime: flags only, the flagged references follow K1 with atomics

@@ -40,6 +40,9 @@ class MLPCompute:
         # half-precision x0 is): set by MLPTrainer when its fused SGD embedding update consumes it; the autograd bridge
         # and the per-table optimiser paths keep fp32
         self.dx0_bf16 = False
+        # layer 0 as one launch (gather inside the GEMM); TRS_MLP_FUSED_GATHER=0: gather-concat + GEMM (A/B knob, tests)
+        import os
+        self.fused_gather = os.environ.get("TRS_MLP_FUSED_GATHER", "1") != "0"
 
     def _resident(self, rows, training):
         """bf16-resident path: use_amp, training step, every GEMM of the net made of interior tiles."""
@@ -117,11 +120,13 @@ class MLPCompute:
         sync_fwd = bool(training and use_bn and self.sync_bn and tdist.world_info()[1] > 1)
         if res:
             self._refresh_weight_images()
-            x = torch.empty((rows, net.input_shape), dtype=torch.bfloat16, device=dev)
-            ops.mlp_gather_concat(net.tables(), Bt, passes, x16=x)
-        else:
-            x = torch.empty((rows, net.input_shape), dtype=torch.float32, device=dev)
-            ops.mlp_gather_concat(net.tables(), Bt, passes, x)
+        # x0 = the concatenated embedding rows.  Layer 0 runs as ONE launch when the shape allows (the gather inside the
+        # GEMM's A-operand load, ops.mlp_gather_gemm1 — it writes the x0 image the weight-gradient GEMM needs as a
+        # by-product, and only when there will be a backward pass); otherwise gather-concat, then the GEMM
+        x_dtype = torch.bfloat16 if res else torch.float32
+        need_x0 = training or L == 0
+        x = torch.empty((rows, net.input_shape), dtype=x_dtype, device=dev) if need_x0 else None
+        gathered = False  # x holds x0
         ctx = {"ids": ids, "B": B, "passes": passes, "x": [x], "y": [], "mean": [], "var": [], "training": training,
                "resident": res, "Bt": (Bt, keep), "sync": sync_fwd}
         tracked = []
@@ -135,13 +140,37 @@ class MLPCompute:
             if fuse_stats:
                 n_tiles = (rows + ops.GEMM_TILE_ROWS - 1) // ops.GEMM_TILE_ROWS
                 part = torch.empty((n_tiles, 2, fc.out_features), dtype=torch.float32, device=dev)
-            if res:
-                # y_l rounded to bf16 when its statistics come from the fp32 accumulators of the same launch (or there
-                # is no BatchNorm): what autocast's half-precision linear output is
-                y = self._gemm16(False, x, self.w16[l], bias=fc.bias.data, bn_part=part,
-                                 out_bf16=fuse_stats or not use_bn)
+            y = None
+            if l == 0 and self.fused_gather and ids["user"].dtype == torch.int32 and (res or not net.use_bf16):
+                # (int32 ids: what the device loader and the presort produce; the autograd bridge's int64 ids fall through)
+                y = torch.empty((rows, fc.out_features), device=dev,
+                                dtype=torch.bfloat16 if (res and (fuse_stats or not use_bn)) else torch.float32)
+                timed = self.gemm_events is not None and self._time_gemms
+                if timed:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                if not ops.mlp_gather_gemm1(net.tables(), Bt, passes, self.w16[0] if res else fc.weight.data, fc.bias.data,
+                                            y, part, x):
+                    y = None
+                elif timed:
+                    e1.record()
+                    self.gemm_events.append((e0, e1, 2.0 * rows * fc.out_features * net.input_shape))
+            if y is not None:
+                gathered = need_x0  # the fused launch wrote the x0 image (when one was asked for)
             else:
-                y = self._gemm(False, True, x, fc.weight.data, bias=fc.bias.data, bf16=net.use_bf16, bn_part=part)
+                if l == 0 and not gathered:
+                    if x is None:
+                        x = torch.empty((rows, net.input_shape), dtype=x_dtype, device=dev)
+                    ops.mlp_gather_concat(net.tables(), Bt, passes, **({"x16": x} if res else {"x": x}))
+                    gathered = True
+                    ctx["x"][0] = x
+                if res:
+                    # y_l rounded to bf16 when its statistics come from the fp32 accumulators of the same launch (or
+                    # there is no BatchNorm): what autocast's half-precision linear output is
+                    y = self._gemm16(False, x, self.w16[l], bias=fc.bias.data, bn_part=part,
+                                     out_bf16=fuse_stats or not use_bn)
+                else:
+                    y = self._gemm(False, True, x, fc.weight.data, bias=fc.bias.data, bf16=net.use_bf16, bn_part=part)
             ctx["y"].append(y)
             mean = var = gamma = beta = None
             stat_passes = 1
@@ -189,6 +218,7 @@ class MLPCompute:
         if tracked:  # BatchNorm1d.num_batches_tracked of every layer: + passes, one launch
             torch._foreach_add_(tracked, passes)
         if L == 0:
+            ops.mlp_gather_concat(net.tables(), Bt, passes, x)
             ops.rowdot(x, net.output_layer.weight.data.reshape(-1), net.output_layer.bias.data, out)
         return out, ctx
 

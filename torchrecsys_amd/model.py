@@ -595,6 +595,7 @@ class FitRunner:
         fast = (kind == "sgd" and not has_meta) or (kind is not None and self.trainer.wants_presort(B))
         if fast and m.rng == 'reference':
             fast = self.ep['user'].dtype == torch.int32
+        ops.stamp("run_steps:setup")
         if fast:  # whole batches, step loop in C (csrc/fast_step.hip): from the resident stream, or from the epoch's
             full = self.n_train // B  # host-prepared id arrays (bit-exact reference batches)
             presort = self.trainer.wants_presort(B)
@@ -613,6 +614,7 @@ class FitRunner:
                             self._presort(0, full, prefetch=True, next_epoch=True)
                     s0, ps = self._slice
                     n = min(n, s0 + ps.n_batches - b)
+                    ops.stamp("run_steps:before_fast_sorted_steps")
                     self.trainer.fast_sorted_steps(ps, b - s0, B, n, self.loss_sums[b:b + n],
                                                    m._item_meta_dev() if has_meta else None)
                 elif m.rng == 'device' and self.sampler is None:

@@ -382,6 +382,15 @@ def train_steps_sgd(net, T, stream_ui, neg_static, shuffle_key, sample_seed, fir
     check(_lib.load().trs_train_steps_sgd(C.byref(a), _stream()), "trs_train_steps_sgd")
 
 
+TIMELINE = None  # diagnostic (bench.py TRS_BENCH_TIMELINE=1): a list that receives (label, time.perf_counter()) stamps
+
+
+def stamp(label):
+    if TIMELINE is not None:
+        import time
+        TIMELINE.append((label, time.perf_counter()))
+
+
 class FlagStepCall:
     """trs_train_steps_sgd in flag mode (sparse regime) with the argument struct built ONCE: a call only writes the
     fields that change (step count, stamp, the slice offsets of ids / flags, the loss slot).  The generic wrapper above
@@ -519,6 +528,25 @@ def mlp_gather_concat(T, Bt, passes, x=None, x16=None):
         raise ValueError("mlp_gather_concat: x and x16 must share the row stride")
     check(_lib.load().trs_mlp_gather_concat(C.byref(T), C.byref(Bt), passes, ptr(x), ptr(x16), ld, _stream()),
           "trs_mlp_gather_concat")
+
+
+def mlp_gather_gemm1(T, Bt, passes, W, bias, y, bn_part=None, x_image=None):
+    """MLP layer 0 with the gather inside the GEMM (trs_mlp_gather_gemm1_fwd).  W: the fp32 weight (N, K) or its bfloat16
+    image; y: preallocated (rows, N) fp32 or bfloat16 output; x_image: optional (rows, K) buffer for the x0 image the
+    weight-gradient GEMM reads (fp32 with an fp32 W, bfloat16 with a bfloat16 W).  Returns False when the shape is not
+    one the fused kernels take (nothing launched: run mlp_gather_concat + gemm)."""
+    bf16 = W.dtype == torch.bfloat16
+    y32 = y if y.dtype == torch.float32 else None
+    y16 = y if y.dtype == torch.bfloat16 else None
+    x32 = x_image if (x_image is not None and x_image.dtype == torch.float32) else None
+    x16 = x_image if (x_image is not None and x_image.dtype == torch.bfloat16) else None
+    rc = _lib.load().trs_mlp_gather_gemm1_fwd(C.byref(T), C.byref(Bt), passes, int(bf16), ptr(W), W.stride(0), ptr(bias),
+                                              W.shape[0], ptr(y32), ptr(y16), y.stride(0), ptr(bn_part), ptr(x32),
+                                              ptr(x16), x_image.stride(0) if x_image is not None else 0, _stream())
+    if rc == 1:
+        return False
+    check(rc, "trs_mlp_gather_gemm1_fwd")
+    return True
 
 
 def mlp_embed_sgd_supported(T):
