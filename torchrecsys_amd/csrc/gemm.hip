@@ -758,7 +758,9 @@ struct GatherSrc {
 // ids of the workgroup's 256 rows (row r of the stacked passes: pass = r >= B) -> LDS, out-of-range ids clamped to row 0
 // and reported; table base pointers -> LDS (a field index that changes with the k-tile would otherwise index the kernel
 // argument struct dynamically)
-__device__ __forceinline__ void gather_ids_to_lds(const GatherSrc& S, int64_t m0, int32_t* s_ids, const float** s_tab,
+typedef const __attribute__((address_space(1))) float* gfloat_ptr;  // global loads, not flat ones (a flat load also
+// counts on lgkmcnt and is drained by every barrier's LDS wait)
+__device__ __forceinline__ void gather_ids_to_lds(const GatherSrc& S, int64_t m0, int32_t* s_ids, gfloat_ptr* s_tab,
                                                   int tid) {
   for (int i = tid; i < S.F * 256; i += 512) {
     const int f = i >> 8, row = i & 255;
@@ -772,7 +774,7 @@ __device__ __forceinline__ void gather_ids_to_lds(const GatherSrc& S, int64_t m0
     }
     s_ids[i] = id;
   }
-  if (tid < S.F) s_tab[tid] = S.tab[tid];
+  if (tid < S.F) s_tab[tid] = (gfloat_ptr)S.tab[tid];
 }
 
 // bf16-resident form: B (the bf16 weight image) by LDS-DMA as in gemm16_nt_glds_kernel; A register-staged — a thread
@@ -782,9 +784,12 @@ __device__ __forceinline__ void gather_ids_to_lds(const GatherSrc& S, int64_t m0
 template <bool OUT16>
 __global__ __launch_bounds__(512) void gemm16_gather_nt_kernel(const Gemm16Args g, const GatherSrc S,
                                                               unsigned short* __restrict__ x16, int64_t ldx) {
-  __shared__ __attribute__((aligned(1024))) char lds[4 * G3_TILE];
-  __shared__ int32_t s_ids[GATHER_FIELDS * 256];
-  __shared__ const float* s_tab[GATHER_FIELDS];
+  // ONE LDS object (tiles | ids | table pointers): with several, the compiler can no longer tell the LDS-DMA's target
+  // from the other LDS accesses and puts s_waitcnt vmcnt(0) behind every DMA piece (each piece then waits for its own
+  // landing, and for the A loads in flight)
+  __shared__ __attribute__((aligned(1024))) char lds[4 * G3_TILE + GATHER_FIELDS * 256 * 4 + GATHER_FIELDS * 8];
+  int32_t* s_ids = reinterpret_cast<int32_t*>(lds + 4 * G3_TILE);
+  gfloat_ptr* s_tab = reinterpret_cast<gfloat_ptr*>(lds + 4 * G3_TILE + GATHER_FIELDS * 256 * 4);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;
   int64_t lid = blockIdx.x;
@@ -809,15 +814,16 @@ __global__ __launch_bounds__(512) void gemm16_gather_nt_kernel(const Gemm16Args 
   f32x4 ra[4][2];
   auto a_issue = [&](int kt) {
     const int k0 = kt * BK2, f = k0 / D, off = k0 - f * D + kc * 8;
-    const float* tab = s_tab[f];
+    const gfloat_ptr tab = s_tab[f];
+    typedef const __attribute__((address_space(1))) f32x4* gvec_ptr;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      const float* p = tab + (int64_t)s_ids[f * 256 + r0 + 64 * it] * D + off;
-      ra[it][0] = *reinterpret_cast<const f32x4*>(p);
-      ra[it][1] = *reinterpret_cast<const f32x4*>(p + 4);
+      const gfloat_ptr p = tab + (int64_t)s_ids[f * 256 + r0 + 64 * it] * D + off;
+      ra[it][0] = *(gvec_ptr)p;
+      ra[it][1] = *(gvec_ptr)(p + 4);
     }
   };
-  auto a_commit = [&](char* tile, int kt) {
+  auto a_commit = [&](char* tile, int kt, bool img) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int row = r0 + 64 * it;
@@ -827,25 +833,37 @@ __global__ __launch_bounds__(512) void gemm16_gather_nt_kernel(const Gemm16Args 
         v[e] = (__bf16)ra[it][0][e];
         v[4 + e] = (__bf16)ra[it][1][e];
       }
-      *reinterpret_cast<bf16x8*>(tile + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4)) = v;
-      if (image) *reinterpret_cast<bf16x8*>(x16 + (m0 + row) * ldx + (int64_t)kt * BK2 + kc * 8) = v;
+      // (inline asm: a ds_write the compiler can see is ordered behind the LDS-DMA pieces just issued for the same buffer —
+      // it cannot tell the A half from the B half — i.e. s_waitcnt vmcnt(0) in front of the commit, which exposes the
+      // DMA's whole latency every k-tile; the barrier's lgkmcnt(0) covers this write)
+      const uint32_t la = (uint32_t)(uintptr_t)(g3_lptr)(tile + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+      asm volatile("ds_write_b128 %0, %1" ::"v"(la), "v"(__builtin_bit_cast(i32x4, v)) : "memory");
+      if (img) *reinterpret_cast<bf16x8*>(x16 + (m0 + row) * ldx + (int64_t)kt * BK2 + kc * 8) = v;
     }
   };
   __syncthreads();  // ids and table pointers are in LDS
   a_issue(0);
   g3_stage(g.B, g.ldb, n0, 0, lds + G3_TILE, wave, lane);
-  a_commit(lds, 0);
+  a_commit(lds, 0, image);
+  // The loads of tile t+1 are issued right after tile t was committed — a whole iteration (barrier, MFMA block) before
+  // their own commit.  Issued at the top of tile t instead (one MFMA block, ~0.9 us, ahead) they stalled every k-tile
+  // by ~1.2 us: a random table row from HBM takes longer than that under load (c5's first layer: 290 against 195 us for
+  // the LDS-DMA kernel on a materialised x0).  Pulling tile t+2 into L2 by 4-byte LDS-DMAs into a sink was slower still
+  // (+60 us per step: the DMA issue slots).
+  a_issue(nk > 1 ? 1 : 0);
   const int fsw = (lr >> 1) & 7;
   for (int kt = 0; kt < nk; ++kt) {
+    // Everything older than the 8 A loads issued last (this wave's LDS-DMA pieces and image stores of the previous
+    // iteration) has landed; the A loads stay in flight across the barrier.  Explicit: the compiler orders an LDS-DMA
+    // only against THIS wave's later LDS accesses, the barrier needs it for the other waves' reads.
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __syncthreads();  // tile kt is in LDS (A: ds_write, B: LDS-DMA), tile kt - 1 has been read by everyone
     const int cur = kt & 1;
     const bool more = kt + 1 < nk;
     char* nxt = lds + (cur ^ 1) * 2 * G3_TILE;
-    const int64_t kn = (int64_t)(kt + 1) * BK2;
+    const int64_t kn = (int64_t)(more ? kt + 1 : kt) * BK2;
     const char* ta = lds + cur * 2 * G3_TILE + (wm * 128 + lr) * 128;
     const char* tb = lds + cur * 2 * G3_TILE + G3_TILE + (wn * 64 + lr) * 128;
-    a_issue(more ? kt + 1 : kt);  // (unconditional: a load under a branch drains the queue at the join)
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < BK2 / 16; ++ks) {
       const int sw = ((ks * 2 + lk) ^ fsw) << 4;
@@ -854,13 +872,25 @@ __global__ __launch_bounds__(512) void gemm16_gather_nt_kernel(const Gemm16Args 
       for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(ta + i * 32 * 128 + sw);
 #pragma unroll
       for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(tb + j * 32 * 128 + sw);
-      if (more) g3_piece(g.A, g.B, g.lda, g.ldb, m0, n0, kn, nxt, wave, lane, 4 + ks);  // B: one DMA piece per k-step
+      // B: its four DMA pieces in the first two k-steps — the commit below waits for EVERYTHING in flight (the compiler
+      // cannot count the A loads across the loop's back edge and emits vmcnt(0)), so the pieces should have landed by
+      // then (the weights come from L2).  Nothing in this loop sits under a branch: at the join of a conditional block
+      // the compiler waits for every load in flight too, which would drain the A loads at the first k-step; the last
+      // iteration re-stages its own tile into the dead buffer instead
+      if (ks < 2) {
+        g3_piece(g.A, g.B, g.lda, g.ldb, m0, n0, kn, nxt, wave, lane, 4 + 2 * ks);
+        g3_piece(g.A, g.B, g.lda, g.ldb, m0, n0, kn, nxt, wave, lane, 5 + 2 * ks);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (more) a_commit(nxt, kt + 1);
+    __builtin_amdgcn_sched_barrier(0);  // (the conversion of the staged A rows stays behind the MFMA block ...
+    a_commit(nxt, more ? kt + 1 : kt, image && more);  // (last iteration: its own tile again, into the dead buffer)
+    __builtin_amdgcn_sched_barrier(0);  // ... and the next loads behind the commit that frees their registers)
+    a_issue(kt + 2 < nk ? kt + 2 : nk - 1);
+    __builtin_amdgcn_sched_barrier(0);
   }
   g3_epilogue<OUT16>(g, acc, lds, m0, n0, by, wave, lane);
 }
@@ -884,11 +914,11 @@ __device__ __forceinline__ void g32_piece(const float* __restrict__ P, int64_t l
 // piece of a tile row takes its source address from the row's id instead of a row stride; the column-block-0 workgroups
 // copy every landed A tile to the fp32 x0 image the weight-gradient GEMM reads (four ds_read_b128 + 16-byte stores per
 // wave and k-tile).
-__device__ __forceinline__ void g32_piece_gather(const float* const* s_tab, const int32_t* s_ids, int D, int k0,
+__device__ __forceinline__ void g32_piece_gather(const gfloat_ptr* s_tab, const int32_t* s_ids, int D, int k0,
                                                  char* lds_tile, int piece, int lane) {
   const int row = piece * 8 + (lane >> 3);
   const int f = k0 / D, off = k0 - f * D;
-  const float* src = s_tab[f] + (int64_t)s_ids[f * 256 + row] * D + off + (((lane & 7) ^ ((row >> 1) & 7)) << 2);
+  const gfloat_ptr src = s_tab[f] + (int64_t)s_ids[f * 256 + row] * D + off + (((lane & 7) ^ ((row >> 1) & 7)) << 2);
   __builtin_amdgcn_global_load_lds((g3_gptr)src, (g3_lptr)(lds_tile + piece * 1024), 16, 0, 0);
 }
 
@@ -898,7 +928,9 @@ __global__ __launch_bounds__(512) void gemm32_nt_glds_kernel(const GemmArgs g, c
   constexpr int WN = BNT / 64, WM = 8 / WN, TM = 256 / WM, MI = TM / 32;  // 2 x 4 of 128 x 64 | 4 x 2 of 64 x 64
   constexpr int TILE_A = 256 * 128, TILE_B = BNT * 128, STAGE = TILE_A + TILE_B;
   constexpr int PA = 32 / 8, PB = (BNT / 8) / 8;  // DMA pieces per wave and tile: A 4, B 4 | 2
-  __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE > 8 * 16384 ? 2 * STAGE : 8 * 16384];
+  constexpr int LDS_TILES = 2 * STAGE > 8 * 16384 ? 2 * STAGE : 8 * 16384;
+  // (ONE LDS object: see gemm16_gather_nt_kernel)
+  __shared__ __attribute__((aligned(1024))) char lds[LDS_TILES + (GATHER ? GATHER_FIELDS * 256 * 4 + GATHER_FIELDS * 8 : 0)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   int64_t lid = blockIdx.x;
@@ -916,8 +948,8 @@ __global__ __launch_bounds__(512) void gemm32_nt_glds_kernel(const GemmArgs g, c
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int lr = lane & 31, lk = lane >> 5;
   const int f = (lr >> 1) & 7;
-  __shared__ int32_t s_ids[GATHER ? GATHER_FIELDS * 256 : 1];
-  __shared__ const float* s_tab[GATHER ? GATHER_FIELDS : 1];
+  int32_t* s_ids = reinterpret_cast<int32_t*>(lds + LDS_TILES);
+  gfloat_ptr* s_tab = reinterpret_cast<gfloat_ptr*>(lds + LDS_TILES + GATHER_FIELDS * 256 * 4);
   if (GATHER) {
     gather_ids_to_lds(S, m0, s_ids, s_tab, tid);
     __syncthreads();
