@@ -150,10 +150,10 @@ struct TripleRows {
   float uls1, uls2;
 };
 
-template <int VEC, int G, int K, bool FULL, int OPT>
+template <int VEC, int G, int K, bool FULL, int OPT, int NTU = 0>
 __device__ __forceinline__ void load_rows(TripleRows<VEC, K>& r, const trs_tables& T, const OptArgs& o,
                                           const TripleIds& id, int lig) {
-  row_load<VEC, G, K, FULL>(r.u, T.user, id.u, T.D, lig);
+  row_load<VEC, G, K, FULL, (NTU & 1) != 0>(r.u, T.user, id.u, T.D, lig);
   row_load<VEC, G, K, FULL>(r.pi, T.item, id.p, T.D, lig);
   row_load<VEC, G, K, FULL>(r.ni, T.item, id.n, T.D, lig);
   r.ul = T.user_lin[id.u];
@@ -196,7 +196,10 @@ struct DeferEntry {
   float clin;    // increment of the row's 1-wide term
 };
 
-template <int NET, int VEC, int G, int K, int SRC, bool FULL, int INL, int OPT = OPT_SGD>
+// NTU (INL 3): bit 0 = the user row is loaded nontemporally, bit 1 = the updated user row is stored nontemporally — user
+// tables far beyond the Infinity Cache (c4: 5.1 GB) are read and written once per epoch per row; keeping them out leaves
+// the cache to the item table, whose rows do come back (launch_fwd_stage decides by table size).
+template <int NET, int VEC, int G, int K, int SRC, bool FULL, int INL, int OPT = OPT_SGD, int NTU = 0>
 __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) {
   constexpr int N = K * VEC;
   constexpr int TPW = TRS_WAVE / G;
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
           if (OPT == OPT_SGD) {
 #pragma unroll
             for (int n = 0; n < N; ++n) un.v[n] = r.u.v[n] + (-a.lr) * g.v[n];
-            row_store<VEC, G, K>(un, T.user + id.u * (int64_t)D, D, lig);
+            row_store<VEC, G, K, (NTU & 2) != 0>(un, T.user + id.u * (int64_t)D, D, lig);
             if (lig == 0) T.user_lin[id.u] = r.ul + (-a.lr) * (gp + gn);
           } else {
 #pragma unroll
@@ -351,16 +354,16 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
   TripleIds idE = finalize_ids<SRC>(a, wE);
   TripleIds idO;
   TripleRows<VEC, K> rE, rO;
-  load_rows<VEC, G, K, FULL, OPT>(rE, T, a.o, idE, lig);
+  load_rows<VEC, G, K, FULL, OPT, NTU>(rE, T, a.o, idE, lig);
   for (int64_t it = 0; it < niter2; it += 2) {
     wE = issue_ids<SRC, INL>(a, t + 2 * stride);
     idO = finalize_ids<SRC>(a, wO);
-    load_rows<VEC, G, K, FULL, OPT>(rO, T, a.o, idO, lig);
+    load_rows<VEC, G, K, FULL, OPT, NTU>(rO, T, a.o, idO, lig);
     reduce(rE, idE, t);
 
     wO = issue_ids<SRC, INL>(a, t + 3 * stride);
     idE = finalize_ids<SRC>(a, wE);
-    load_rows<VEC, G, K, FULL, OPT>(rE, T, a.o, idE, lig);
+    load_rows<VEC, G, K, FULL, OPT, NTU>(rE, T, a.o, idE, lig);
     reduce(rO, idO, t + stride);
     t += 2 * stride;
   }
@@ -854,7 +857,7 @@ __global__ __launch_bounds__(TRS_BLOCK) void user_update_kernel(const FastArgs a
 // int32 ids — in the software pipeline of fwd_stage_kernel (ids two triples ahead, the three row gathers of the next
 // triple in flight while the current one is reduced).  Same arithmetic as score_kernel<MODE 0>; used by
 // trs_score_forward (evaluate(), forward_pair) when the shape allows.
-template <int NET, int VEC, int G, int K, bool FULL>
+template <int NET, int VEC, int G, int K, bool FULL, int NTM = 0>
 __global__ __launch_bounds__(TRS_BLOCK) void pair_scores_kernel(const ScoreArgs a) {
   constexpr int N = K * VEC;
   constexpr int TPW = TRS_WAVE / G;
@@ -890,10 +893,10 @@ __global__ __launch_bounds__(TRS_BLOCK) void pair_scores_kernel(const ScoreArgs 
     if ((uint32_t)r.p >= (uint64_t)T.n_items) { r.ok = false; r.p = 0; }
     if ((uint32_t)r.n >= (uint64_t)T.n_items) { r.ok = false; r.n = 0; }
   };
-  auto gather = [&](Rows& r, const Ids& id) {
-    row_load<VEC, G, K, FULL>(r.u, T.user, id.u, D, lig);
-    row_load<VEC, G, K, FULL>(r.pi, T.item, id.p, D, lig);
-    row_load<VEC, G, K, FULL>(r.ni, T.item, id.n, D, lig);
+  auto gather = [&](Rows& r, const Ids& id) {  // NTM (experiment): bit 0 = user rows nontemporal, bit 1 = item rows
+    row_load<VEC, G, K, FULL, (NTM & 1) != 0>(r.u, T.user, id.u, D, lig);
+    row_load<VEC, G, K, FULL, (NTM & 2) != 0>(r.pi, T.item, id.p, D, lig);
+    row_load<VEC, G, K, FULL, (NTM & 2) != 0>(r.ni, T.item, id.n, D, lig);
     r.ul = T.user_lin[id.u]; r.pl = T.item_lin[id.p]; r.nl = T.item_lin[id.n];
   };
   auto reduce = [&](const Rows& r, const Ids& id, int64_t t) {
@@ -1263,6 +1266,11 @@ static int launch_fwd_stage(const FastArgs& a, hipStream_t s, uint32_t* deferred
   if (grid < 1) grid = 1;
   if (grid > 4096) grid = 4096;
   const int src = !a.from_stream ? 0 : (a.neg_static ? 2 : 1);
+  // one-launch flag mode: user rows loaded AND stored nontemporally when the user table is far beyond the Infinity Cache
+  // (as in the scoring pass, trs_launch_pair_scores): c4, 1 024-step windows, 37.0-37.4 -> 36.2-36.3 us per step (loads
+  // alone: no change).  TRS_K1_NT = 0 | 1 | 3 forces a setting.
+  static const int ntu_env = getenv("TRS_K1_NT") ? atoi(getenv("TRS_K1_NT")) : -1;
+  const int ntu = ntu_env >= 0 ? ntu_env : ((int64_t)a.T.n_users * a.T.D * 4 > ((int64_t)512 << 20) ? 3 : 0);
 #define TRS_LAUNCH(V, GG, KK, FULL)                                                                             \
   {                                                                                                             \
     const dim3 gr((unsigned)grid), bl(TRS_BLOCK);                                                               \
@@ -1275,7 +1283,9 @@ static int launch_fwd_stage(const FastArgs& a, hipStream_t s, uint32_t* deferred
       if (grid <= cap) {                                                                                        \
         FastArgs b = a;                                                                                         \
         b.sync_target = a.sync_base + (uint32_t)grid;                                                           \
-        hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL, 3>), gr, bl, 0, s, b);                      \
+        if (ntu == 1) hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL, 3, OPT_SGD, 1>), gr, bl, 0, s, b); \
+        else if (ntu == 3) hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL, 3, OPT_SGD, 3>), gr, bl, 0, s, b); \
+        else hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL, 3>), gr, bl, 0, s, b);                 \
         *deferred = (uint32_t)grid;                                                                             \
       } else                                                                                                    \
         hipLaunchKernelGGL((fwd_stage_kernel<NET, V, GG, KK, 0, FULL, 2>), gr, bl, 0, s, a);                      \
@@ -1436,9 +1446,19 @@ int trs_launch_pair_scores(int net, const ScoreArgs* ap, hipStream_t s) {
   static const int64_t grid_cap = getenv("TRS_PASS_GRID_CAP") ? atoll(getenv("TRS_PASS_GRID_CAP")) : 4096;
   grid = grid < 1 ? 1 : (grid > grid_cap ? grid_cap : grid);
   const dim3 gr((unsigned)grid), bl(TRS_BLOCK);
+  // user rows nontemporal when the user table is far beyond the Infinity Cache (256 MiB): its rows are read once per
+  // pass and would only displace the item rows and 1-wide terms that do come back.  Measured at c4 (10M x 128 fp32 = 5.1
+  // GB of user rows, 512 MB of item rows), fresh triples per launch: B = 262 144 75.7 -> 74.2 us (0.680 -> 0.694 of the
+  // HBM peak), 64 batches per launch 0.712 -> 0.723-0.729; item rows nontemporal as well: 0.663 (TRS_PASS_NT = 0..3
+  // forces a setting: bit 0 user rows, bit 1 item rows)
+  static const int ntm_env = getenv("TRS_PASS_NT") ? atoi(getenv("TRS_PASS_NT")) : -1;
+  const int ntm = ntm_env >= 0 ? ntm_env : ((int64_t)a.T.n_users * a.T.D * 4 > ((int64_t)512 << 20) ? 1 : 0);
 #define TRS_PS(NETV, V, GG)                                                                                    \
   {                                                                                                            \
-    if (V * GG == a.T.D) hipLaunchKernelGGL((pair_scores_kernel<NETV, V, GG, 1, true>), gr, bl, 0, s, a);      \
+    if (V * GG == a.T.D && ntm == 1) hipLaunchKernelGGL((pair_scores_kernel<NETV, V, GG, 1, true, 1>), gr, bl, 0, s, a); \
+    else if (V * GG == a.T.D && ntm == 2) hipLaunchKernelGGL((pair_scores_kernel<NETV, V, GG, 1, true, 2>), gr, bl, 0, s, a); \
+    else if (V * GG == a.T.D && ntm == 3) hipLaunchKernelGGL((pair_scores_kernel<NETV, V, GG, 1, true, 3>), gr, bl, 0, s, a); \
+    else if (V * GG == a.T.D) hipLaunchKernelGGL((pair_scores_kernel<NETV, V, GG, 1, true>), gr, bl, 0, s, a); \
     else hipLaunchKernelGGL((pair_scores_kernel<NETV, V, GG, 1, false>), gr, bl, 0, s, a);                     \
   }
 #define TRS_CASE(GG)                                                          \

@@ -39,7 +39,8 @@ struct RowReg {
 // the three row gathers of a triple (and drains anything prefetched).  Lanes past the row's end load the row's first
 // chunk instead and are zeroed by a multiply with a 0/1 mask (a select would let the optimiser sink the load back under
 // the condition); FULL = the lane group covers the row exactly (D == G*K*VEC): no mask at all.
-template <int VEC, int G, int K, bool FULL = false>
+// NT: nontemporal load (rows that are read once and should not displace what is re-read: the read-only scoring pass).
+template <int VEC, int G, int K, bool FULL = false, bool NT = false>
 __device__ __forceinline__ void row_load(RowReg<VEC, K>& r, const float* __restrict__ tab, int64_t row, int D,
                                          int lig) {
   const float* p = tab + row * (int64_t)D;
@@ -47,7 +48,14 @@ __device__ __forceinline__ void row_load(RowReg<VEC, K>& r, const float* __restr
   for (int k = 0; k < K; ++k) {
     const int e = (k * G + lig) * VEC;
     if (FULL) {
-      typename VecT<VEC>::type x = *reinterpret_cast<const typename VecT<VEC>::type*>(p + e);
+      using VT = float __attribute__((ext_vector_type(VEC)));
+      typename VecT<VEC>::type x;
+      if (NT) {
+        const VT t = __builtin_nontemporal_load(reinterpret_cast<const VT*>(p + e));
+        x = __builtin_bit_cast(typename VecT<VEC>::type, t);
+      } else {
+        x = *reinterpret_cast<const typename VecT<VEC>::type*>(p + e);
+      }
       const float* xs = reinterpret_cast<const float*>(&x);
 #pragma unroll
       for (int c = 0; c < VEC; ++c) r.v[k * VEC + c] = xs[c];
@@ -62,7 +70,7 @@ __device__ __forceinline__ void row_load(RowReg<VEC, K>& r, const float* __restr
   }
 }
 
-template <int VEC, int G, int K>
+template <int VEC, int G, int K, bool NT = false>
 __device__ __forceinline__ void row_store(const RowReg<VEC, K>& r, float* __restrict__ dst, int D, int lig) {
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -72,7 +80,12 @@ __device__ __forceinline__ void row_store(const RowReg<VEC, K>& r, float* __rest
       float* xs = reinterpret_cast<float*>(&x);
 #pragma unroll
       for (int c = 0; c < VEC; ++c) xs[c] = r.v[k * VEC + c];
-      *reinterpret_cast<typename VecT<VEC>::type*>(dst + e) = x;
+      if (NT) {
+        using VT = float __attribute__((ext_vector_type(VEC)));
+        __builtin_nontemporal_store(__builtin_bit_cast(VT, x), reinterpret_cast<VT*>(dst + e));
+      } else {
+        *reinterpret_cast<typename VecT<VEC>::type*>(dst + e) = x;
+      }
     }
   }
 }
