@@ -89,10 +89,16 @@ const char* trs_last_error(void);
  *   3: trs_bn_relu_forward (running statistics, batch counter, output-layer dot) and trs_bn_relu_backward (outer-product
  *      form, outer_xw) grew arguments; trs_hinge_auc_backward, trs_f32_to_bf16_multi, trs_mlp_embed_sgd_update added.
  *   4: trs_sampler.seen_users (bounds of the seen CSR); trs_train_args.sync_dev (flag mode as one launch per step);
- *      trs_mlp_gather_gemm1_fwd added. */
+ *      trs_mlp_gather_gemm1_fwd, trs_tuning_set added; trs_epoch_flags takes batches up to 262 144; the presort entry
+ *      points no longer use their temp buffers (no vendor sort). */
 #define TRS_ABI_VERSION 4
 #define TRS_SYNC_WORDS 288
 int trs_abi_version(void);
+/* Tuning / A-B knobs of the launch paths (kernel selection, launch shapes): GRID_CAP, PASS_GRID_CAP, K1_ITERS,
+ * PASS_ITERS, PASS_NT, K1_NT, GEMM32_NO_GLDS, GEMM16_TN_WIDE, GEMM16_TILE, GEMM16_NO_GLDS, BN_FINAL_TWO_SWEEPS (meanings:
+ * csrc/trs_common.h TrsTuning).  The library reads TRS_<name> from the environment ONCE, at its first use; this entry
+ * point changes a knob afterwards (tests, tools): unset != 0 restores the default.  The defaults are the measured best. */
+int trs_tuning_set(const char* name, int64_t value, int32_t unset);
 /* 0 if the current HIP device is gfx950, TRS_E_DEVICE otherwise. */
 int trs_check_device(void);
 
@@ -317,7 +323,7 @@ int trs_train_steps_sgd(const trs_train_args* args, void* stream);
 /* Epoch-level grouping of the item references by row.  trs_epoch_presort covers n_batches whole batches starting at
  * epoch position first_pos: it writes the triples' ids (generated from the resident stream exactly as
  * trs_batch_prepare would, or taken as given when stream_ui is NULL) and the 2*batch references of every batch sorted
- * by item row (rocprim segmented radix sort, one segment per batch; key = item row (uint32), payload = (t<<1)|which
+ * by item row (hand-written counting sort in LDS, one workgroup per batch; key = item row (uint32), payload = (t<<1)|which
  * (uint32), t = position inside the batch).  Passing the sorted arrays (offset to the first batch of the call) to
  * trs_train_steps_sgd together with the id arrays replaces K2a/K2b by one atomic-free launch: each run of equal keys is
  * summed by one lane group and applied with a plain whole-row read-modify-write (runs are cut every 64 references; cut
@@ -326,7 +332,7 @@ int trs_train_steps_sgd(const trs_train_args* args, void* stream);
  * 1 negative) of position q is referenced again inside q's batch — neighbour compare on the sorted keys, scattered back
  * by payload (trs_train_args.item_dup_flags_dev). */
 /* Per-position flags of an epoch slice: 1 iff the triple's user is referenced by another triple of the same batch
- * (segmented sort of the user ids, one segment per batch).  Passing them (offset to the first batch) with a (batch,D) staging buffer to
+ * (per-batch counting sort of the user ids).  Passing them (offset to the first batch) with a (batch,D) staging buffer to
  * trs_train_steps_sgd in presorted mode lets K1 apply the user update itself for users referenced once in the batch
  * (plain store; K1 then stages the OLD user row for the item update instead of the gradient) — K3 shrinks to the
  * duplicated users: with the slice's sorted (user, position) pairs (offset to the call's first batch; slice_pos0 = that

@@ -43,3 +43,21 @@ def rel_err(a, b):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def tune():
+    """tune(GEMM16_TILE=256, ...): set tuning knobs of libtrs_hip.so for the test (trs_tuning_set; the library reads the
+    TRS_* environment only once, at its first use), defaults restored afterwards."""
+    from torchrecsys_amd import _lib
+    touched = []
+
+    def _set(**knobs):
+        lib = _lib.load()
+        for k, v in knobs.items():
+            _lib.check(lib.trs_tuning_set(k.encode(), int(v), 0), "trs_tuning_set")
+            touched.append(k)
+    yield _set
+    lib = _lib.load()
+    for k in touched:
+        lib.trs_tuning_set(k.encode(), 0, 1)

@@ -460,10 +460,10 @@ def test_gemm_f32_all_layouts(M, N, K, tA, tB):
 
 
 @pytest.mark.parametrize("M,N,K,stats", [(32768, 512, 160, True), (32768, 384, 96, False), (65536, 256, 32, True)])
-def test_gemm_f32_nt_lds_dma_kernel(M, N, K, stats, monkeypatch):
+def test_gemm_f32_nt_lds_dma_kernel(M, N, K, stats, tune):
     """fp32 NT GEMMs whose 256-row tiles fill the chip take gemm32_nt_glds_kernel (256 x 256 tiles, or 256 x 128 when N is
     only a multiple of 128): exact-FMA products, bias, per-128-row BatchNorm partials; == the register-staged kernel
-    (TRS_GEMM32_NO_GLDS=1) to fp32 summation accuracy."""
+    (knob GEMM32_NO_GLDS = 1) to fp32 summation accuracy."""
     ops = _ops()
     rs = np.random.RandomState(M % 97 + N)
     A = torch.from_numpy(rs.normal(0, 1, (M, K)).astype(np.float32)).to(DEV)
@@ -477,7 +477,7 @@ def test_gemm_f32_nt_lds_dma_kernel(M, N, K, stats, monkeypatch):
         r3 = ref.reshape(M // 128, 128, N)
         assert rel_err(part[:, 0].cpu().numpy(), r3.mean(dim=1).cpu().numpy()) < 1e-5
         assert rel_err(part[:, 1].cpu().numpy(), ((r3 - r3.mean(dim=1, keepdim=True)) ** 2).sum(dim=1).cpu().numpy()) < 1e-5
-    monkeypatch.setenv("TRS_GEMM32_NO_GLDS", "1")
+    tune(GEMM32_NO_GLDS=1)
     out2 = ops.gemm(False, True, A, Bm, bias=bias)
     assert float((out - out2).abs().max()) < 2e-5 * float(ref.abs().max())
 
@@ -506,13 +506,12 @@ def test_gemm_split_k_wgrad_shape_and_strided_views():
 
 @pytest.mark.parametrize("tile", ["128", "256", "512", "512-regstage"])
 @pytest.mark.parametrize("B,K,H", [(256, 128, 256), (512, 256, 512), (384, 1280, 768)])
-def test_gemm_bf16_resident_tiles_and_fused_bn_statistics(tile, B, K, H, monkeypatch):
+def test_gemm_bf16_resident_tiles_and_fused_bn_statistics(tile, B, K, H, tune):
     """The workgroup tiles of the bf16-resident kernels (128x128, 256x128, 256x256 filled by the LDS-DMA [NT form] and
-    256x256 staged through registers; forced through TRS_GEMM16_TILE / TRS_GEMM16_NO_GLDS) give the same product, bf16
+    256x256 staged through registers; forced through the knobs GEMM16_TILE / GEMM16_NO_GLDS) give the same product, bf16
     output and per-128-row BatchNorm partials."""
     ops = _ops()
-    monkeypatch.setenv("TRS_GEMM16_TILE", tile.split("-")[0])
-    monkeypatch.setenv("TRS_GEMM16_NO_GLDS", "1" if tile.endswith("regstage") else "0")
+    tune(GEMM16_TILE=int(tile.split("-")[0]), GEMM16_NO_GLDS=1 if tile.endswith("regstage") else 0)
     rs = np.random.RandomState(B + K)
     rows = 2 * B
     x = torch.from_numpy(rs.normal(0, 1, (rows, K)).astype(np.float32)).to(DEV).to(torch.bfloat16)
@@ -675,9 +674,9 @@ def test_mlp_embed_sgd_update_refuses_what_it_cannot_do():
 
 
 @pytest.mark.parametrize("B", [300, 128 * 16 * 12 - 5, 128 * 16 * 30, 128 * 16 * 40 + 77])
-def test_bn_statistics_finalise_kernels_agree(B, monkeypatch):
+def test_bn_statistics_finalise_kernels_agree(B, tune):
     """The finalise of the BatchNorm batch statistics: the kernel that keeps a thread's chunk partials in registers (up to
-    8 / 16 / 32 chunks per thread) and the two-sweep kernel (longer chunk lists; forced by TRS_BN_FINAL_TWO_SWEEPS=1) add
+    8 / 16 / 32 chunks per thread) and the two-sweep kernel (longer chunk lists; forced by the knob BN_FINAL_TWO_SWEEPS = 1) add
     in the same order — bit-identical mean / variance / running statistics."""
     ops = _ops()
     rs = np.random.RandomState(B % 1000)
@@ -689,7 +688,7 @@ def test_bn_statistics_finalise_kernels_agree(B, monkeypatch):
     rw = torch.from_numpy(rs.normal(0, 1, passes * B).astype(np.float32)).to(DEV)
     res = []
     for two in ("0", "1"):
-        monkeypatch.setenv("TRS_BN_FINAL_TWO_SWEEPS", two)
+        tune(BN_FINAL_TWO_SWEEPS=int(two))
         mean, var = torch.empty((passes, H), device=DEV), torch.empty((passes, H), device=DEV)
         rm, rv = torch.zeros(H, device=DEV), torch.ones(H, device=DEV)
         ops.bn_batch_stats(y, B, passes, 0.1, mean, var, rm, rv)

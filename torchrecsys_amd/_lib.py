@@ -146,6 +146,7 @@ PROTOTYPES = {
     "trs_score_all_items": (C.c_int, [C.c_int, _T, _i64, _i64, _i64, _vp, _vp, _vp]),
     "trs_topk_workspace_bytes": (C.c_int64, [_i64, _i32]),
     "trs_topk": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _i64, _vp]),
+    "trs_tuning_set": (C.c_int, [C.c_char_p, _i64, _i32]),
     "trs_mlp_gather_concat": (C.c_int, [_T, _Bp, _i32, _vp, _vp, _i64, _vp]),
     "trs_mlp_gather_gemm1_fwd": (C.c_int, [_T, _Bp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64,
                                            _vp]),
@@ -213,3 +214,24 @@ def check(rc, what=""):
 def ptr(t):
     """Device pointer of a torch tensor (None -> NULL)."""
     return None if t is None else t.data_ptr()
+
+
+class tuning:
+    """Context manager over trs_tuning_set: `with _lib.tuning(GEMM16_TILE=256): ...` sets the library's knobs (names as
+    in csrc/trs_common.h TrsTuning, without the TRS_ prefix) and restores their defaults on exit.  The library reads the
+    TRS_* environment only once, at its first use, so tests and tools switch kernels through this."""
+
+    def __init__(self, **knobs):
+        self.knobs = knobs
+
+    def __enter__(self):
+        lib = load()
+        for k, v in self.knobs.items():
+            check(lib.trs_tuning_set(k.encode(), int(v), 0), "trs_tuning_set")
+        return self
+
+    def __exit__(self, *exc):
+        lib = load()
+        for k in self.knobs:
+            check(lib.trs_tuning_set(k.encode(), 0, 1), "trs_tuning_set")
+        return False

@@ -14,6 +14,63 @@ void trs_set_error(const char* fmt, ...) {
 
 extern "C" const char* trs_last_error(void) { return g_err; }
 
+// ---- tuning knobs: the TRS_* environment is read here, once -----------------------------------------------------
+#include <mutex>
+#include <stdlib.h>
+
+namespace {
+struct Knob {
+  const char* name;  // without the TRS_ prefix
+  int64_t TrsTuning::*wide;
+  int TrsTuning::*narrow;
+  int64_t unset;
+};
+const Knob KNOBS[] = {
+    {"GRID_CAP", &TrsTuning::grid_cap, nullptr, 256 * 16},
+    {"PASS_GRID_CAP", &TrsTuning::pass_grid_cap, nullptr, 4096},
+    {"K1_ITERS", nullptr, &TrsTuning::k1_iters, 0},
+    {"PASS_ITERS", nullptr, &TrsTuning::pass_iters, 0},
+    {"PASS_NT", nullptr, &TrsTuning::pass_nt, -1},
+    {"K1_NT", nullptr, &TrsTuning::k1_nt, -1},
+    {"GEMM32_NO_GLDS", nullptr, &TrsTuning::gemm32_no_glds, 0},
+    {"GEMM16_TN_WIDE", nullptr, &TrsTuning::gemm16_tn_wide, -1},
+    {"GEMM16_TILE", nullptr, &TrsTuning::gemm16_tile, 0},
+    {"GEMM16_NO_GLDS", nullptr, &TrsTuning::gemm16_no_glds, 0},
+    {"BN_FINAL_TWO_SWEEPS", nullptr, &TrsTuning::bn_final_two_sweeps, 0},
+};
+TrsTuning g_tuning;
+std::once_flag g_tuning_once;
+void knob_store(const Knob& k, int64_t v) {
+  if (k.wide) g_tuning.*(k.wide) = v;
+  else g_tuning.*(k.narrow) = (int)v;
+}
+}  // namespace
+
+TrsTuning& trs_tuning() {
+  std::call_once(g_tuning_once, [] {
+    for (const Knob& k : KNOBS) {
+      char name[64];
+      snprintf(name, sizeof(name), "TRS_%s", k.name);
+      const char* e = getenv(name);
+      knob_store(k, (e && *e) ? atoll(e) : k.unset);
+    }
+  });
+  return g_tuning;
+}
+
+// name: a knob of TrsTuning without the TRS_ prefix ("GEMM16_TILE"); unset != 0 restores the knob's default.
+extern "C" int trs_tuning_set(const char* name, int64_t value, int32_t unset) {
+  TRS_REQUIRE(name != nullptr, "trs_tuning_set: NULL name");
+  (void)trs_tuning();
+  for (const Knob& k : KNOBS)
+    if (strcmp(k.name, name) == 0) {
+      knob_store(k, unset ? k.unset : value);
+      return TRS_OK;
+    }
+  trs_set_error("trs_tuning_set: unknown knob %s", name);
+  return TRS_E_ARG;
+}
+
 extern "C" int trs_abi_version(void) { return TRS_ABI_VERSION; }
 
 extern "C" int trs_check_device(void) {

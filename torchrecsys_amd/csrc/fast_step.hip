@@ -1258,7 +1258,7 @@ static int launch_fwd_stage(const FastArgs& a, hipStream_t s, uint32_t* deferred
   // own reductions, enough (>= 2 per CU) to fill the chip
   // measured at c2 (B = 65536, D = 64): 2 iterations 35 us, 4: 26, 6-8: 22-25, 16: 29.  Small batches keep >= 2
   // iterations (the pipeline's minimum) but spread over as many workgroups as there is work for.
-  static const int iters_env = getenv("TRS_K1_ITERS") ? atoi(getenv("TRS_K1_ITERS")) : 0;  // tuning knob
+  const int iters_env = trs_tuning().k1_iters;
   int64_t iters = iters_env > 0 ? iters_env : (a.B + 512 * 4 * (int64_t)tpw - 1) / (512 * 4 * (int64_t)tpw);
   if (iters < 2) iters = 2;
   if (iters > 8 && iters_env <= 0) iters = 8;
@@ -1269,7 +1269,7 @@ static int launch_fwd_stage(const FastArgs& a, hipStream_t s, uint32_t* deferred
   // one-launch flag mode: user rows loaded AND stored nontemporally when the user table is far beyond the Infinity Cache
   // (as in the scoring pass, trs_launch_pair_scores): c4, 1 024-step windows, 37.0-37.4 -> 36.2-36.3 us per step (loads
   // alone: no change).  TRS_K1_NT = 0 | 1 | 3 forces a setting.
-  static const int ntu_env = getenv("TRS_K1_NT") ? atoi(getenv("TRS_K1_NT")) : -1;
+  const int ntu_env = trs_tuning().k1_nt;
   const int ntu = ntu_env >= 0 ? ntu_env : ((int64_t)a.T.n_users * a.T.D * 4 > ((int64_t)512 << 20) ? 3 : 0);
 #define TRS_LAUNCH(V, GG, KK, FULL)                                                                             \
   {                                                                                                             \
@@ -1439,11 +1439,11 @@ int trs_launch_pair_scores(int net, const ScoreArgs* ap, hipStream_t s) {
   RowCfg c;
   if (!pick_row_cfg(a.T.D, c) || c.vec != 4 || c.k != 1 || c.g < 8) return 1;
   const int tpw = TRS_WAVE / c.g;
-  static const int iters_env = getenv("TRS_PASS_ITERS") ? atoi(getenv("TRS_PASS_ITERS")) : 0;  // tuning knob
+  const int iters_env = trs_tuning().pass_iters;
   int64_t iters = iters_env > 0 ? iters_env : (a.Bt.B + 512 * 4 * (int64_t)tpw - 1) / (512 * 4 * (int64_t)tpw);
   iters = iters < 2 ? 2 : (iters > 8 && iters_env <= 0 ? 8 : iters);
   int64_t grid = ((a.Bt.B + tpw - 1) / tpw + 4 * iters - 1) / (4 * iters);
-  static const int64_t grid_cap = getenv("TRS_PASS_GRID_CAP") ? atoll(getenv("TRS_PASS_GRID_CAP")) : 4096;
+  const int64_t grid_cap = trs_tuning().pass_grid_cap;
   grid = grid < 1 ? 1 : (grid > grid_cap ? grid_cap : grid);
   const dim3 gr((unsigned)grid), bl(TRS_BLOCK);
   // user rows nontemporal when the user table is far beyond the Infinity Cache (256 MiB): its rows are read once per
@@ -1451,7 +1451,7 @@ int trs_launch_pair_scores(int net, const ScoreArgs* ap, hipStream_t s) {
   // GB of user rows, 512 MB of item rows), fresh triples per launch: B = 262 144 75.7 -> 74.2 us (0.680 -> 0.694 of the
   // HBM peak), 64 batches per launch 0.712 -> 0.723-0.729; item rows nontemporal as well: 0.663 (TRS_PASS_NT = 0..3
   // forces a setting: bit 0 user rows, bit 1 item rows)
-  static const int ntm_env = getenv("TRS_PASS_NT") ? atoi(getenv("TRS_PASS_NT")) : -1;
+  const int ntm_env = trs_tuning().pass_nt;
   const int ntm = ntm_env >= 0 ? ntm_env : ((int64_t)a.T.n_users * a.T.D * 4 > ((int64_t)512 << 20) ? 1 : 0);
 #define TRS_PS(NETV, V, GG)                                                                                    \
   {                                                                                                            \

@@ -1204,8 +1204,7 @@ static int gemm_impl(bool bf16, int transA, int transB, int64_t M, int64_t N, in
                     (int64_t)(splits - 1) * g.k_per_split < K;
   // fp32 NT on the LDS-DMA kernel when 256-row tiles fill the chip (TRS_GEMM32_NO_GLDS=1: tuning / test knob)
   {
-    const char* ng = getenv("TRS_GEMM32_NO_GLDS");
-    const bool want = !(ng && atoi(ng) != 0);
+    const bool want = trs_tuning().gemm32_no_glds == 0;
     const int bnt = N % 256 == 0 ? 256 : (N % 128 == 0 && !bn_part_dev ? 128 : 0);
     if (!bf16 && want && akc && bkc && splits == 1 && beta == 0.f && bnt && M % 256 == 0 && K % 32 == 0 &&
         (M / 256) * (N / bnt) >= 256 && g.vecA && g.vecB && (((uintptr_t)C_dev) & 15) == 0 && ldc % 4 == 0 &&
@@ -1279,8 +1278,7 @@ static int tn_wide_splits(int64_t M, int64_t N, int64_t K) {
 // (measured at the c5 weight-gradient shapes, K = 65 536: 1024 x 1280 281 -> 233 us, 512 x 1024 107 -> 94, but 256 x 512 —
 // two tiles x 128 splits of slabs — 38 -> 44: eight tiles at least.  TRS_GEMM16_TN_WIDE = 0 | 1 overrides: tuning knob)
 static bool tn_wide_wanted(int64_t M, int64_t N) {
-  const char* e = getenv("TRS_GEMM16_TN_WIDE");
-  if (e) return atoi(e) != 0;
+  if (trs_tuning().gemm16_tn_wide >= 0) return trs_tuning().gemm16_tn_wide != 0;
   return (M / 256) * (N / 256) >= 8;
 }
 
@@ -1327,8 +1325,7 @@ extern "C" int trs_gemm_bf16in(int tn, int64_t M, int64_t N, int64_t K, float al
   // Tile selection (TRS_GEMM16_TILE = 128 | 256 | 512 forces 128x128 | 256x128 | 256x256 where the shape allows: tests,
   // tuning).  The kernel is bound by the vector L1's miss path (TCP_PENDING_STALL ~ 50 % of the cycles at 128x128), so
   // the tile that moves the fewest operand bytes per MAC wins as long as every CU still gets a workgroup.
-  const char* tile_env = getenv("TRS_GEMM16_TILE");
-  const int tile = tile_env ? atoi(tile_env) : 0;
+  const int tile = trs_tuning().gemm16_tile;
   const bool can_big = M % 256 == 0, can_wide = can_big && N % 256 == 0;
   const bool wide = tn_wide || (tile ? (tile == 512 && can_wide) : (can_wide && (M / 256) * (N / 256) * splits >= 256));
   const bool big = wide || (tile ? (tile == 256 && can_big) : (can_big && (M / 256) * (N / BN) * splits >= 256));
@@ -1337,8 +1334,7 @@ extern "C" int trs_gemm_bf16in(int tn, int64_t M, int64_t N, int64_t K, float al
   g.gx = (int)gx; g.gy = (int)gy; g.splits = splits;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)(gx * gy * splits));
-  const char* ng_env = getenv("TRS_GEMM16_NO_GLDS");  // A/B knob (tests, tuning): the register-staged 256 x 256 kernel
-  const bool no_glds = ng_env && atoi(ng_env) != 0;
+  const bool no_glds = trs_tuning().gemm16_no_glds != 0;  // A/B knob (tests, tuning): the register-staged 256 x 256 kernel
   const bool c_vec = (((uintptr_t)(C_bf16_dev ? C_bf16_dev : (void*)C_dev)) & 15) == 0 && ldc % 8 == 0;  // 16-byte stores
   if (wide && !tn && splits == 1 && beta == 0.f && !no_glds && c_vec) {
     g.gx = (int)(N / 256); g.gy = (int)(M / 256);

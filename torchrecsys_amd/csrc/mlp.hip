@@ -282,9 +282,9 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_stats_final_regs_kernel(const fl
 static void launch_bn_stats_final(const float* part, int64_t rows_per_pass, int chunk_rows, int H, int nc, int passes,
                                   float* mean_out, float* var_out, hipStream_t s) {
   const dim3 gr((H + FIN_COLS - 1) / FIN_COLS, passes), bl(TRS_BLOCK);
-  const char* e = getenv("TRS_BN_FINAL_TWO_SWEEPS");
+  const bool two_sweeps = trs_tuning().bn_final_two_sweeps != 0;
   const int per_thread = (nc + FIN_SEGS - 1) / FIN_SEGS;
-  if (e && atoi(e) != 0) {
+  if (two_sweeps) {
     hipLaunchKernelGGL(bn_stats_final_kernel, gr, bl, 0, s, part, rows_per_pass, chunk_rows, H, nc, mean_out, var_out);
   } else if (per_thread <= 8) {
     hipLaunchKernelGGL(bn_stats_final_regs_kernel<8>, gr, bl, 0, s, part, rows_per_pass, chunk_rows, H, nc, mean_out, var_out);
@@ -534,9 +534,9 @@ __global__ __launch_bounds__(TRS_BLOCK) void bn_bwd_final_regs_kernel(const floa
 static void launch_bn_bwd_final(const float* part, int H, int nc, int passes, float* sums, float* dgamma, float* dbeta,
                                 hipStream_t s) {
   const dim3 gr((H + FIN_COLS - 1) / FIN_COLS), bl(TRS_BLOCK);
-  const char* e = getenv("TRS_BN_FINAL_TWO_SWEEPS");
+  const bool two_sweeps = trs_tuning().bn_final_two_sweeps != 0;
   const int per_thread = (nc + FIN_SEGS - 1) / FIN_SEGS;
-  if ((e && atoi(e) != 0) || passes > 2 || per_thread > 32)
+  if (two_sweeps || passes > 2 || per_thread > 32)
     hipLaunchKernelGGL(bn_bwd_final_kernel, gr, bl, 0, s, part, H, nc, passes, sums, dgamma, dbeta);
   else if (per_thread <= 16)
     hipLaunchKernelGGL(bn_bwd_final_regs_kernel<16>, gr, bl, 0, s, part, H, nc, passes, sums, dgamma, dbeta);
@@ -664,9 +664,9 @@ __global__ __launch_bounds__(TRS_BLOCK) void colsum_final_regs_kernel(const floa
 
 static void launch_colsum_final(const float* part, int H, int nc, int passes, float* out, hipStream_t s) {
   const dim3 gr((H + FIN_COLS - 1) / FIN_COLS), bl(TRS_BLOCK);
-  const char* e = getenv("TRS_BN_FINAL_TWO_SWEEPS");
+  const bool two_sweeps = trs_tuning().bn_final_two_sweeps != 0;
   const int per_thread = (nc + FIN_SEGS - 1) / FIN_SEGS;
-  if ((e && atoi(e) != 0) || passes > 2 || per_thread > 32)
+  if (two_sweeps || passes > 2 || per_thread > 32)
     hipLaunchKernelGGL(colsum_final_kernel, gr, bl, 0, s, part, H, nc, passes, out);
   else if (per_thread <= 16)
     hipLaunchKernelGGL(colsum_final_regs_kernel<16>, gr, bl, 0, s, part, H, nc, passes, out);
@@ -1591,15 +1591,15 @@ extern "C" int trs_mlp_embed_sgd_update(const trs_tables* tables, const trs_batc
   a.cats_per_wg = (int)c;
   const size_t lds = (size_t)M * c * (D * 4 + 4) + (size_t)(EMB_META_THREADS / TRS_WAVE) * 2 * EMB_LIST * 4 +
                      (size_t)(EMB_META_THREADS / TRS_WAVE + 1) * 4;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static const int attr_done = [] {  // (a function-local static: initialised once, thread-safe)
     const int cap = 160 * 1024 - 1024;
     (void)hipFuncSetAttribute((const void*)mlp_embed_meta_kernel<int64_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     (void)hipFuncSetAttribute((const void*)mlp_embed_meta_kernel<int64_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     (void)hipFuncSetAttribute((const void*)mlp_embed_meta_kernel<int32_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     (void)hipFuncSetAttribute((const void*)mlp_embed_meta_kernel<int32_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    attr_done = true;
-  }
+    return 1;
+  }();
+  (void)attr_done;
   TRS_EMB(mlp_embed_meta_kernel, dim3((unsigned)wgs), dim3(EMB_META_THREADS), lds)
 #undef TRS_EMB
   TRS_CHECK_LAUNCH("mlp_embed_meta_kernel");

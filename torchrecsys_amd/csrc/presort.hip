@@ -6,19 +6,15 @@
 // position, the negative a counter-based draw), so they are grouped ONCE per epoch:
 //   epoch_refs_kernel   every position q of the epoch -> its triple (u, i, j) [written out: K1 then reads contiguous ids
 //                       instead of deriving them] and two references  key = item row, payload = (t << 1) | which;
-//   rocprim segmented radix sort, one segment per batch (the positions of a batch are contiguous already, so sorting on
-//                       a (batch, item) key would spend half its passes on bits that are in order): item_bits = 17 at
-//                       c2 -> two 9-bit passes, one 1024-thread workgroup per batch; measured 0.95 ms per 512 batches of
-//                       131 072 references against 2.0 ms for the global 26-bit sort (tools/micro/segsort_bench.hip).
+//   batch_group_items_kernel   a counting sort in LDS, one 1024-thread workgroup per batch (the positions of a batch are
+//                       contiguous already: only the row id is a key), walking the key space in chunks — no vendor
+//                       library anywhere in this file since round 3 (rounds 1-2: rocprim's segmented radix sort, two 9-bit
+//                       passes, 0.95 ms per 512 batches of 131 072 references against 0.64 ms for this kernel).
 // Per step, sorted_item_update_kernel gives every run of equal keys to ONE lane group: it sums c * u over the run
 // (c = -lr * gz of the reference, u = the still-unmodified user row) in registers and applies it with a single plain
 // whole-row read-modify-write.  Runs are cut at 64-reference boundaries so a hot row (skewed data) is reduced by many
 // groups in parallel; only such cut runs fall back to float atomics (one add per 64 references instead of 64).
 #include <cstring>
-
-#include <rocprim/device/device_segmented_radix_sort.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "score_kernels.h"
 #include "opt_rows.h"
@@ -34,31 +30,6 @@ namespace trs {
 struct RefPayload {
   uint32_t tw;  // (t << 1) | which   (t = position inside the batch, which: 0 positive / 1 negative)
 };
-
-// segment s of the sort = [s * len, (s + 1) * len)
-struct SegBegin {
-  uint32_t len;
-  __host__ __device__ uint32_t operator()(uint32_t s) const { return s * len; }
-};
-using SegIt = rocprim::transform_iterator<rocprim::counting_iterator<uint32_t>, SegBegin>;
-static inline SegIt seg_it(uint32_t first, uint32_t len) {
-  return rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(first), SegBegin{len});
-}
-// The payload of reference 2q + w, (t << 1) | w = (2q + w) mod 2*batch, is not materialised: the item sort reads it
-// through an iterator (8 bytes per triple less to write and to read back).
-struct RefVal {
-  uint32_t per_batch;  // 2 * batch
-  uint32_t mask;       // per_batch - 1 when it is a power of two (no division), else 0
-  __host__ __device__ RefPayload operator()(uint32_t i) const { return RefPayload{mask ? (i & mask) : (i % per_batch)}; }
-};
-using RefValIt = rocprim::transform_iterator<rocprim::counting_iterator<uint32_t>, RefVal>;
-static inline RefValIt ref_val_it(int64_t batch) {
-  const uint32_t pb = (uint32_t)(2 * batch);
-  return rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), RefVal{pb, (pb & (pb - 1)) ? 0u : pb - 1});
-}
-// 9-bit (item rows) / 10-bit (users) digits need >= 512 / 1024 threads; 1024 x 8 measured best for both
-using ItemSortCfg = rocprim::segmented_radix_sort_config<9, rocprim::kernel_config<1024, 8>>;
-using UserSortCfg = rocprim::segmented_radix_sort_config<10, rocprim::kernel_config<1024, 8>>;
 
 struct EpochArgs {
   const int2* sui;  // resident stream {user, item} or NULL (ids given in user/pos/neg)
@@ -161,9 +132,12 @@ __device__ __forceinline__ uint32_t flag_bit(int32_t row, int hashed, int log2_b
 // the same triples in every pass (t = tid + k * 1024), so what phase A learns ("my reference came later") stays in
 // registers — one bit per reference — until phase B needs it; only the final flags go to memory.
 constexpr int FLAG_U = 8;
-constexpr int FLAG_MAX_ROUNDS = 8;   // batch <= 1024 * FLAG_U * FLAG_MAX_ROUNDS = 65 536 triples
+constexpr int FLAG_ROUNDS = 8;       // rounds per 64-bit word of "came later" bits: 8 rounds x FLAG_U triples
+constexpr int FLAG_MAX_GROUPS = 4;   // batch <= 1024 * FLAG_U * FLAG_ROUNDS * FLAG_MAX_GROUPS = 262 144 triples
 
-template <int SRC>
+// NG: 64-bit words of "came later" bits a thread keeps per id stream (compile-time: the words stay in registers).  The
+// batch's ids are given (trs_epoch_flags writes them first with a wide launch of epoch_refs_kernel).
+template <int NG>
 __global__ __launch_bounds__(FLAG_THREADS) void batch_flags_kernel(const FlagArgs a) {
   extern __shared__ uint32_t bm[];
   const int words = 1 << (a.log2_bits - 5);
@@ -172,55 +146,21 @@ __global__ __launch_bounds__(FLAG_THREADS) void batch_flags_kernel(const FlagArg
   const int lb = a.log2_bits;
   uint16_t* iflags16 = reinterpret_cast<uint16_t*>(a.iflags);  // {pos, neg} of a position as one 16-bit word
   constexpr int STEP = FLAG_THREADS * FLAG_U;
-  constexpr int GEN_U = 8;  // triples per thread whose random stream reads are in flight together
-  // ---- the batch's ids (as epoch_refs_kernel: generated from the resident stream, or clamped in place)
-  for (int t0 = threadIdx.x; t0 < B; t0 += FLAG_THREADS * GEN_U) {
-    int64_t u[GEN_U], i[GEN_U], j[GEN_U], p[GEN_U];
-    bool in[GEN_U];
-#pragma unroll
-    for (int k = 0; k < GEN_U; ++k) {
-      const int t = t0 + k * FLAG_THREADS;
-      in[k] = t < B;
-      const int64_t q = q0 + (in[k] ? t : 0);
-      if (SRC != 0) {
-        p[k] = trs_feistel_perm(a.first_pos + q, a.N, a.shuffle_key, a.hb);
-        const int2 ui = a.sui[p[k]];
-        u[k] = ui.x;
-        i[k] = ui.y;
-        j[k] = SRC == 2 ? (int64_t)a.neg_static[p[k]] : 0;
-      } else {
-        u[k] = a.user[q];
-        i[k] = a.pos[q];
-        j[k] = a.neg[q];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < GEN_U; ++k) {
-      const int64_t q = q0 + t0 + k * FLAG_THREADS;
-      if (SRC == 1) j[k] = trs_sample_one_neg(a.sample_seed, (uint64_t)(a.first_pos + q), i[k], a.n_items);
-      bool ok = true;
-      if ((uint64_t)u[k] >= (uint64_t)a.n_users) { ok = false; u[k] = 0; }
-      if ((uint64_t)i[k] >= (uint64_t)a.n_items) { ok = false; i[k] = 0; }
-      if ((uint64_t)j[k] >= (uint64_t)a.n_items) { ok = false; j[k] = 0; }
-      if (in[k]) {
-        if (!ok && a.err) atomicOr(a.err, 1);
-        if (SRC != 0 || !ok) {
-          a.user[q] = (int32_t)u[k];
-          a.pos[q] = (int32_t)i[k];
-          a.neg[q] = (int32_t)j[k];
-        }
-      }
-    }
-  }
   // ---- item references, then users: phases A / B / C over the same LDS bitmap
   for (int what = a.what_first; what < a.what_end; ++what) {
     const int hashed = what == 0 ? a.item_hash : a.user_hash;
     const int32_t* ida = what == 0 ? a.pos : a.user;
-    uint64_t lat0 = 0, lat1 = 0;  // bit rd * FLAG_U + k: the first / second id of triple (round rd, k) came later
+    // bit (rd % 8) * FLAG_U + k of word rd / 8: the first / second id of triple (round rd, k) came later
+    uint64_t lat0[NG], lat1[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) lat0[g] = lat1[g] = 0;
     for (int w = threadIdx.x; w < words; w += FLAG_THREADS) bm[w] = 0u;
-    __syncthreads();  // (also: the ids written above are visible to the whole workgroup)
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
 #pragma unroll 1
-    for (int rd = 0; rd * STEP < B; ++rd) {  // A: set; a bit already set = a later arrival
+    for (int rr = 0; rr < FLAG_ROUNDS && (g * FLAG_ROUNDS + rr) * STEP < B; ++rr) {  // A: set; a bit already set = a later arrival
+      const int rd = g * FLAG_ROUNDS + rr;
       const int t0 = threadIdx.x + rd * STEP;
       uint32_t b0[FLAG_U], b1[FLAG_U];
 #pragma unroll
@@ -234,28 +174,32 @@ __global__ __launch_bounds__(FLAG_THREADS) void batch_flags_kernel(const FlagArg
       for (int k = 0; k < FLAG_U; ++k) {
         if (t0 + k * FLAG_THREADS < B) {
           const uint32_t o0 = atomicOr(&bm[b0[k] >> 5], 1u << (b0[k] & 31));
-          lat0 |= (uint64_t)((o0 >> (b0[k] & 31)) & 1u) << (rd * FLAG_U + k);
+          lat0[g] |= (uint64_t)((o0 >> (b0[k] & 31)) & 1u) << (rr * FLAG_U + k);
           if (what == 0) {
             const uint32_t o1 = atomicOr(&bm[b1[k] >> 5], 1u << (b1[k] & 31));
-            lat1 |= (uint64_t)((o1 >> (b1[k] & 31)) & 1u) << (rd * FLAG_U + k);
+            lat1[g] |= (uint64_t)((o1 >> (b1[k] & 31)) & 1u) << (rr * FLAG_U + k);
           }
         }
       }
     }
+    }
     __syncthreads();
     for (int w = threadIdx.x; w < words; w += FLAG_THREADS) bm[w] = 0u;
     __syncthreads();
-    for (uint64_t m = lat0; m; m &= m - 1) {  // B: the later arrivals mark their row as shared (few: ids re-read)
-      const int bit = __ffsll((unsigned long long)m) - 1;
-      const int64_t q = q0 + threadIdx.x + (int64_t)(bit / FLAG_U) * STEP + (bit % FLAG_U) * FLAG_THREADS;
-      const uint32_t b = flag_bit(ida[q], hashed, lb);
-      atomicOr(&bm[b >> 5], 1u << (b & 31));
-    }
-    for (uint64_t m = lat1; m; m &= m - 1) {
-      const int bit = __ffsll((unsigned long long)m) - 1;
-      const int64_t q = q0 + threadIdx.x + (int64_t)(bit / FLAG_U) * STEP + (bit % FLAG_U) * FLAG_THREADS;
-      const uint32_t b = flag_bit(a.neg[q], hashed, lb);
-      atomicOr(&bm[b >> 5], 1u << (b & 31));
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {  // B: the later arrivals mark their row as shared (few: ids re-read)
+      for (uint64_t m = lat0[g]; m; m &= m - 1) {
+        const int bit = __ffsll((unsigned long long)m) - 1;
+        const int64_t q = q0 + threadIdx.x + (int64_t)(g * FLAG_ROUNDS + bit / FLAG_U) * STEP + (bit % FLAG_U) * FLAG_THREADS;
+        const uint32_t b = flag_bit(ida[q], hashed, lb);
+        atomicOr(&bm[b >> 5], 1u << (b & 31));
+      }
+      for (uint64_t m = lat1[g]; m; m &= m - 1) {
+        const int bit = __ffsll((unsigned long long)m) - 1;
+        const int64_t q = q0 + threadIdx.x + (int64_t)(g * FLAG_ROUNDS + bit / FLAG_U) * STEP + (bit % FLAG_U) * FLAG_THREADS;
+        const uint32_t b = flag_bit(a.neg[q], hashed, lb);
+        atomicOr(&bm[b >> 5], 1u << (b & 31));
+      }
     }
     __syncthreads();
     for (int t0 = threadIdx.x; t0 < B; t0 += STEP) {  // C: flag = "my row is shared"
@@ -300,18 +244,24 @@ __global__ __launch_bounds__(FLAG_THREADS) void batch_flags_kernel(const FlagArg
 // Output = the batch's references in ascending row order (inside a row: arrival order — it only permutes the fp32
 // summation order of the run).  Measured at c2 (100 K rows = 7 chunks, 14 sweeps): 0.64 ms per 512 batches against
 // 0.88 ms for rocprim's segmented radix sort on the same keys; 20 K rows: 0.19 against 0.41 ms.
-constexpr int GRP_THREADS = 1024, GRP_BINS = 16384, GRP_BIN_BITS = 14, GRP_CAP = 22528, GRP_U = 8, GRP_MAX_CHUNKS = 8;
-constexpr int GRP_WMAX = 16;  // windows per chunk: 2B / GRP_CAP + 2 <= 14 for 2B <= 2^18
+// Any table size (the chunk loop just gets longer: every batch of the slice is grouped by its own workgroup at the same
+// time, so a 1M-row table's 61 chunks cost the slice 61 x 2 sweeps over ids that sit in L2, not 61 x the slice) and any
+// batch up to 2^21 references: a staged word packs (row in chunk, payload) into 32 bits, so a batch whose payload needs
+// more than 18 bits takes chunks of 2^(32 - payload bits) rows instead of 2^14 (BIN_BITS template parameter).
+constexpr int GRP_THREADS = 1024, GRP_MAX_BIN_BITS = 14, GRP_MIN_BIN_BITS = 10, GRP_CAP = 22528, GRP_U = 8;
+constexpr int GRP_LDS_WORDS = (1 << GRP_MAX_BIN_BITS) + GRP_CAP;  // cursors + staging buffer (152 KB)
+constexpr int GRP_WMAX = 256;  // windows per chunk: 2B / GRP_CAP + 2
 
 // SRC 0: the references' rows are the pos / neg ids (payload 2t + w).  SRC 1: they come interleaved, keys[2t] / keys[2t+1]
 // (the metadata columns: `pos_all` is that array, read 8 bytes per triple).  SRC 2: ONE reference per position — the
 // users of a batch (`pos_all` = user ids): B references per batch, payload = the position in the SLICE, b * batch + t.
-template <int SRC>
+template <int SRC, int BIN_BITS>
 __global__ __launch_bounds__(GRP_THREADS) void batch_group_items_kernel(const int32_t* __restrict__ pos_all,
                                                                        const int32_t* __restrict__ neg_all,
                                                                        int64_t batch, int64_t n_items, int pb,
                                                                        uint32_t* __restrict__ keys_all,
                                                                        RefPayload* __restrict__ vals_all) {
+  constexpr int GRP_BINS = 1 << BIN_BITS;
   extern __shared__ uint32_t grp_lds[];
   uint32_t* cur = grp_lds;               // GRP_BINS counters, then cursors
   uint32_t* stage = grp_lds + GRP_BINS;  // GRP_CAP packed (row in chunk << pb) | payload
@@ -1035,12 +985,51 @@ static int bits_for(int64_t n) {
   return b;
 }
 
+// batch_group_items_kernel<SRC> for n_batches batches of `batch` positions over a table of n_rows rows.  pay_bits = bits
+// of the largest payload (SRC 0 / 1: 2 * batch references, SRC 2: batch).  0, or a negative error.
+template <int SRC>
+static int launch_group(const int32_t* pos, const int32_t* neg, int64_t n_batches, int64_t batch, int64_t n_rows,
+                        int pay_bits, uint32_t* keys_out, RefPayload* vals_out, hipStream_t s, const char* who) {
+  const int refs_bits = bits_for((SRC == 2 ? 1 : 2) * batch);
+  int bin_bits = 32 - pay_bits;
+  if (bin_bits > GRP_MAX_BIN_BITS) bin_bits = GRP_MAX_BIN_BITS;
+  if (bin_bits < GRP_MIN_BIN_BITS || ((int64_t)1 << refs_bits) / GRP_CAP + 2 > GRP_WMAX) {
+    trs_set_error("%s: a batch of %lld positions is too long for the per-batch grouping (at most 2^21 references)", who,
+                  (long long)batch);
+    return TRS_E_ARG;
+  }
+  const size_t lds = (size_t)GRP_LDS_WORDS * 4;
+  const dim3 gr((unsigned)n_batches), bl(GRP_THREADS);
+#define TRS_GRP(BB)                                                                                                 \
+  case BB: {                                                                                                        \
+    static const int attr_done = [] { /* > 64 KB of dynamic LDS needs the opt-in, once per kernel (thread-safe static) */ \
+      (void)hipFuncSetAttribute((const void*)batch_group_items_kernel<SRC, BB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                GRP_LDS_WORDS * 4);                                                                  \
+      return 1;                                                                                                     \
+    }();                                                                                                            \
+    (void)attr_done;                                                                                                \
+    hipLaunchKernelGGL((batch_group_items_kernel<SRC, BB>), gr, bl, lds, s, pos, neg, batch, n_rows, pay_bits, keys_out, \
+                       vals_out);                                                                                   \
+    break;                                                                                                          \
+  }
+  switch (bin_bits) {
+    TRS_GRP(14)
+    TRS_GRP(13)
+    TRS_GRP(12)
+    TRS_GRP(11)
+    TRS_GRP(10)
+  }
+#undef TRS_GRP
+  TRS_CHECK_LAUNCH("batch_group_items_kernel");
+  return TRS_OK;
+}
+
 }  // namespace trs
 
 using namespace trs;
 
 // Sizes (bytes) a caller must provide for an epoch slice of n_batches whole batches:
-//   ids: 3 x n_pos int32 (user, pos, neg)   keys: 2 x (2 n_pos) keys   vals: 2 x (2 n_pos) x 8   temp: rocprim scratch
+//   ids: 3 x n_pos int32 (user, pos, neg)   keys: 2 x (2 n_pos) keys   vals: 2 x (2 n_pos) x 8   temp: 256 bytes, unused
 extern "C" int trs_epoch_presort_sizes(int64_t n_batches, int64_t batch, int64_t n_items, int64_t* key_bytes_out,
                                        int64_t* keys_total_bytes_out, int64_t* vals_total_bytes_out,
                                        int64_t* temp_bytes_out) {
@@ -1051,12 +1040,7 @@ extern "C" int trs_epoch_presort_sizes(int64_t n_batches, int64_t batch, int64_t
   TRS_REQUIRE(bits <= 32 && 2 * n_batches * batch < ((int64_t)1 << 32), "trs_epoch_presort_sizes: slice too long");
   const int kb = 4;
   const size_t n = (size_t)(2 * n_batches * batch);
-  size_t temp = 0;
-  hipError_t e = rocprim::segmented_radix_sort_pairs<ItemSortCfg>(
-      nullptr, temp, (uint32_t*)nullptr, (uint32_t*)nullptr,
-      ref_val_it(batch), (RefPayload*)nullptr, n, (unsigned)n_batches, seg_it(0, (uint32_t)(2 * batch)), seg_it(1, (uint32_t)(2 * batch)),
-      0u, (unsigned)bits, (hipStream_t)0);
-  TRS_REQUIRE(e == hipSuccess, "trs_epoch_presort_sizes: rocprim size query failed");
+  const size_t temp = 0;  // (no scratch since the vendor sort is gone; the argument stays for the ABI)
   *key_bytes_out = kb;
   *keys_total_bytes_out = 2 * (int64_t)n * kb;
   *vals_total_bytes_out = 2 * (int64_t)n * (int64_t)sizeof(RefPayload);
@@ -1108,57 +1092,49 @@ extern "C" int trs_epoch_presort(const int32_t* stream_ui_dev, const int32_t* ne
   const int src = !stream_ui_dev ? 0 : (neg_static_dev ? 2 : 1);
   hipStream_t s = (hipStream_t)stream;
   const dim3 gr(trs_grid(n_pos, TRS_BLOCK)), bl(TRS_BLOCK);
-  static const bool vendor_sort = getenv("TRS_VENDOR_SORT") && atoi(getenv("TRS_VENDOR_SORT")) != 0;  // A/B knob
-  const int pay_bits = bits_for(2 * batch);  // a staged word = (row in chunk, payload): GRP_BIN_BITS + pay_bits <= 32
-  const bool hand = !vendor_sort && n_items <= (int64_t)GRP_BINS * GRP_MAX_CHUNKS && GRP_BIN_BITS + pay_bits <= 32;
-  if (hand) a.keys = nullptr;  // the grouping kernel reads pos / neg themselves
+  const int pay_bits = bits_for(2 * batch);
+  a.keys = nullptr;  // the grouping kernel reads pos / neg themselves
   if (src == 0) hipLaunchKernelGGL((epoch_refs_kernel<uint32_t, 0>), gr, bl, 0, s, a);
   else if (src == 1) hipLaunchKernelGGL((epoch_refs_kernel<uint32_t, 1>), gr, bl, 0, s, a);
   else hipLaunchKernelGGL((epoch_refs_kernel<uint32_t, 2>), gr, bl, 0, s, a);
   TRS_CHECK_LAUNCH("epoch_refs_kernel");
   const size_t n = (size_t)(2 * n_pos);
-  size_t temp = (size_t)temp_bytes;
+  (void)temp_bytes;
   RefPayload* vin = (RefPayload*)vals_dev;
   RefPayload* vout = vin + n;
   uint32_t* kin = (uint32_t*)keys_dev;
-  if (hand) {
-    // hand-written grouping (counting sort in LDS, one workgroup per batch): no key array, no vendor library
-    static bool attr_done = false;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute((const void*)batch_group_items_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (GRP_BINS + GRP_CAP) * 4);
-      attr_done = true;
-    }
-    hipLaunchKernelGGL(batch_group_items_kernel<0>, dim3((unsigned)n_batches), dim3(GRP_THREADS),
-                       (size_t)(GRP_BINS + GRP_CAP) * 4, s, (const int32_t*)pos_dev, (const int32_t*)neg_dev, batch,
-                       n_items, pay_bits, kin + n, vout);
-    TRS_CHECK_LAUNCH("batch_group_items_kernel");
-    *sorted_keys_out = (void*)(kin + n);
-    *sorted_vals_out = (void*)vout;
-    if (item_dup_flags_out_dev) {
-      (void)hipMemsetAsync(item_dup_flags_out_dev, 0, n, s);
-      hipLaunchKernelGGL(item_flags_kernel, dim3(trs_grid((int64_t)n, TRS_BLOCK)), bl, 0, s, kin + n, vout, (int64_t)n,
-                         2 * batch, item_dup_flags_out_dev);
-      TRS_CHECK_LAUNCH("item_flags_kernel");
-    }
-    return TRS_OK;
-  }
-  hipError_t e = rocprim::segmented_radix_sort_pairs<ItemSortCfg>(
-      temp_dev, temp, kin, kin + n,
-      ref_val_it(batch), vout, n,
-      (unsigned)n_batches, seg_it(0, (uint32_t)(2 * batch)), seg_it(1, (uint32_t)(2 * batch)), 0u, (unsigned)bits, s);
+  // hand-written grouping (counting sort in LDS, one workgroup per batch): no key array, no vendor library
+  const int rc = launch_group<0>((const int32_t*)pos_dev, (const int32_t*)neg_dev, n_batches, batch, n_items, pay_bits,
+                                 kin + n, vout, s, "trs_epoch_presort");
+  if (rc) return rc;
   *sorted_keys_out = (void*)(kin + n);
   *sorted_vals_out = (void*)vout;
-  if (e != hipSuccess) {
-    trs_set_error("trs_epoch_presort: rocprim::segmented_radix_sort_pairs failed: %s", hipGetErrorString(e));
-    return TRS_E_LAUNCH;
-  }
   if (item_dup_flags_out_dev) {
     (void)hipMemsetAsync(item_dup_flags_out_dev, 0, n, s);
     hipLaunchKernelGGL(item_flags_kernel, dim3(trs_grid((int64_t)n, TRS_BLOCK)), bl, 0, s, kin + n, vout, (int64_t)n,
                        2 * batch, item_dup_flags_out_dev);
     TRS_CHECK_LAUNCH("item_flags_kernel");
   }
+  return TRS_OK;
+}
+
+// batch_flags_kernel<NG> with as many 64-bit words of "came later" bits per thread as the batch needs
+static int launch_flags(const FlagArgs& a, int64_t n_batches, size_t lds, hipStream_t s) {
+  const int64_t per_group = (int64_t)FLAG_THREADS * FLAG_U * FLAG_ROUNDS;
+  const int ng = (int)((a.batch + per_group - 1) / per_group);
+  const dim3 gr((unsigned)n_batches), bl(FLAG_THREADS);
+#define TRS_FL(NG)                                                                                                   \
+  {                                                                                                                  \
+    static const int attr_done = [] { /* > 64 KB of dynamic LDS needs the opt-in once per kernel */                   \
+      (void)hipFuncSetAttribute((const void*)batch_flags_kernel<NG>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); \
+      return 1;                                                                                                      \
+    }();                                                                                                             \
+    (void)attr_done;                                                                                                 \
+    hipLaunchKernelGGL((batch_flags_kernel<NG>), gr, bl, lds, s, a);                                                  \
+  }
+  if (ng <= 1) TRS_FL(1) else if (ng == 2) TRS_FL(2) else TRS_FL(4)
+#undef TRS_FL
+  TRS_CHECK_LAUNCH("batch_flags_kernel");
   return TRS_OK;
 }
 
@@ -1172,9 +1148,9 @@ extern "C" int trs_epoch_flags(const int32_t* stream_ui_dev, const int32_t* neg_
   TRS_REQUIRE(!sampler || (sampler->k_neg >= 1 && (!sampler->popularity || (sampler->pop_items && sampler->pop_n > 0)) &&
                            ((sampler->seen_off == nullptr) == (sampler->seen_items == nullptr))),
               "trs_epoch_flags: bad sampler options");
-  TRS_REQUIRE(batch <= (int64_t)FLAG_THREADS * FLAG_U * FLAG_MAX_ROUNDS,
+  TRS_REQUIRE(batch <= (int64_t)FLAG_THREADS * FLAG_U * FLAG_ROUNDS * FLAG_MAX_GROUPS,
               "trs_epoch_flags: batch %lld exceeds %d (one workgroup per batch keeps a bit per reference in registers)",
-              (long long)batch, FLAG_THREADS * FLAG_U * FLAG_MAX_ROUNDS);
+              (long long)batch, FLAG_THREADS * FLAG_U * FLAG_ROUNDS * FLAG_MAX_GROUPS);
   TRS_REQUIRE(n_batches > 0 && batch > 0 && batch < ((int64_t)1 << 30) && n_users > 0 && n_items > 0 &&
                   n_users < ((int64_t)1 << 31) && n_items < ((int64_t)1 << 31), "trs_epoch_flags: bad sizes");
   TRS_REQUIRE(user_dev && pos_dev && neg_dev && user_dup_flags_out_dev && item_dup_flags_out_dev,
@@ -1229,19 +1205,9 @@ extern "C" int trs_epoch_flags(const int32_t* stream_ui_dev, const int32_t* neg_
     TRS_CHECK_LAUNCH("epoch_refs_kernel");
     src = 0;  // the ids now exist (validated and clamped): the flags kernel takes them as given
   }
-  const dim3 gr((unsigned)n_batches), bl(FLAG_THREADS);
-#define TRS_FL(SRC)                                                                                             \
-  {                                                                                                             \
-    static bool attr_done = false; /* > 64 KB of dynamic LDS needs the opt-in once per kernel */                \
-    if (!attr_done) {                                                                                           \
-      (void)hipFuncSetAttribute((const void*)batch_flags_kernel<SRC>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                128 * 1024);                                                                    \
-      attr_done = true;                                                                                         \
-    }                                                                                                           \
-    hipLaunchKernelGGL((batch_flags_kernel<SRC>), gr, bl, lds, s, a);                                           \
-  }
-  if (src == 0) TRS_FL(0) else if (src == 1) TRS_FL(1) else TRS_FL(2)
-#undef TRS_FL
+  (void)src;  // the ids exist by now (given, or written by epoch_refs_kernel above): the flags kernel only reads them
+  const int rcf = launch_flags(a, n_batches, lds, s);
+  if (rcf) return rcf;
   TRS_CHECK_LAUNCH("batch_flags_kernel");
   return TRS_OK;
 }
@@ -1253,8 +1219,9 @@ extern "C" int trs_epoch_user_flags(const int32_t* user_dev, int64_t n_batches, 
                                     uint8_t* flags_out_dev, void* stream) {
   TRS_REQUIRE(user_dev && flags_out_dev && n_batches > 0 && batch > 0 && n_users > 0 && n_users < ((int64_t)1 << 31),
               "trs_epoch_user_flags: bad arguments");
-  TRS_REQUIRE(batch <= (int64_t)FLAG_THREADS * FLAG_U * FLAG_MAX_ROUNDS, "trs_epoch_user_flags: batch %lld exceeds %d",
-              (long long)batch, FLAG_THREADS * FLAG_U * FLAG_MAX_ROUNDS);
+  TRS_REQUIRE(batch <= (int64_t)FLAG_THREADS * FLAG_U * FLAG_ROUNDS * FLAG_MAX_GROUPS,
+              "trs_epoch_user_flags: batch %lld exceeds %d", (long long)batch,
+              FLAG_THREADS * FLAG_U * FLAG_ROUNDS * FLAG_MAX_GROUPS);
   FlagArgs a = {};
   a.batch = batch;
   a.n_users = n_users;
@@ -1268,19 +1235,14 @@ extern "C" int trs_epoch_user_flags(const int32_t* user_dev, int64_t n_batches, 
   a.user_hash = n_users > ((int64_t)1 << lb) ? 1 : 0;
   a.what_first = 1;
   a.what_end = 2;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)batch_flags_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    attr_done = true;
-  }
-  hipLaunchKernelGGL((batch_flags_kernel<0>), dim3((unsigned)n_batches), dim3(FLAG_THREADS), ((size_t)1 << lb) / 8,
-                     (hipStream_t)stream, a);
+  const int rcf = launch_flags(a, n_batches, ((size_t)1 << lb) / 8, (hipStream_t)stream);
+  if (rcf) return rcf;
   TRS_CHECK_LAUNCH("batch_flags_kernel");
   return TRS_OK;
 }
 
 // User-duplicate flags of an epoch slice (n_pos = n_batches*batch positions; position q < 2^32).  ukeys: 2 x n_pos keys
-// (4 B when bits(n_users)+bits(n_batches) <= 32, else 8 B), uvals: 2 x n_pos uint32, temp: rocprim scratch.
+// (4 B), uvals: 2 x n_pos uint32, temp: 256 bytes, unused.
 extern "C" int trs_epoch_user_dups_sizes(int64_t n_batches, int64_t batch, int64_t n_users, int64_t* ukeys_bytes_out,
                                          int64_t* uvals_bytes_out, int64_t* temp_bytes_out) {
   TRS_REQUIRE(n_batches > 0 && batch > 0 && n_users > 0 && ukeys_bytes_out && uvals_bytes_out && temp_bytes_out,
@@ -1290,12 +1252,7 @@ extern "C" int trs_epoch_user_dups_sizes(int64_t n_batches, int64_t batch, int64
   TRS_REQUIRE(bits <= 32, "trs_epoch_user_dups_sizes: user ids do not fit 32 bits");
   const int kb = 4;
   const size_t n = (size_t)(n_batches * batch);
-  size_t temp = 0;
-  hipError_t e = rocprim::segmented_radix_sort_pairs<UserSortCfg>(
-      nullptr, temp, (const uint32_t*)nullptr, (uint32_t*)nullptr, rocprim::counting_iterator<uint32_t>(0),
-      (uint32_t*)nullptr, n, (unsigned)n_batches, seg_it(0, (uint32_t)batch), seg_it(1, (uint32_t)batch), 0u,
-      (unsigned)bits, (hipStream_t)0);
-  TRS_REQUIRE(e == hipSuccess, "trs_epoch_user_dups_sizes: rocprim size query failed");
+  const size_t temp = 0;  // (no scratch: the argument stays for the ABI)
   *ukeys_bytes_out = 2 * (int64_t)n * kb;
   *uvals_bytes_out = 2 * (int64_t)n * 4;
   *temp_bytes_out = (int64_t)temp + 256;
@@ -1314,45 +1271,20 @@ extern "C" int trs_epoch_user_dups(const int32_t* user_dev, int64_t n_batches, i
   TRS_REQUIRE(user_bits <= 32, "trs_epoch_user_dups: user ids do not fit 32 bits");
   hipStream_t s = (hipStream_t)stream;
   const dim3 gr(trs_grid(n_pos, TRS_BLOCK)), bl(TRS_BLOCK);
-  size_t temp = (size_t)temp_bytes;
+  (void)temp_bytes;
   uint32_t* vin = (uint32_t*)uvals_dev;
   uint32_t* kin = (uint32_t*)ukeys_dev;
-  // one segment per batch; the sort reads the user ids where they lie (non-negative int32 = uint32 keys) and numbers
-  // the positions q with a counting iterator — no key / payload arrays are built first: two 10-bit passes for up to
-  // 2^20 users
-  hipError_t e = hipSuccess;
-  const char* vs_env = getenv("TRS_VENDOR_SORT");
-  if (!(vs_env && atoi(vs_env) != 0) && n_users <= (int64_t)GRP_BINS * GRP_MAX_CHUNKS &&
-      GRP_BIN_BITS + bits_for(batch) <= 32) {
-    // small user tables: the batch's users grouped by the hand-written counting sort (one reference per position)
-    static bool attr_done = false;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute((const void*)batch_group_items_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (GRP_BINS + GRP_CAP) * 4);
-      attr_done = true;
-    }
-    hipLaunchKernelGGL(batch_group_items_kernel<2>, dim3((unsigned)n_batches), dim3(GRP_THREADS),
-                       (size_t)(GRP_BINS + GRP_CAP) * 4, s, user_dev, (const int32_t*)nullptr, batch, n_users,
-                       bits_for(batch), kin + n_pos, (RefPayload*)(vin + n_pos));
-  } else {
-    e = rocprim::segmented_radix_sort_pairs<UserSortCfg>(
-        temp_dev, temp, (const uint32_t*)user_dev, kin + n_pos, rocprim::counting_iterator<uint32_t>(0), vin + n_pos,
-        (size_t)n_pos, (unsigned)n_batches, seg_it(0, (uint32_t)batch), seg_it(1, (uint32_t)batch), 0u,
-        (unsigned)user_bits, s);
-  }
-  if (e == hipSuccess) {
-    (void)hipMemsetAsync(flags_out_dev, 0, (size_t)n_pos, s);
-    hipLaunchKernelGGL((user_flags_kernel<uint32_t>), gr, bl, 0, s, kin + n_pos, vin + n_pos, n_pos, batch,
-                       flags_out_dev);
-  }
+  // one batch per workgroup: the batch's users grouped by the counting sort (one reference per position; the user ids are
+  // read where they lie, the payload is the position in the slice)
+  const int rc = launch_group<2>(user_dev, (const int32_t*)nullptr, n_batches, batch, n_users, bits_for(batch),
+                                 kin + n_pos, (RefPayload*)(vin + n_pos), s, "trs_epoch_user_dups");
+  if (rc) return rc;
+  (void)hipMemsetAsync(flags_out_dev, 0, (size_t)n_pos, s);
+  hipLaunchKernelGGL((user_flags_kernel<uint32_t>), gr, bl, 0, s, kin + n_pos, vin + n_pos, n_pos, batch, flags_out_dev);
   if (sorted_ukeys_out) *sorted_ukeys_out = (void*)(kin + n_pos);
   if (ukey_bytes_out) *ukey_bytes_out = 4;
   if (sorted_uvals_out) *sorted_uvals_out = (void*)(vin + n_pos);
-  if (e != hipSuccess) {
-    trs_set_error("trs_epoch_user_dups: rocprim::segmented_radix_sort_pairs failed: %s", hipGetErrorString(e));
-    return TRS_E_LAUNCH;
-  }
-  TRS_CHECK_LAUNCH("user_keys/flags_kernel");
+  TRS_CHECK_LAUNCH("user_flags_kernel");
   return TRS_OK;
 }
 
@@ -1401,33 +1333,12 @@ extern "C" int trs_epoch_presort_meta(const int32_t* pos_dev, const int32_t* neg
   hipLaunchKernelGGL(meta_refs_kernel, dim3(trs_grid(n_pos, TRS_BLOCK)), dim3(TRS_BLOCK), 0, s, pos_dev, neg_dev, n_pos,
                      batch, item_meta_dev, M, m, n_cat, kin, vin, err_flag_dev, pos_meta_out_dev, neg_meta_out_dev);
   TRS_CHECK_LAUNCH("meta_refs_kernel");
-  size_t temp = (size_t)temp_bytes;
+  (void)temp_bytes;
   *sorted_keys_out = (void*)(kin + n);
   *sorted_vals_out = (void*)(vin + n);
-  const char* vs_env = getenv("TRS_VENDOR_SORT");
-  if (!(vs_env && atoi(vs_env) != 0) && n_cat <= (int64_t)GRP_BINS * GRP_MAX_CHUNKS &&
-      GRP_BIN_BITS + bits_for(2 * batch) <= 32) {
-    // the column's references grouped by the hand-written counting sort (categories = rows; keys interleaved in kin)
-    static bool attr_done = false;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute((const void*)batch_group_items_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (GRP_BINS + GRP_CAP) * 4);
-      attr_done = true;
-    }
-    hipLaunchKernelGGL(batch_group_items_kernel<1>, dim3((unsigned)n_batches), dim3(GRP_THREADS),
-                       (size_t)(GRP_BINS + GRP_CAP) * 4, s, (const int32_t*)kin, (const int32_t*)nullptr, batch, n_cat,
-                       bits_for(2 * batch), kin + n, vin + n);
-    TRS_CHECK_LAUNCH("batch_group_items_kernel");
-    return TRS_OK;
-  }
-  hipError_t e = rocprim::segmented_radix_sort_pairs<ItemSortCfg>(
-      temp_dev, temp, kin, kin + n, ref_val_it(batch), vin + n, n, (unsigned)n_batches,
-      seg_it(0, (uint32_t)(2 * batch)), seg_it(1, (uint32_t)(2 * batch)), 0u, (unsigned)bits_for(n_cat), s);
-  if (e != hipSuccess) {
-    trs_set_error("trs_epoch_presort_meta: rocprim::segmented_radix_sort_pairs failed: %s", hipGetErrorString(e));
-    return TRS_E_LAUNCH;
-  }
-  return TRS_OK;
+  // the column's references grouped by the counting sort (categories = rows; keys interleaved in kin)
+  return launch_group<1>((const int32_t*)kin, (const int32_t*)nullptr, n_batches, batch, n_cat, bits_for(2 * batch),
+                         kin + n, vin + n, s, "trs_epoch_presort_meta");
 }
 
 // One launch of the sorted item update for a step (used by trs_train_steps_sgd's sorted mode).

@@ -31,10 +31,29 @@ void trs_set_error(const char* fmt, ...);
     }                                                                      \
   } while (0)
 
+// Tuning / A-B knobs of the launch paths (kernel selection, launch shapes).  The defaults are the measured best; nothing
+// in the product path needs them.  Read from the TRS_* environment ONCE, when the library is first used (api.cpp) — no
+// launch path calls getenv — and changeable afterwards through trs_tuning_set (include/trs.h: tests, tools/).
+// -1 = "not set: decide by shape" where a knob overrides an automatic choice.
+struct TrsTuning {
+  int64_t grid_cap;       // TRS_GRID_CAP        workgroups of a grid-stride kernel (256 CUs x 16)
+  int64_t pass_grid_cap;  // TRS_PASS_GRID_CAP   ... of pair_scores_kernel (4096)
+  int k1_iters;           // TRS_K1_ITERS        pipelined iterations per lane group of fwd_stage_kernel (0: by batch)
+  int pass_iters;         // TRS_PASS_ITERS      ... of pair_scores_kernel (0: by batch)
+  int pass_nt;            // TRS_PASS_NT         nontemporal rows in the scoring pass: bit 0 user, bit 1 item (-1)
+  int k1_nt;              // TRS_K1_NT           nontemporal user rows in the one-launch step: 1 loads, 3 loads + stores (-1)
+  int gemm32_no_glds;     // TRS_GEMM32_NO_GLDS  1: fp32 NT GEMMs on the register-staged 128 x 128 kernel
+  int gemm16_tn_wide;     // TRS_GEMM16_TN_WIDE  0 | 1: weight-gradient GEMMs on 256 x 256 tiles (-1)
+  int gemm16_tile;        // TRS_GEMM16_TILE     128 | 256 | 512: force the bf16-resident tile (0)
+  int gemm16_no_glds;     // TRS_GEMM16_NO_GLDS  1: bf16 NT GEMMs on the register-staged 256 x 256 kernel
+  int bn_final_two_sweeps;  // TRS_BN_FINAL_TWO_SWEEPS  1: the two-sweep finalise kernels
+};
+TrsTuning& trs_tuning();
+
 // grid for a memory-bound grid-stride kernel: enough workgroups to fill 256 CUs x 16 blocks, no more (measured on the
 // update kernels: 512 blocks 31 us, 1024 23 us, 4096 21 us, 16384 21 us).
 static inline int trs_grid(int64_t work_items, int items_per_block) {
-  static const int64_t cap = getenv("TRS_GRID_CAP") ? atoll(getenv("TRS_GRID_CAP")) : 256 * 16;  // tuning knob
+  const int64_t cap = trs_tuning().grid_cap;
   int64_t g = (work_items + items_per_block - 1) / items_per_block;
   if (g < 1) g = 1;
   if (g > cap) g = cap;

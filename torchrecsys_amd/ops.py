@@ -304,7 +304,7 @@ class EpochFlags:
     """The sparse regime's presort (trs_epoch_flags): ids of n_batches whole batches + conservative duplicate flags,
     one launch, no sort.  Same surface as EpochPresort where the step loop needs it."""
 
-    MAX_BATCH = 65_536  # one workgroup per batch (csrc/presort.hip FLAG_THREADS * FLAG_U * FLAG_MAX_ROUNDS)
+    MAX_BATCH = 262_144  # one workgroup per batch (csrc/presort.hip FLAG_THREADS * FLAG_U * FLAG_ROUNDS * FLAG_MAX_GROUPS)
 
     def __init__(self, n_batches, batch, n_users, n_items, device):
         self.n_batches, self.batch, self.n_users, self.n_items = n_batches, batch, n_users, n_items
