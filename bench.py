@@ -495,13 +495,13 @@ def main():
         # A constant read from that file, not a live measurement: named in traffic_source; null when no profile of the
         # running config exists.
         traffic, traffic_source = None, None
-        pmc_path = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_{args.config}.json")
+        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"{r_}_pmc_traffic_{args.config}.json") for r_ in ("r03", "r02")) if os.path.exists(q)), "")
         if world == 1 and args.optimizer == "sgd" and os.path.exists(pmc_path):
             pk = json.load(open(pmc_path))["kernels"]
             parts = {"item_update_kernel": ("item_owner_update_kernel", "item_update_kernel")}.get(dom, (dom,))
             if all(q in pk for q in parts):
                 traffic = sum(pk[q]["traffic_bytes_per_launch"] for q in parts)
-                traffic_source = f"profiles/r02_pmc_traffic_{args.config}.json (rocprofv3 --pmc, not measured in this run)"
+                traffic_source = f"profiles/{os.path.basename(pmc_path)} (rocprofv3 --pmc, not measured in this run)"
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                            "samples": n_samples[dom],

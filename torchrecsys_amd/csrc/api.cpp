@@ -28,6 +28,7 @@ struct Knob {
 const Knob KNOBS[] = {
     {"GRID_CAP", &TrsTuning::grid_cap, nullptr, 256 * 16},
     {"PASS_GRID_CAP", &TrsTuning::pass_grid_cap, nullptr, 4096},
+    {"PRESORT_GRID_CAP", &TrsTuning::presort_grid_cap, nullptr, 512},
     {"K1_ITERS", nullptr, &TrsTuning::k1_iters, 0},
     {"PASS_ITERS", nullptr, &TrsTuning::pass_iters, 0},
     {"PASS_NT", nullptr, &TrsTuning::pass_nt, -1},

@@ -217,6 +217,10 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
   const int64_t stride = nwave * TPW;  // triples between two iterations of one lane group
   float loss_acc = 0.f;
 
+#ifdef TRS_K1_STAMPS  // diagnostic build only (tools/k1_stamps.py): s_memrealtime (100 MHz) at four points of every workgroup
+  uint64_t* stamps = reinterpret_cast<uint64_t*>(a.gz) + 4 * (int64_t)blockIdx.x;  // (gz is unused in INL 3)
+  if (INL == 3 && threadIdx.x == 0) stamps[0] = __builtin_amdgcn_s_memrealtime();
+#endif
   int64_t t = wave * TPW + lane / G;
   // wave-uniform trip count: the wave's first group decides (its t is the smallest of the wave)
   const int64_t t_first = wave * TPW;
@@ -367,6 +371,9 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
     reduce(rO, idO, t + stride);
     t += 2 * stride;
   }
+#ifdef TRS_K1_STAMPS
+  if (INL == 3 && threadIdx.x == 0) stamps[1] = __builtin_amdgcn_s_memrealtime();
+#endif
   __shared__ float s_loss[TRS_BLOCK / TRS_WAVE];
   const float wl = trs_wave_sum(loss_acc);
   if (lane == 0) s_loss[threadIdx.x >> 6] = wl;
@@ -448,12 +455,19 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
       }
     }
     __syncthreads();
+#ifdef TRS_K1_STAMPS
+    if (threadIdx.x == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();
+#endif
     // every row read of the step is behind us, chip-wide
     apply_round();
     for (int e0 = DU; e0 < n_list; e0 += DU) {
       load_round(e0);
       apply_round();
     }
+#ifdef TRS_K1_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) stamps[3] = __builtin_amdgcn_s_memrealtime();
+#endif
   }
 }
 

@@ -979,6 +979,17 @@ void sorted_updates_fused_kernel(const SortedArgs ia, const UserDupArgs ua,
                                                                    (int)gridDim.x - n_user_blocks);
 }
 
+// Grid of epoch_refs_kernel.  It runs on a side stream BESIDE the training steps and is a chain of random 8-byte reads:
+// launched as wide as the chip (4096 workgroups of 256 threads, 31 VGPRs: 8 per CU = every wave slot) it finishes a
+// 512-batch slice in 0.4 ms — and for those 0.4 ms no workgroup of a step kernel finds a wave slot (rocprofv3, c4: step
+// launches of 280 us beside a 33 us median, every slice).  Two workgroups per CU leave three quarters of the slots to
+// the steps; the slice's ids then take ~4x as long, of the 18 ms the slice's steps run.
+static inline int presort_grid(int64_t n_pos) {
+  const int64_t cap = trs_tuning().presort_grid_cap;
+  int64_t g = (n_pos + TRS_BLOCK - 1) / TRS_BLOCK;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
 static int bits_for(int64_t n) {
   int b = 1;
   while (b < 63 && ((int64_t)1 << b) < n) ++b;
@@ -1091,7 +1102,7 @@ extern "C" int trs_epoch_presort(const int32_t* stream_ui_dev, const int32_t* ne
   TRS_REQUIRE(bits <= 32 && 2 * n_pos < ((int64_t)1 << 32), "trs_epoch_presort: slice too long");
   const int src = !stream_ui_dev ? 0 : (neg_static_dev ? 2 : 1);
   hipStream_t s = (hipStream_t)stream;
-  const dim3 gr(trs_grid(n_pos, TRS_BLOCK)), bl(TRS_BLOCK);
+  const dim3 gr(presort_grid(n_pos)), bl(TRS_BLOCK);
   const int pay_bits = bits_for(2 * batch);
   a.keys = nullptr;  // the grouping kernel reads pos / neg themselves
   if (src == 0) hipLaunchKernelGGL((epoch_refs_kernel<uint32_t, 0>), gr, bl, 0, s, a);
@@ -1199,7 +1210,7 @@ extern "C" int trs_epoch_flags(const int32_t* stream_ui_dev, const int32_t* neg_
     e.err = err_flag_dev;
     e.S = trs_sampler_args(sampler);
     e.hb = trs_feistel_half_bits(N * kn);
-    const dim3 ge(trs_grid(e.n_pos, TRS_BLOCK)), be(TRS_BLOCK);
+    const dim3 ge(presort_grid(e.n_pos)), be(TRS_BLOCK);
     if (src == 1) hipLaunchKernelGGL((epoch_refs_kernel<uint32_t, 1>), ge, be, 0, s, e);
     else hipLaunchKernelGGL((epoch_refs_kernel<uint32_t, 2>), ge, be, 0, s, e);
     TRS_CHECK_LAUNCH("epoch_refs_kernel");

@@ -38,6 +38,7 @@ void trs_set_error(const char* fmt, ...);
 struct TrsTuning {
   int64_t grid_cap;       // TRS_GRID_CAP        workgroups of a grid-stride kernel (256 CUs x 16)
   int64_t pass_grid_cap;  // TRS_PASS_GRID_CAP   ... of pair_scores_kernel (4096)
+  int64_t presort_grid_cap;  // TRS_PRESORT_GRID_CAP  ... of epoch_refs_kernel on the side stream (512: see presort.hip)
   int k1_iters;           // TRS_K1_ITERS        pipelined iterations per lane group of fwd_stage_kernel (0: by batch)
   int pass_iters;         // TRS_PASS_ITERS      ... of pair_scores_kernel (0: by batch)
   int pass_nt;            // TRS_PASS_NT         nontemporal rows in the scoring pass: bit 0 user, bit 1 item (-1)
