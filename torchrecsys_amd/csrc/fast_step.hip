@@ -179,9 +179,10 @@ __device__ __forceinline__ void load_rows(TripleRows<VEC, K>& r, const trs_table
 // user row is staged only when one of the triple's item references still goes through the runs.  At c4 (65 536
 // references over 1M items per step) 94 % of the references are alone: the step becomes one read and one write per row.
 // INL 3 (flag mode as ONE launch per step; launch_fwd_stage picks it when every workgroup of the grid is resident at
-// once): INL 2, and the flagged references are applied by this same launch instead of flagged_update_kernel.  Every wave
-// lists its flagged references in LDS — (triple, which) | table row | coefficient | coefficient of the 1-wide term, no
-// atomics: slots come from ballots — and stages their rows in global memory as in INL 2.  After its last triple a
+// once): INL 2, and the flagged references are applied by this same launch instead of flagged_update_kernel.  The
+// workgroup lists its flagged references in LDS — (triple, which) | table row | coefficient | coefficient of the 1-wide
+// term; a wave takes its slots with ONE LDS atomic per iteration, positions inside come from ballots — and stages their
+// rows in global memory as in INL 2.  After its last triple a
 // workgroup waits for its loads and stores (s_waitcnt vmcnt(0) + barrier), counts itself in on the step's arrival
 // counter and waits until ALL workgroups of the launch have done so: from then on no row of the tables is read any more
 // by this step, so the float atomics of the flagged references — each workgroup re-reads the rows IT staged (same CU:
@@ -204,9 +205,10 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
   constexpr int N = K * VEC;
   constexpr int TPW = TRS_WAVE / G;
   constexpr bool DEFER = INL == 3;
-  constexpr int LIST_CAP = DEFER ? DEFER_ITERS * TPW * 3 : 1;
-  __shared__ DeferEntry s_list[TRS_BLOCK / TRS_WAVE][LIST_CAP];
-  int n_list = 0;  // wave-uniform: entries of this wave's list
+  constexpr int NWV = TRS_BLOCK / TRS_WAVE;
+  constexpr int LIST_CAP = DEFER ? NWV * DEFER_ITERS * TPW * 3 : 1;  // every reference of the workgroup's triples
+  __shared__ DeferEntry s_list[LIST_CAP];  // ONE list per workgroup: slots handed out by an LDS counter
+  __shared__ int s_total;                  // entries of s_list
   const trs_tables& T = a.T;
   const int D = T.D;
   const int64_t B = a.B;
@@ -221,6 +223,10 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
   uint64_t* stamps = reinterpret_cast<uint64_t*>(a.gz) + 4 * (int64_t)blockIdx.x;  // (gz is unused in INL 3)
   if (INL == 3 && threadIdx.x == 0) stamps[0] = __builtin_amdgcn_s_memrealtime();
 #endif
+  if (DEFER) {
+    if (threadIdx.x == 0) s_total = 0;
+    __syncthreads();
+  }
   int64_t t = wave * TPW + lane / G;
   // wave-uniform trip count: the wave's first group decides (its t is the smallest of the wave)
   const int64_t t_first = wave * TPW;
@@ -271,12 +277,17 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
       const bool lead = lig == 0 && live;
       const uint64_t mu = __ballot(lead && id.dup), mp = __ballot(lead && id.pdup), mn = __ballot(lead && id.ndup);
       const uint64_t below = ((uint64_t)1 << lane) - 1;
-      DeferEntry* L = s_list[threadIdx.x >> 6];
-      const int bu = n_list, bp = bu + __popcll(mu), bn = bp + __popcll(mp);
+      const int cu = __popcll(mu), cp = __popcll(mp), cn = __popcll(mn);
+      int bu = 0;
+      if (cu + cp + cn) {  // (wave-uniform) this wave's slots of the workgroup's list: one LDS atomic per iteration
+        if (lane == 0) bu = atomicAdd(&s_total, cu + cp + cn);
+        bu = __builtin_amdgcn_readfirstlane(bu);
+      }
+      DeferEntry* L = s_list;
+      const int bp = bu + cu, bn = bp + cp;
       if (lead && id.dup) L[bu + __popcll(mu & below)] = {(uint32_t)tt << 2, id.u, -a.lr, -a.lr * (gp + gn)};
       if (lead && id.pdup) L[bp + __popcll(mp & below)] = {((uint32_t)tt << 2) | 1u, id.p, -a.lr * gp, -a.lr * gp};
       if (lead && id.ndup) L[bn + __popcll(mn & below)] = {((uint32_t)tt << 2) | 2u, id.n, -a.lr * gn, -a.lr * gn};
-      n_list = bn + __popcll(mn);
     }
     if (id.valid) {
       RowReg<VEC, K> g;
@@ -352,12 +363,15 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
   // value forces the wait for it): triple k's rows live in the "even" or "odd" register set by parity; in triple k's
   // phase the ids of k+2 are issued, the ids of k+1 consumed and its rows issued, then triple k is reduced.  Program
   // order = issue order, so each wait covers only loads older than everything that should stay in flight.
+  TripleIds idE, idO;
+  TripleRows<VEC, K> rE, rO;
+  {
+  // (INL 3: handing the workgroup's (iteration, wave) chunks out dynamically through an LDS counter was built and
+  // measured: no change — the launch's slow tail is whole workgroups on slower XCDs / CUs, not single waves)
   const int64_t niter2 = (niter + 1) & ~(int64_t)1;  // even trip count: surplus phases run on clamped, invalid triples
   RawIds wE = issue_ids<SRC, INL>(a, t);
   RawIds wO = issue_ids<SRC, INL>(a, t + stride);
-  TripleIds idE = finalize_ids<SRC>(a, wE);
-  TripleIds idO;
-  TripleRows<VEC, K> rE, rO;
+  idE = finalize_ids<SRC>(a, wE);
   load_rows<VEC, G, K, FULL, OPT, NTU>(rE, T, a.o, idE, lig);
   for (int64_t it = 0; it < niter2; it += 2) {
     wE = issue_ids<SRC, INL>(a, t + 2 * stride);
@@ -370,6 +384,7 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
     load_rows<VEC, G, K, FULL, OPT, NTU>(rE, T, a.o, idE, lig);
     reduce(rO, idO, t + stride);
     t += 2 * stride;
+  }
   }
 #ifdef TRS_K1_STAMPS
   if (INL == 3 && threadIdx.x == 0) stamps[1] = __builtin_amdgcn_s_memrealtime();
@@ -386,18 +401,23 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
     if (L != 0.f) atomicAdd(a.loss_sum, L);
   }
   if (DEFER) {
-    // this wave's flagged references, DU at a time: the staged rows of a round are loaded together (L2: written by this
-    // CU a moment ago), then one float atomic per element, a row = adjacent dwords (the full-rate atomic shape)
+    // The workgroup's flagged references are dealt round-robin to its four waves (a single wave's share of them is 0 to
+    // 6 at c4, and the longest one of the launch would set the kernel's end), DU at a time: the staged rows of a round
+    // are loaded together (L2: written by this CU a moment ago), then one float atomic per element, a row = adjacent
+    // dwords (the full-rate atomic shape)
     constexpr int DU = 4, KDD = (N * G + TRS_WAVE - 1) / TRS_WAVE;
-    const DeferEntry* L = s_list[threadIdx.x >> 6];
+    const int wv = threadIdx.x >> 6;
+    const int total = s_total;
+    const int n_mine = total > wv ? (total - wv + NWV - 1) / NWV : 0;  // entries wv, wv + NWV, ... of the list
     float x[DU][KDD], cc[DU], cl[DU];
     float *dst[DU], *dlin[DU];
     bool has[DU];
     auto load_round = [&](int e0) {
 #pragma unroll
       for (int k = 0; k < DU; ++k) {
-        has[k] = e0 + k < n_list;
-        const DeferEntry en = L[has[k] ? e0 + k : 0];  // same address in every lane: one LDS broadcast
+        has[k] = e0 + k < n_mine;
+        // (same address in every lane: one LDS broadcast; without an entry, slot 0 is read as a dummy and not used)
+        const DeferEntry en = s_list[has[k] ? wv + NWV * (e0 + k) : 0];
         const int which = (int)(en.tw & 3u);
         const int64_t tk = has[k] ? (int64_t)(en.tw >> 2) : 0;
         const int64_t rk = has[k] ? (int64_t)en.row : 0;
@@ -460,7 +480,7 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
 #endif
     // every row read of the step is behind us, chip-wide
     apply_round();
-    for (int e0 = DU; e0 < n_list; e0 += DU) {
+    for (int e0 = DU; e0 < n_mine; e0 += DU) {
       load_round(e0);
       apply_round();
     }
