@@ -315,7 +315,7 @@ def test_hinge_auc():
                                           (50_000, 131_072, 1, True), (50_000, 131_073, 1, False)])
 def test_item_references_grouped_by_row(NI, B, nb, skew):
     """trs_epoch_presort's grouping of every batch's 2B item references — the hand-written counting sort in LDS (tables up
-    to 8 chunks of 16 384 rows and batches up to 131 072; beyond either: the segmented radix sort) — sizes either side
+    to 8 chunks of 16 384 rows in rounds 1-2, any number since round 3: the same kernel walks more chunks) — sizes either side
     of the chunk and hand-over boundaries, ragged batches, hot rows longer than the staging buffer (zipf: a quarter of a
     65 536-batch on one row): per batch the keys are the batch's pos / neg rows in ascending order, the payloads a
     permutation of 0..2B-1 with ids[payload] == key.  Bit-exact (index work)."""
@@ -350,7 +350,7 @@ def test_item_references_grouped_by_row(NI, B, nb, skew):
                                           (131_072, 4096, 2, False), (131_073, 4096, 2, False)])
 def test_users_grouped_by_row_for_the_duplicate_runs(NU, B, nb, skew):
     """trs_epoch_user_dups: every batch's users grouped by row (the counting sort with ONE reference per position for user
-    tables up to 131 072 rows, incl. a hot user longer than the staging buffer; 131 073 rows: the segmented radix sort) —
+    tables of any size, incl. a hot user longer than the staging buffer and one row more than 8 chunks of 16 384) —
     keys ascending per batch, payloads the slice positions of the batch, user[payload] == key; the duplicate flags == a
     bincount.  Bit-exact."""
     ops = _ops()

@@ -705,7 +705,7 @@ __device__ __forceinline__ void sorted_item_update_staged_body(const SortedArgs&
 
 // ---------------------------------------------------------------------------------------------- user duplicates
 // flags[q] = 1 iff the user of position q is referenced by another triple of the same batch (static for the epoch):
-// segmented sort of (user, q) with one segment per batch, then compare neighbours inside the segment.
+// per-batch grouping of (user, q) by user, then compare neighbours inside the batch.
 template <typename KeyT>
 __global__ __launch_bounds__(TRS_BLOCK) void user_flags_kernel(const KeyT* __restrict__ keys,
                                                               const uint32_t* __restrict__ vals, int64_t n_pos,
@@ -1224,7 +1224,7 @@ extern "C" int trs_epoch_flags(const int32_t* stream_ui_dev, const int32_t* neg_
 }
 
 // User-duplicate flags alone (conservative when n_users exceeds the bitmap): the dense regime's plain-SGD step needs no
-// sorted user runs (flagged users add their staged gradient with float atomics), so the second segmented sort of the
+// sorted user runs (flagged users add their staged gradient with float atomics), so the per-batch grouping of the users of the
 // slice is replaced by the bitmap kernel restricted to the user ids.
 extern "C" int trs_epoch_user_flags(const int32_t* user_dev, int64_t n_batches, int64_t batch, int64_t n_users,
                                     uint8_t* flags_out_dev, void* stream) {

@@ -160,7 +160,7 @@ class SparseScorerTrainer:
     def _sync(self):
         """(device arrival counter, host count of scheduled arrivals) of the one-launch flag-mode step
         (trs_train_args.sync_dev / sync_count_host), or None: TRS_FLAG_ONE_LAUNCH=0."""
-        if os.environ.get("TRS_FLAG_ONE_LAUNCH", "1") == "0":
+        if os.environ.get("TRS_FLAG_ONE_LAUNCH", "1") == "0" or getattr(self, "_one_launch_off", False):
             return None
         if getattr(self, "sync", None) is None:
             import ctypes
@@ -521,7 +521,12 @@ class SparseScorerTrainer:
 
     def check_errors(self):
         from .collaborative._scorer import check_err_flag
-        check_err_flag(self.err, "fit")
+        try:
+            check_err_flag(self.err, "fit")
+        except RuntimeError:
+            self._one_launch_off = True  # (the grid was not resident at once: two launches per step from now on)
+            self._flag_call = None
+            raise
 
 
 def net_has_meta_lin(net):

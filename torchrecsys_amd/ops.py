@@ -199,7 +199,7 @@ class EpochPresort:
                  item_flags=True):
         """item_meta (n_items, M) int32 + n_meta (categories per column): also sort every metadata column's references.
         user_sort=False (plain SGD without metadata): user duplicates as FLAGS only (trs_epoch_user_flags: the LDS-bitmap
-        kernel, no second segmented sort); the step then adds the flagged users' gradients with float atomics."""
+        kernel, no grouping of the users); the step then adds the flagged users' gradients with float atomics."""
         lib = _lib.load()
         self.user_sort = bool(user_sort) or batch > EpochFlags.MAX_BATCH
         self.item_flags = bool(item_flags)  # False: skip the item-duplicate flag pass (only K1's INL 2 mode reads them)
