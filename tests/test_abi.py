@@ -58,6 +58,29 @@ def test_bad_arguments_return_error_codes_without_a_gpu():
         _lib.check(-1, "x")
 
 
+def test_tuning_knobs_are_set_through_the_abi_not_the_environment():
+    """trs_tuning_set (include/trs.h): every knob of csrc/trs_common.h TrsTuning is settable and resettable by name; an
+    unknown name is an error; no source file of the library calls getenv outside the one-time read in api.cpp."""
+    from torchrecsys_amd import _lib
+    lib = _lib.load()
+    src = open(os.path.join(ROOT, "torchrecsys_amd", "csrc", "trs_common.h")).read()
+    body = src[src.index("struct TrsTuning {"):src.index("TrsTuning& trs_tuning();")]
+    import re
+    names = re.findall(r"// TRS_([A-Z0-9_]+) ", body)
+    assert len(names) >= 10
+    for n in names:
+        assert lib.trs_tuning_set(n.encode(), 1, 0) == 0, n
+        assert lib.trs_tuning_set(n.encode(), 0, 1) == 0, n
+    assert lib.trs_tuning_set(b"NO_SUCH_KNOB", 1, 0) < 0 and b"unknown knob" in lib.trs_last_error()
+    with _lib.tuning(GEMM16_TILE=256):
+        pass
+    csrc = os.path.join(ROOT, "torchrecsys_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h", ".cpp")) and f != "api.cpp":
+            assert "getenv(" not in open(os.path.join(csrc, f)).read(), f
+    assert open(os.path.join(csrc, "api.cpp")).read().count("getenv(") == 1
+
+
 def _header_struct_fields(name):
     """Member names of `typedef struct NAME { ... } NAME;` in include/trs.h, in declaration order."""
     import re

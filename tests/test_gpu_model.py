@@ -727,3 +727,43 @@ def test_predict_many_equals_predict(net_type):
     assert model.predict_many([], top_k=5).shape == (0, 5)
     with pytest.raises(IndexError):
         model.predict_many([0, n_u], top_k=3)
+
+
+def test_touch_host_path_changes_nothing():
+    """FitRunner.touch_host_path (bench.py calls it between the warm-up's synchronise and the clock): the host side of the
+    next run_steps() call walked with ZERO steps — no kernel launched, no state advanced: the run that follows is the run
+    without it, bit for bit (same batches, same tables, same losses)."""
+    from torchrecsys_amd.engine import SparseScorerTrainer
+    from torchrecsys_amd.model import TorchRecSys
+    g = torch.Generator(device=DEV)
+    g.manual_seed(1)
+    n_users, n_items, n, B = 50_000, 60_000, 600_000, 2048  # sparse regime: the flag-mode step
+    users = torch.randint(0, n_users, (n,), device=DEV, dtype=torch.int32, generator=g)
+    items = torch.randint(0, n_items, (n,), device=DEV, dtype=torch.int32, generator=g)
+    old = SparseScorerTrainer.SLICE_BATCHES
+    SparseScorerTrainer.SLICE_BATCHES = 16
+    try:
+        res = []
+        for touch in (False, True):
+            seed(3)
+            with contextlib.redirect_stdout(io.StringIO()):
+                m = TorchRecSys.from_tensors(users, items, n_users=n_users, n_items=n_items, n_factors=32, net_type="fm",
+                                             dynamic_neg_sampling=True, rng="device", seed=2)
+            r = m.make_runner(torch.optim.SGD(m.parameters(), lr=0.05), B)
+            m.net.train()
+            r.begin_epoch()
+            r.run_steps(5)
+            torch.cuda.synchronize()
+            if touch:
+                assert r.touch_host_path() and r.next_batch == 5
+                torch.cuda.synchronize()
+            r.run_steps(20)  # crosses a slice boundary
+            torch.cuda.synchronize()
+            r.trainer.check_errors()
+            res.append(({k: v.clone() for k, v in m.state_dict().items()}, r.loss_sums[:25].clone()))
+    finally:
+        SparseScorerTrainer.SLICE_BATCHES = old
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-5, atol=0)
+    for k in res[0][0]:
+        # (float atomics on the few shared rows may reorder sums from run to run: last-bit differences only)
+        assert torch.allclose(res[0][0][k], res[1][0][k], rtol=0, atol=1e-6), k
