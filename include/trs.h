@@ -90,8 +90,9 @@ const char* trs_last_error(void);
  *      form, outer_xw) grew arguments; trs_hinge_auc_backward, trs_f32_to_bf16_multi, trs_mlp_embed_sgd_update added.
  *   4: trs_sampler.seen_users (bounds of the seen CSR); trs_train_args.sync_dev (flag mode as one launch per step);
  *      trs_mlp_gather_gemm1_fwd, trs_tuning_set added; trs_epoch_flags takes batches up to 262 144; the presort entry
- *      points no longer use their temp buffers (no vendor sort). */
-#define TRS_ABI_VERSION 4
+ *      points no longer use their temp buffers (no vendor sort).
+ *   5: trs_epoch_flags_ordered (flagged-first batches), trs_train_args.n_flagged_dev. */
+#define TRS_ABI_VERSION 5
 #define TRS_SYNC_WORDS 288
 int trs_abi_version(void);
 /* Tuning / A-B knobs of the launch paths (kernel selection, launch shapes): GRID_CAP, PASS_GRID_CAP, K1_ITERS,
@@ -317,6 +318,10 @@ typedef struct trs_train_args {
                                 done, wait for the whole grid, and add the flagged references' contributions
                                 themselves (no second launch).  err bit 2: the grid did not become resident within
                                 0.2 s (that step's results are not exact). */
+  const int32_t* n_flagged_dev; /* NULL, or (n_steps) int32 from trs_epoch_flags_ordered (the id and flag arrays above
+                                then are the ones it ordered): batch st's first n_flagged_dev[st] triples are the ones
+                                that carry a flagged reference.  The one-launch step then counts a workgroup in as soon
+                                as it is past those triples and never waits for the slowest workgroup. */
 } trs_train_args;
 int trs_train_steps_sgd(const trs_train_args* args, void* stream);
 
@@ -349,6 +354,17 @@ int trs_epoch_flags(const int32_t* stream_ui_dev, const int32_t* neg_static_dev,
                     int64_t n_items, int32_t* user_dev, int32_t* pos_dev, int32_t* neg_dev,
                     uint8_t* user_dup_flags_out_dev, uint8_t* item_dup_flags_out_dev, int32_t* err_flag_dev,
                     const trs_sampler* sampler, void* stream);
+/* trs_epoch_flags, and — with n_flagged_out_dev (n_batches int32) — every batch partitioned IN PLACE (ids and flags
+ * together; given ids are permuted too) so that the triples with at least one flagged reference come first; their
+ * number goes to n_flagged_out_dev[b].  The order of the triples inside a batch means nothing to a training step (its
+ * loss and gradients are sums over the batch): the same multiset of triples, the same flags per triple.  A batch with
+ * more than 12 288 misplaced triples is left in its order and reported as n_flagged = batch.  Replaces nothing in the
+ * reference (its order inside a batch is a random permutation too: FastDataLoader(shuffle=True), model.py:223-225). */
+int trs_epoch_flags_ordered(const int32_t* stream_ui_dev, const int32_t* neg_static_dev, int64_t N, uint64_t shuffle_key,
+                            uint64_t sample_seed, int64_t first_pos, int64_t n_batches, int64_t batch, int64_t n_users,
+                            int64_t n_items, int32_t* user_dev, int32_t* pos_dev, int32_t* neg_dev,
+                            uint8_t* user_dup_flags_out_dev, uint8_t* item_dup_flags_out_dev,
+                            int32_t* n_flagged_out_dev, int32_t* err_flag_dev, const trs_sampler* sampler, void* stream);
 /* User-duplicate flags alone, by the same LDS bitmap (no sort; conservative for n_users > 2^20).  Plain SGD without
  * metadata needs nothing else about the users: pass the flags to trs_train_steps_sgd with sorted_ukeys_dev = NULL and the
  * flagged users add their staged gradient rows with float atomics in the sorted-run launch. */

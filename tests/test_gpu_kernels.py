@@ -286,12 +286,19 @@ def test_sampler_options_bit_exact_and_properties(opts):
     # the epoch-level generators produce the same triples (flags kernel and sorted presort)
     err = torch.zeros(1, dtype=torch.int32, device=DEV)
     ui = ops.interleave_stream(d(su), d(si))
-    for cls in (ops.EpochFlags, ops.EpochPresort):
-        ep = cls(nb, B, NU, NI, DEV)
+    for cls, kw in ((ops.EpochFlags, {"ordered": False}), (ops.EpochPresort, {})):
+        ep = cls(nb, B, NU, NI, DEV, **kw)
         ep.run(ui, None, key, seed_, 0, err, sampler=sm)
         torch.cuda.synchronize()
         for q, arr in zip(("user", "pos", "neg"), ep.ids):
             assert np.array_equal(arr[:nb * B].cpu().numpy().astype(np.int64), np.concatenate(got[q])), (cls.__name__, q)
+    # ... and the flagged-first order is a permutation of every batch's triples
+    ep = ops.EpochFlags(nb, B, NU, NI, DEV)
+    ep.run(ui, None, key, seed_, 0, err, sampler=sm)
+    trip = np.stack([a[:nb * B].cpu().numpy().astype(np.int64) for a in ep.ids], axis=1).reshape(nb, B, 3)
+    want = np.stack([np.concatenate(got[q]) for q in ("user", "pos", "neg")], axis=1).reshape(nb, B, 3)
+    for b in range(nb):
+        assert np.array_equal(trip[b][np.lexsort(trip[b].T)], want[b][np.lexsort(want[b].T)]), b
     assert err.item() == 0
 
 
@@ -967,21 +974,30 @@ def test_gemm_fused_bn_statistics(B, passes, K, H, bf16):
 @pytest.mark.parametrize("net,D,skew", [("fm", 64, False), ("fm", 64, True), ("fm", 16, True), ("linear", 32, True),
                                         ("fm", 80, False), ("fm", 10, True), ("fm", 128, False)])
 @pytest.mark.parametrize("n_users", [300, 3_000_000])
-@pytest.mark.parametrize("one_launch", [False, True])
-def test_flag_mode_matches_oracle(net, D, skew, n_users, one_launch):
+@pytest.mark.parametrize("one_launch", [False, True, "ordered"])
+def test_flag_mode_matches_oracle(net, D, skew, n_users, one_launch, tune):
     """The sparse regime's step (trs_epoch_flags + K1 taking every lone reference + flagged_update_kernel): rows
     referenced once in the batch updated in place by K1, the flagged references added with float atomics afterwards — 3
     batches in one C call == oracle SGD steps.  n_users = 3M: more rows than bitmap bits, so the user flags are
     hashed (conservative) — flagged lone rows must still be exact.  Flags: exact where the table fits the bitmap.
     one_launch: the same step as ONE launch (trs_train_args.sync_dev): K1's workgroups count themselves in on the
     arrival counter after their last row read, wait for the whole grid and apply the flagged references themselves;
-    the library reports the arrivals it scheduled (3 launches x grid), and a second call continues the counter."""
+    the library reports the arrivals it scheduled (3 launches x grid), and a second call continues the counter.
+    ordered: the presort also puts every batch's triples with a flagged reference first (trs_epoch_flags_ordered: the
+    same multiset of triples, the same flags per triple, their count reported) and the one-launch step counts its
+    workgroups in after those triples (trs_train_args.n_flagged_dev) instead of after its last one."""
     ops = _ops()
     rs = np.random.RandomState(D + skew)
     NU, NI, B, nb, lr = n_users, 57 if n_users == 300 else 5000, 512, 3, 0.05
-    p, _, _ = make_case(net, D, 0, 8, NU=300, NI=NI, seed=2)
-    urows = np.sort(rs.choice(NU, 300, replace=False)) if NU > 300 else np.arange(300)  # the users that occur
-    u_small = rs.randint(0, 300, nb * B)
+    NUS = 300  # users that occur
+    if one_launch == "ordered" and n_users > 300:
+        # mostly lone references (16 000 users and 20 000 items for batches of 2 048) and four iterations per wave: about
+        # 40 % of the triples carry a flag, so the workgroups count themselves in after iteration 2 of 4 (mid-loop)
+        NUS, NI, B = 16000, 20000, 2048
+        tune(K1_ITERS=4)
+    p, _, _ = make_case(net, D, 0, 8, NU=NUS, NI=NI, seed=2)
+    urows = np.sort(rs.choice(NU, NUS, replace=False)) if NU > 300 else np.arange(300)  # the users that occur
+    u_small = rs.randint(0, NUS, nb * B)
     u = urows[u_small]
     i = rs.randint(0, NI, nb * B)
     j = rs.randint(0, NI, nb * B)
@@ -998,9 +1014,22 @@ def test_flag_mode_matches_oracle(net, D, skew, n_users, one_launch):
         t["user.weight"], t[lin[0]] = big, big1
     T, keep = ops.make_tables(t["user.weight"], t["item.weight"], t[lin[0]], t[lin[1]])
     err = torch.zeros(1, dtype=torch.int32, device=DEV)
-    ef = ops.EpochFlags(nb, B, NU, NI, DEV)
+    ordered = one_launch == "ordered"
+    ef = ops.EpochFlags(nb, B, NU, NI, DEV, ordered=ordered)
     ef.run(None, None, 0, 0, 0, err, given_ids=[torch.from_numpy(a.astype(np.int32)).to(DEV) for a in (u, i, j)])
     ids, udup, idup = ef.step_args(0)
+    if ordered:  # every batch: a permutation of its triples, the flagged ones first, their number reported
+        uo, io, jo = (t_[:nb * B].cpu().numpy().astype(np.int64) for t_ in ids)
+        small_of = {int(r): k for k, r in enumerate(urows)}
+        for b in range(nb):
+            sl = slice(b * B, (b + 1) * B)
+            a_, b_ = np.stack([u[sl], i[sl], j[sl]], 1), np.stack([uo[sl], io[sl], jo[sl]], 1)
+            assert np.array_equal(a_[np.lexsort(a_.T)], b_[np.lexsort(b_.T)])
+            anyf = (udup[sl].cpu().numpy() != 0) | (idup[sl].cpu().numpy() != 0).any(axis=1)
+            nf = int(ef.n_flagged[b].item())
+            assert nf == int(anyf.sum()) and anyf[:nf].all() and not anyf[nf:].any()
+        u, i, j = uo, io, jo  # what the steps (and the oracle below) see
+        u_small = np.array([small_of[int(x)] for x in u])
     for b in range(nb):
         sl = slice(b * B, (b + 1) * B)
         ucnt = np.unique(u[sl], return_counts=True)
@@ -1019,10 +1048,10 @@ def test_flag_mode_matches_oracle(net, D, skew, n_users, one_launch):
     scratch, ustage = ops.train_scratch(NU, NI, B, D, DEV), torch.empty((B, D), device=DEV)
     # (two C calls, 2 + 1 steps: the arrival counter carries over from call to call)
     ops.train_steps_sgd(net, T, None, None, 0, 0, 0, B, 2, lr, *ids, gz, du, losses, err, scratch, 1, None,
-                        user_dup=udup, item_dup=idup, ustage=ustage, sync=sync)
+                        user_dup=udup, item_dup=idup, ustage=ustage, sync=sync, n_flagged=ef.n_flagged_from(0))
     ids2, udup2, idup2 = ef.step_args(2)
     ops.train_steps_sgd(net, T, None, None, 0, 0, 0, B, 1, lr, *ids2, gz, du, losses[2:], err, scratch, 3, None,
-                        user_dup=udup2, item_dup=idup2, ustage=ustage, sync=sync)
+                        user_dup=udup2, item_dup=idup2, ustage=ustage, sync=sync, n_flagged=ef.n_flagged_from(2))
     torch.cuda.synchronize()
     if one_launch:  # every launch counted all its workgroups in, and the library knows how many it scheduled
         assert sync[1].value > 0 and sync[1].value % 3 == 0 and int(sync[0][0].item()) == sync[1].value

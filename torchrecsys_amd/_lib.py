@@ -11,7 +11,7 @@ TRS_MAX_META = 8
 TRS_NET_LINEAR = 0
 TRS_NET_FM = 1
 LOSS_ID = {"hinge": 0, "bpr": 1}  # TRS_LOSS_HINGE / TRS_LOSS_BPR
-ABI_VERSION = 4  # == TRS_ABI_VERSION of include/trs.h (tests/test_abi.py)
+ABI_VERSION = 5  # == TRS_ABI_VERSION of include/trs.h (tests/test_abi.py)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtrs_hip.so")
@@ -100,7 +100,7 @@ class TrsTrainArgs(C.Structure):
                 ("slice_pos0", C.c_int64),
                 ("opt", C.POINTER(TrsOpt)), ("meta", C.POINTER(TrsMetaStage)),
                 ("events", C.POINTER(C.c_void_p)), ("sync_dev", C.c_void_p),
-                ("sync_count_host", C.POINTER(C.c_uint32))]
+                ("sync_count_host", C.POINTER(C.c_uint32)), ("n_flagged_dev", C.c_void_p)]
 
 
 _vp, _i32, _i64, _u64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
@@ -131,6 +131,8 @@ PROTOTYPES = {
                                          C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp, _vp, _vp]),
     "trs_epoch_flags": (C.c_int, [_vp, _vp, _i64, _u64, _u64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
                                   C.POINTER(TrsSampler), _vp]),
+    "trs_epoch_flags_ordered": (C.c_int, [_vp, _vp, _i64, _u64, _u64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp,
+                                          _vp, _vp, _vp, C.POINTER(TrsSampler), _vp]),
     "trs_epoch_user_flags": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "trs_epoch_user_dups_sizes": (C.c_int, [_i64, _i64, _i64, c_int64_p, c_int64_p, c_int64_p]),
     "trs_epoch_user_dups": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, C.POINTER(C.c_void_p),

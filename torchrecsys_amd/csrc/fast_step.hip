@@ -72,6 +72,9 @@ struct FastArgs {
   // completed target (TRS_SYNC_WORDS uint32 in all)
   uint32_t* sync;
   uint32_t sync_base, sync_target;
+  // flagged-first order (trs_epoch_flags_ordered): *nflag = the batch's triples that carry a flagged reference, all of them
+  // at its first positions; NULL = any order
+  const int32_t* nflag;
 };
 
 struct RawIds {   // loads issued, nothing consumed yet
@@ -223,10 +226,32 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
   uint64_t* stamps = reinterpret_cast<uint64_t*>(a.gz) + 4 * (int64_t)blockIdx.x;  // (gz is unused in INL 3)
   if (INL == 3 && threadIdx.x == 0) stamps[0] = __builtin_amdgcn_s_memrealtime();
 #endif
+  // Flagged-first batches (a.nflag): every flagged row of the step is read in the launch's first `fi` iterations, so a
+  // workgroup counts itself in on the arrival counter as soon as its four waves are past them — mid-loop, with a plain
+  // (non-returning) atomic nobody waits for — and at the end of its own loop only LOOKS at the counter: every other
+  // workgroup counted itself in ~10 us ago, so the look finds the grid complete and the flagged references' atomics go
+  // out at once.  No workgroup waits for the slowest one any more (time stamps before: main loops end at 15 / 18 / 23
+  // us, everybody then waited until 24.5 and applied until 27-29).
+  __shared__ int s_arr;  // waves of this workgroup that are past the flagged iterations
+  int64_t fi = 0;
+  bool early = false, arrived = false;
   if (DEFER) {
-    if (threadIdx.x == 0) s_total = 0;
+    if (threadIdx.x == 0) s_total = s_arr = 0;
+    if (a.nflag) {
+      const int64_t nf = *a.nflag;
+      fi = (nf + stride - 1) / stride;
+      early = fi < (B + stride - 1) / stride;  // (not: a batch left in its order reports nf = B)
+    }
     __syncthreads();
   }
+  auto arrive = [&]() {  // wave-uniform
+    int before = 0;
+    if (lane == 0) before = atomicAdd(&s_arr, 1);
+    before = __builtin_amdgcn_readfirstlane(before);
+    if (before == NWV - 1 && lane == 0)  // the workgroup's last wave: count the workgroup in (result unused: no wait)
+      (void)__hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    arrived = true;
+  };
   int64_t t = wave * TPW + lane / G;
   // wave-uniform trip count: the wave's first group decides (its t is the smallest of the wave)
   const int64_t t_first = wave * TPW;
@@ -373,18 +398,22 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
   RawIds wO = issue_ids<SRC, INL>(a, t + stride);
   idE = finalize_ids<SRC>(a, wE);
   load_rows<VEC, G, K, FULL, OPT, NTU>(rE, T, a.o, idE, lig);
+  if (DEFER && early && fi == 0) arrive();
   for (int64_t it = 0; it < niter2; it += 2) {
     wE = issue_ids<SRC, INL>(a, t + 2 * stride);
     idO = finalize_ids<SRC>(a, wO);
     load_rows<VEC, G, K, FULL, OPT, NTU>(rO, T, a.o, idO, lig);
     reduce(rE, idE, t);
+    if (DEFER && early && it + 1 == fi) arrive();  // (the rows already in flight belong to triples without a flagged reference)
 
     wO = issue_ids<SRC, INL>(a, t + 3 * stride);
     idE = finalize_ids<SRC>(a, wE);
     load_rows<VEC, G, K, FULL, OPT, NTU>(rE, T, a.o, idE, lig);
     reduce(rO, idO, t + stride);
+    if (DEFER && early && it + 2 == fi) arrive();
     t += 2 * stride;
   }
+  if (DEFER && early && !arrived) arrive();  // a wave with fewer iterations than fi (the batch's tail)
   }
 #ifdef TRS_K1_STAMPS
   if (INL == 3 && threadIdx.x == 0) stamps[1] = __builtin_amdgcn_s_memrealtime();
@@ -448,7 +477,18 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
     // the first round's staged rows travel to registers WHILE the workgroup waits for the grid (they are this
     // workgroup's own data, complete since the barrier above; typical: 2-3 flagged references per wave = one round)
     load_round(0);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && early) {
+      // counted in long ago, and so has everybody else: one look at the counter (bounded wait as below if it is not so)
+      const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
+      const uint64_t limit = (a.err && (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4)) ? 0ull : 5000000ull;
+      while ((int32_t)(__hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.sync_target) < 0) {
+        __builtin_amdgcn_s_sleep(6);
+        if (__builtin_amdgcn_s_memrealtime() - t_start > limit) {
+          if (a.err) atomicOr(a.err, 4);
+          break;
+        }
+      }
+    } else if (threadIdx.x == 0) {
       // Arrivals are returning atomics on the counter's line: the workgroup whose add completes the grid publishes the
       // target on eight flag lines (128 B apart); everybody else polls only its flag line (blockIdx % 8), which nobody
       // writes meanwhile.  (All 512 workgroups polling the counter itself queued their reads between the arrivals on one
@@ -1659,6 +1699,7 @@ extern "C" int trs_train_steps_sgd(const trs_train_args* args, void* stream) {
       a.ustage = ustage_buf_dev;
       a.sync = args->sync_count_host ? args->sync_dev : nullptr;
       a.sync_base = a.sync ? *args->sync_count_host : 0u;
+      a.nflag = args->n_flagged_dev ? args->n_flagged_dev + st : nullptr;
     }
     if (adaptive) {  // this step's effective learning rate, in double like the Python floats of torch.optim
       OptArgs& o = a.o;

@@ -119,6 +119,8 @@ struct FlagArgs {
   int log2_bits;              // bitmap size
   int item_hash, user_hash;   // 0: row id = bit (table fits the bitmap), 1: hashed
   int what_first, what_end;   // tables flagged: [0, 2) items then users; [1, 2) users only (the dense regime sorts its items)
+  int32_t* nflag;             // NULL, or (n_batches): phase D puts the triples with a flagged reference first and counts them
+  int ord_off, ord_cap;       // phase D's LDS scratch: words in front of the two position lists, entries per list
 };
 
 constexpr int FLAG_THREADS = 1024;
@@ -222,6 +224,89 @@ __global__ __launch_bounds__(FLAG_THREADS) void batch_flags_kernel(const FlagArg
       }
     }
     __syncthreads();
+  }
+  if (!a.nflag) return;
+  // ---- D: flagged-first order.  The one-launch step (fwd_stage_kernel INL 3) may add a flagged reference's update into
+  // its table only when NO workgroup reads that row any more; if the triples that carry a flagged reference are the
+  // batch's first nf, every workgroup is past them after its first ceil(nf / stride) iterations and counts itself in
+  // there — the grid-wide wait at the end of the launch finds the count complete.  The order inside a batch means
+  // nothing to the step (a sum over the batch), so the batch is partitioned in place: nf = the number of flagged triples;
+  // the k-th NON-flagged triple at a position < nf (a hole) changes places with the k-th flagged triple at a position >=
+  // nf (a mover) — ranks from per-64 ballots and one scan, positions through two LDS lists (the bitmap is dead by now),
+  // then m disjoint swaps of (user, pos, neg, flags).  Deterministic; a batch with more misplaced triples than the lists
+  // hold is left as it is and reported as nf = batch (the step then counts in after its last iteration, as before).
+  {
+    const int cells = (B + 63) >> 6;
+    uint32_t* F = bm;  // flagged triples in front of cell c (cell = 64 consecutive positions)
+    uint32_t* holes = bm + a.ord_off;
+    uint32_t* movers = holes + a.ord_cap;
+    __shared__ uint32_t s_nf, s_flnf;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int NWV = FLAG_THREADS / 64;
+    auto flagged = [&](int t) -> bool { return t < B && (iflags16[q0 + t] != 0 || a.uflags[q0 + t] != 0); };
+    for (int c = wv; c < cells; c += NWV) {
+      const uint64_t bal = __ballot(flagged(c * 64 + lane));
+      if (lane == 0) F[c] = (uint32_t)__popcll((unsigned long long)bal);
+    }
+    __syncthreads();
+    if (wv == 0) {  // exclusive scan over the cells: a lane sums `per` consecutive cells, the wave scans the 64 sums
+      const int per = (cells + 63) >> 6;
+      uint32_t sum = 0;
+      for (int i = 0; i < per; ++i) {
+        const int c = lane * per + i;
+        if (c < cells) sum += F[c];
+      }
+      uint32_t incl = sum;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+      }
+      uint32_t run = incl - sum;
+      for (int i = 0; i < per; ++i) {
+        const int c = lane * per + i;
+        if (c < cells) {
+          const uint32_t v = F[c];
+          F[c] = run;
+          run += v;
+        }
+      }
+      if (lane == 63) s_nf = s_flnf = incl;  // (s_flnf: flagged triples in front of position nf; nf = batch has no such position)
+    }
+    __syncthreads();
+    const int nf = (int)s_nf;
+    for (int c = wv; c < cells; c += NWV) {
+      const int t = c * 64 + lane;
+      const bool f = flagged(t);
+      const uint64_t bal = __ballot(f);
+      const uint32_t fl = F[c] + (uint32_t)__popcll((unsigned long long)(bal & ((1ull << lane) - 1ull)));
+      if (t == nf) s_flnf = fl;
+      if (t < nf && !f && t - fl < (uint32_t)a.ord_cap) holes[t - fl] = (uint32_t)t;
+    }
+    __syncthreads();
+    const uint32_t flnf = s_flnf;
+    const int m = nf - (int)flnf;  // holes = movers
+    if (m > a.ord_cap) {
+      if (threadIdx.x == 0) a.nflag[blockIdx.x] = B;
+      return;
+    }
+    for (int c = wv; c < cells; c += NWV) {
+      const int t = c * 64 + lane;
+      const bool f = flagged(t);
+      const uint64_t bal = __ballot(f);
+      const uint32_t fl = F[c] + (uint32_t)__popcll((unsigned long long)(bal & ((1ull << lane) - 1ull)));
+      if (t >= nf && f) movers[fl - flnf] = (uint32_t)t;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < m; k += FLAG_THREADS) {
+      const int64_t x = q0 + holes[k], y = q0 + movers[k];
+      const int32_t ux = a.user[x], px = a.pos[x], nx = a.neg[x], uy = a.user[y], py = a.pos[y], ny = a.neg[y];
+      const uint8_t fux = a.uflags[x], fuy = a.uflags[y];
+      const uint16_t fix = iflags16[x], fiy = iflags16[y];
+      a.user[x] = uy; a.pos[x] = py; a.neg[x] = ny; a.uflags[x] = fuy; iflags16[x] = fiy;
+      a.user[y] = ux; a.pos[y] = px; a.neg[y] = nx; a.uflags[y] = fux; iflags16[y] = fix;
+    }
+    if (threadIdx.x == 0) a.nflag[blockIdx.x] = nf;
   }
 }
 
@@ -1150,11 +1235,30 @@ static int launch_flags(const FlagArgs& a, int64_t n_batches, size_t lds, hipStr
 }
 
 // Ids + conservative duplicate flags of an epoch slice in one launch (the sparse regime's whole presort).
+extern "C" int trs_epoch_flags_ordered(const int32_t* stream_ui_dev, const int32_t* neg_static_dev, int64_t N,
+                                       uint64_t shuffle_key, uint64_t sample_seed, int64_t first_pos, int64_t n_batches,
+                                       int64_t batch, int64_t n_users, int64_t n_items, int32_t* user_dev,
+                                       int32_t* pos_dev, int32_t* neg_dev, uint8_t* user_dup_flags_out_dev,
+                                       uint8_t* item_dup_flags_out_dev, int32_t* n_flagged_out_dev,
+                                       int32_t* err_flag_dev, const trs_sampler* sampler, void* stream);
+
 extern "C" int trs_epoch_flags(const int32_t* stream_ui_dev, const int32_t* neg_static_dev, int64_t N,
                                uint64_t shuffle_key, uint64_t sample_seed, int64_t first_pos, int64_t n_batches,
                                int64_t batch, int64_t n_users, int64_t n_items, int32_t* user_dev, int32_t* pos_dev,
                                int32_t* neg_dev, uint8_t* user_dup_flags_out_dev, uint8_t* item_dup_flags_out_dev,
                                int32_t* err_flag_dev, const trs_sampler* sampler, void* stream) {
+  return trs_epoch_flags_ordered(stream_ui_dev, neg_static_dev, N, shuffle_key, sample_seed, first_pos, n_batches, batch,
+                                 n_users, n_items, user_dev, pos_dev, neg_dev, user_dup_flags_out_dev,
+                                 item_dup_flags_out_dev, nullptr, err_flag_dev, sampler, stream);
+}
+
+// trs_epoch_flags + (n_flagged_out_dev != NULL) the flagged-first order of every batch: see batch_flags_kernel, phase D.
+extern "C" int trs_epoch_flags_ordered(const int32_t* stream_ui_dev, const int32_t* neg_static_dev, int64_t N,
+                                       uint64_t shuffle_key, uint64_t sample_seed, int64_t first_pos, int64_t n_batches,
+                                       int64_t batch, int64_t n_users, int64_t n_items, int32_t* user_dev,
+                                       int32_t* pos_dev, int32_t* neg_dev, uint8_t* user_dup_flags_out_dev,
+                                       uint8_t* item_dup_flags_out_dev, int32_t* n_flagged_out_dev,
+                                       int32_t* err_flag_dev, const trs_sampler* sampler, void* stream) {
   const int64_t kn = sampler && sampler->k_neg > 1 ? sampler->k_neg : 1;
   TRS_REQUIRE(!sampler || (sampler->k_neg >= 1 && (!sampler->popularity || (sampler->pop_items && sampler->pop_n > 0)) &&
                            ((sampler->seen_off == nullptr) == (sampler->seen_items == nullptr))),
@@ -1195,7 +1299,15 @@ extern "C" int trs_epoch_flags(const int32_t* stream_ui_dev, const int32_t* neg_
   a.user_hash = n_users > ((int64_t)1 << lb) ? 1 : 0;
   a.what_first = 0;
   a.what_end = 2;
-  const size_t lds = ((size_t)1 << lb) / 8;
+  size_t lds = ((size_t)1 << lb) / 8;
+  if (n_flagged_out_dev) {  // phase D's scratch shares the bitmap's LDS: cell prefixes + two lists of positions
+    a.nflag = n_flagged_out_dev;
+    a.ord_off = (int)(((batch + 63) / 64 + 64) & ~(int64_t)63);
+    const int64_t half = (batch + 1) / 2;
+    a.ord_cap = (int)(half < 12288 ? (half < 64 ? 64 : half) : 12288);
+    const size_t need = ((size_t)a.ord_off + 2 * (size_t)a.ord_cap) * 4;
+    if (need > lds) lds = need;
+  }
   int src = !stream_ui_dev ? 0 : (neg_static_dev ? 2 : 1);
   hipStream_t s = (hipStream_t)stream;
   if (src != 0) {

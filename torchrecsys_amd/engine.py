@@ -254,7 +254,8 @@ class SparseScorerTrainer:
         ps = sets[i]
         if (ps is None or ps.batch != batch or ps.n_batches < n_batches) and self.sparse_regime(batch):
             ps = sets[i] = ops.EpochFlags(max(n_batches, min(self.SLICE_BATCHES, n_batches)), batch,
-                                          self.params[0].shape[0], self.params[1].shape[0], self.dev)
+                                          self.params[0].shape[0], self.params[1].shape[0], self.dev,
+                                          ordered=os.environ.get("TRS_FLAG_ORDERED", "1") != "0")  # knob: A/B
         elif ps is None or ps.batch != batch or ps.n_batches < n_batches:
             meta_kw = {}
             if self.M > 0 and os.environ.get("TRS_META_SORTED", "1") != "0":  # knob: 0 = atomic scatter of staged fields
@@ -366,7 +367,8 @@ class SparseScorerTrainer:
             arrivals = sy[1].value if sy else 0
             ops.train_steps_sgd(self.net.NET, self.net.tables(), None, None, 0, 0, 0, batch, n_steps, self.fast_lr, *ids,
                                 self.gz, self.du, loss_sums, self.err, self.scratch, self._stamps(n_steps), evs,
-                                user_dup=udup, item_dup=idup, ustage=self.ustage, loss=self.loss_id, sync=self._sync())
+                                user_dup=udup, item_dup=idup, ustage=self.ustage, loss=self.loss_id, sync=self._sync(),
+                                n_flagged=ps.n_flagged_from(b_in_slice))
             if te is not None:
                 # one launch per step (K1's own workgroups applied the flagged references: the library scheduled arrivals
                 # on the counter): the second interval holds no kernel either

@@ -306,12 +306,15 @@ class EpochFlags:
 
     MAX_BATCH = 262_144  # one workgroup per batch (csrc/presort.hip FLAG_THREADS * FLAG_U * FLAG_ROUNDS * FLAG_MAX_GROUPS)
 
-    def __init__(self, n_batches, batch, n_users, n_items, device):
+    def __init__(self, n_batches, batch, n_users, n_items, device, ordered=True):
         self.n_batches, self.batch, self.n_users, self.n_items = n_batches, batch, n_users, n_items
         n_pos = n_batches * batch
         self.ids = [torch.empty(n_pos, dtype=torch.int32, device=device) for _ in range(3)]
         self.user_dup = torch.empty(n_pos, dtype=torch.uint8, device=device)
         self.item_dup = torch.empty((n_pos, 2), dtype=torch.uint8, device=device)
+        # ordered: every batch comes out with its flagged triples first (trs_epoch_flags_ordered) and their count here —
+        # what lets the one-launch step count a workgroup in early (trs_train_args.n_flagged_dev)
+        self.n_flagged = torch.zeros(n_batches, dtype=torch.int32, device=device) if ordered else None
         self.key_bytes = self.ukey_bytes = 0
 
     @staticmethod
@@ -324,19 +327,21 @@ class EpochFlags:
             for dst, src in zip(self.ids, given_ids):
                 dst[:n_pos].copy_(src[:n_pos])
         N = 0 if stream_ui is None else stream_ui.shape[0]
-        check(_lib.load().trs_epoch_flags(ptr(stream_ui), ptr(neg_static), N, int(shuffle_key), int(sample_seed),
-                                          int(first_pos), self.n_batches, self.batch, self.n_users, self.n_items,
-                                          ptr(self.ids[0]), ptr(self.ids[1]), ptr(self.ids[2]), ptr(self.user_dup),
-                                          ptr(self.item_dup), ptr(err_flag), _samp(sampler), _stream()),
-              "trs_epoch_flags")
+        check(_lib.load().trs_epoch_flags_ordered(ptr(stream_ui), ptr(neg_static), N, int(shuffle_key), int(sample_seed),
+                                                  int(first_pos), self.n_batches, self.batch, self.n_users,
+                                                  self.n_items, ptr(self.ids[0]), ptr(self.ids[1]), ptr(self.ids[2]),
+                                                  ptr(self.user_dup), ptr(self.item_dup), ptr(self.n_flagged),
+                                                  ptr(err_flag), _samp(sampler), _stream()),
+              "trs_epoch_flags_ordered")
 
     @property
     def base_ptrs(self):
         """Device addresses of (user, pos, neg ids; user / item duplicate flags) — FlagStepCall offsets them itself."""
         bp = getattr(self, "_base_ptrs", None)
         if bp is None:
-            bp = self._base_ptrs = tuple(t.data_ptr() for t in self.ids) + (self.user_dup.data_ptr(),
-                                                                             self.item_dup.data_ptr())
+            bp = self._base_ptrs = tuple(t.data_ptr() for t in self.ids) + (
+                self.user_dup.data_ptr(), self.item_dup.data_ptr(),
+                self.n_flagged.data_ptr() if self.n_flagged is not None else 0)
         return bp
 
     def step_args(self, b):
@@ -344,11 +349,15 @@ class EpochFlags:
         o = b * self.batch
         return [t[o:] for t in self.ids], self.user_dup[o:], self.item_dup[o:]
 
+    def n_flagged_from(self, b):
+        """Flagged-triple counts from batch b on (None: the batches are in arbitrary order)."""
+        return None if self.n_flagged is None else self.n_flagged[b:]
+
 
 def train_steps_sgd(net, T, stream_ui, neg_static, shuffle_key, sample_seed, first_pos, batch, n_steps,
                     lr, user_buf, pos_buf, neg_buf, gz_buf, du_buf, loss_sums, err_flag, scratch=None, first_stamp=1,
                     events=None, sorted_keys=None, sorted_vals=None, key_bytes=0, user_dup=None, ustage=None,
-                    user_sorted=None, opt=None, meta=None, item_dup=None, loss=0, sync=None):
+                    user_sorted=None, opt=None, meta=None, item_dup=None, loss=0, sync=None, n_flagged=None):
     """n_steps fused steps driven from C (trs_train_steps_sgd).  stream_ui None: the steps' ids are already in
     user/pos/neg_buf.  events: optional flat list of 4*n_steps raw hipEvent_t handles.  opt: None (SGD with lr) or a
     _lib.TrsOpt (SparseAdam / Adagrad on the presorted path; keep the tensors it points to alive).  item_dup: the
@@ -359,6 +368,7 @@ def train_steps_sgd(net, T, stream_ui, neg_static, shuffle_key, sample_seed, fir
     a = _lib.TrsTrainArgs()
     if sync is not None:
         a.sync_dev, a.sync_count_host = ptr(sync[0]), C.pointer(sync[1])
+    a.n_flagged_dev = ptr(n_flagged)  # (n_steps int32 of an ordered EpochFlags, or None)
     a.net, a.n_steps, a.tables, a.batch, a.lr = NET_ID[net], int(n_steps), C.pointer(T), int(batch), float(lr)
     a.first_stamp = int(first_stamp)
     a.loss = int(loss)
@@ -415,6 +425,7 @@ class FlagStepCall:
         a.n_steps, a.first_stamp = int(n_steps), int(first_stamp)
         a.user_buf_dev, a.pos_buf_dev, a.neg_buf_dev = base[0] + 4 * o, base[1] + 4 * o, base[2] + 4 * o
         a.user_dup_flags_dev, a.item_dup_flags_dev = base[3] + o, base[4] + 2 * o
+        a.n_flagged_dev = base[5] + 4 * b_in_slice if base[5] else None
         a.loss_sums_dev = loss_sums.data_ptr()
         check(self.fn(self.ref, _stream()), "trs_train_steps_sgd")
 
