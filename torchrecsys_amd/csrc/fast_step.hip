@@ -232,11 +232,12 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
   // workgroup counted itself in ~10 us ago, so the look finds the grid complete and the flagged references' atomics go
   // out at once.  No workgroup waits for the slowest one any more (time stamps before: main loops end at 15 / 18 / 23
   // us, everybody then waited until 24.5 and applied until 27-29).
-  __shared__ int s_arr;  // waves of this workgroup that are past the flagged iterations
+  __shared__ int s_arr;   // waves of this workgroup that are past the flagged iterations
+  __shared__ int s_left;  // early mode: some wave has not applied all its flagged references inside its loop
   int64_t fi = 0;
   bool early = false, arrived = false;
   if (DEFER) {
-    if (threadIdx.x == 0) s_total = s_arr = 0;
+    if (threadIdx.x == 0) s_total = s_arr = s_left = 0;
     if (a.nflag) {
       const int64_t nf = *a.nflag;
       fi = (nf + stride - 1) / stride;
@@ -251,6 +252,47 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
     if (before == NWV - 1 && lane == 0)  // the workgroup's last wave: count the workgroup in (result unused: no wait)
       (void)__hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     arrived = true;
+  };
+  // early mode: a wave lists its flagged references in ITS OWN part of the list (no LDS atomic) and applies them itself
+  // right after its last iteration — a wave's loads of the rows it staged come back behind its own stores to the same
+  // addresses, so it needs no barrier with the other waves: the look at the arrival counter and the first round of staged
+  // rows are issued behind the last row loads and come back with them.  (Applying them INSIDE the loop, a round per
+  // iteration, was built: the 1 200 waves with something to apply looked at the counter's line once per iteration while
+  // the arrivals were still landing on it — 43 against 33 us per step — and the extra live registers cost a wave per SIMD.)
+  constexpr int CAPW = DEFER_ITERS * TPW * 3, DU = 4, KDD = (N * G + TRS_WAVE - 1) / TRS_WAVE;
+  const int wv = threadIdx.x >> 6;
+  int my_cnt = 0, next_e = 0;
+  bool complete = false;
+  auto entry_at = [&](int e) -> int { return early ? wv * CAPW + e : wv + NWV * e; };
+  auto load_round = [&](float (&x)[DU][KDD], int e0, int n_mine) {
+#pragma unroll
+    for (int k = 0; k < DU; ++k) {
+      const bool has = e0 + k < n_mine;
+      // (same address in every lane: one LDS broadcast; without an entry, slot 0 is read as a dummy and not used)
+      const DeferEntry en = s_list[has ? entry_at(e0 + k) : 0];
+      const int64_t tk = has ? (int64_t)(en.tw >> 2) : 0;
+      const float* src = ((en.tw & 3u) == 0 ? a.du : a.ustage) + tk * (int64_t)D;
+#pragma unroll
+      for (int q = 0; q < KDD; ++q) {
+        const int e = q * TRS_WAVE + lane;
+        x[k][q] = __hip_atomic_load(src + (e < D ? e : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // past L1
+      }
+    }
+  };
+  auto apply_round = [&](float (&x)[DU][KDD], int e0, int n_mine) {
+#pragma unroll
+    for (int k = 0; k < DU; ++k) {
+      if (e0 + k >= n_mine) continue;  // (wave-uniform)
+      const DeferEntry en = s_list[entry_at(e0 + k)];
+      const int which = (int)(en.tw & 3u);
+      float* dst = (which == 0 ? T.user : T.item) + (int64_t)en.row * D;
+#pragma unroll
+      for (int q = 0; q < KDD; ++q) {
+        const int e = q * TRS_WAVE + lane;
+        if (e < D) atomicAdd(dst + e, en.c * x[k][q]);
+      }
+      if (lane == 0) atomicAdd((which == 0 ? T.user_lin : T.item_lin) + en.row, en.clin);
+    }
   };
   int64_t t = wave * TPW + lane / G;
   // wave-uniform trip count: the wave's first group decides (its t is the smallest of the wave)
@@ -304,7 +346,10 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
       const uint64_t below = ((uint64_t)1 << lane) - 1;
       const int cu = __popcll(mu), cp = __popcll(mp), cn = __popcll(mn);
       int bu = 0;
-      if (cu + cp + cn) {  // (wave-uniform) this wave's slots of the workgroup's list: one LDS atomic per iteration
+      if (early) {  // the wave's own part of the list
+        bu = wv * CAPW + my_cnt;
+        my_cnt += cu + cp + cn;
+      } else if (cu + cp + cn) {  // (wave-uniform) this wave's slots of the workgroup's list: one LDS atomic per iteration
         if (lane == 0) bu = atomicAdd(&s_total, cu + cp + cn);
         bu = __builtin_amdgcn_readfirstlane(bu);
       }
@@ -421,6 +466,23 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
   __shared__ float s_loss[TRS_BLOCK / TRS_WAVE];
   const float wl = trs_wave_sum(loss_acc);
   if (lane == 0) s_loss[threadIdx.x >> 6] = wl;
+  if (DEFER && early && my_cnt > 0) {  // (wave-uniform)
+    float x[DU][KDD];
+    const uint32_t seen = __hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    load_round(x, 0, my_cnt);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    complete = (int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)seen) - a.sync_target) >= 0;
+    if (complete) {  // every workgroup of the launch is past its flagged triples: nobody reads these rows any more
+      apply_round(x, 0, my_cnt);
+      for (int e0 = DU; e0 < my_cnt; e0 += DU) {
+        load_round(x, e0, my_cnt);
+        apply_round(x, e0, my_cnt);
+      }
+      next_e = my_cnt;
+    } else if (lane == 0) {
+      s_left = 1;  // (not yet: the workgroup waits below)
+    }
+  }
   if (DEFER) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's row loads and staging stores are done
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -430,53 +492,23 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
     if (L != 0.f) atomicAdd(a.loss_sum, L);
   }
   if (DEFER) {
-    // The workgroup's flagged references are dealt round-robin to its four waves (a single wave's share of them is 0 to
-    // 6 at c4, and the longest one of the launch would set the kernel's end), DU at a time: the staged rows of a round
-    // are loaded together (L2: written by this CU a moment ago), then one float atomic per element, a row = adjacent
-    // dwords (the full-rate atomic shape)
-    constexpr int DU = 4, KDD = (N * G + TRS_WAVE - 1) / TRS_WAVE;
-    const int wv = threadIdx.x >> 6;
+    // Not early: the workgroup's flagged references are dealt round-robin to its four waves (a single wave's share of
+    // them is 0 to 6 at c4, and the longest one of the launch would set the kernel's end), DU at a time: the staged rows
+    // of a round are loaded together (L2: written by this CU a moment ago), then one float atomic per element, a row =
+    // adjacent dwords (the full-rate atomic shape).  Early: what a wave has not applied inside its loop (more than DU
+    // references per iteration left, or a grid that was not counted in yet) — usually nothing, and then the workgroup
+    // does not even look at the counter.
     const int total = s_total;
-    const int n_mine = total > wv ? (total - wv + NWV - 1) / NWV : 0;  // entries wv, wv + NWV, ... of the list
-    float x[DU][KDD], cc[DU], cl[DU];
-    float *dst[DU], *dlin[DU];
-    bool has[DU];
-    auto load_round = [&](int e0) {
-#pragma unroll
-      for (int k = 0; k < DU; ++k) {
-        has[k] = e0 + k < n_mine;
-        // (same address in every lane: one LDS broadcast; without an entry, slot 0 is read as a dummy and not used)
-        const DeferEntry en = s_list[has[k] ? wv + NWV * (e0 + k) : 0];
-        const int which = (int)(en.tw & 3u);
-        const int64_t tk = has[k] ? (int64_t)(en.tw >> 2) : 0;
-        const int64_t rk = has[k] ? (int64_t)en.row : 0;
-        cc[k] = en.c;
-        cl[k] = en.clin;
-        const float* src = (which == 0 ? a.du : a.ustage) + tk * (int64_t)D;
-        dst[k] = (which == 0 ? T.user : T.item) + rk * (int64_t)D;
-        dlin[k] = (which == 0 ? T.user_lin : T.item_lin) + rk;
-#pragma unroll
-        for (int q = 0; q < KDD; ++q) {
-          const int e = q * TRS_WAVE + lane;
-          x[k][q] = __hip_atomic_load(src + (e < D ? e : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // past L1
-        }
-      }
-    };
-    auto apply_round = [&]() {
-#pragma unroll
-      for (int k = 0; k < DU; ++k) {
-        if (!has[k]) continue;
-#pragma unroll
-        for (int q = 0; q < KDD; ++q) {
-          const int e = q * TRS_WAVE + lane;
-          if (e < D) atomicAdd(dst[k] + e, cc[k] * x[k][q]);
-        }
-        if (lane == 0) atomicAdd(dlin[k], cl[k]);
-      }
-    };
+    const int n_mine = early ? my_cnt : (total > wv ? (total - wv + NWV - 1) / NWV : 0);
+    const int e_first = early ? next_e : 0;
+#ifdef TRS_K1_STAMPS
+    if (early && !s_left && threadIdx.x == 0) stamps[2] = stamps[3] = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (early && !s_left) return;  // (workgroup-uniform: written before the barrier above)
+    float x[DU][KDD];
     // the first round's staged rows travel to registers WHILE the workgroup waits for the grid (they are this
     // workgroup's own data, complete since the barrier above; typical: 2-3 flagged references per wave = one round)
-    load_round(0);
+    load_round(x, e_first, n_mine);
     if (threadIdx.x == 0 && early) {
       // counted in long ago, and so has everybody else: one look at the counter (bounded wait as below if it is not so)
       const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
@@ -519,10 +551,10 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
     if (threadIdx.x == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();
 #endif
     // every row read of the step is behind us, chip-wide
-    apply_round();
-    for (int e0 = DU; e0 < n_mine; e0 += DU) {
-      load_round(e0);
-      apply_round();
+    apply_round(x, e_first, n_mine);
+    for (int e0 = e_first + DU; e0 < n_mine; e0 += DU) {
+      load_round(x, e0, n_mine);
+      apply_round(x, e0, n_mine);
     }
 #ifdef TRS_K1_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
