@@ -1068,6 +1068,49 @@ def test_flag_mode_matches_oracle(net, D, skew, n_users, one_launch, tune):
     assert err.item() == 0
 
 
+@pytest.mark.parametrize("net,D", [("fm", 64), ("linear", 32), ("fm", 128)])
+def test_flag_mode_ordered_batches_without_any_shared_row(net, D, tune):
+    """Flagged-first order, edge: no row is named twice in a batch — n_flagged = 0, the one-launch step counts its
+    workgroups in before their first iteration, no wave has anything to apply — 2 steps == oracle SGD steps; and the
+    arrival counter still advances by the grid per launch."""
+    import ctypes
+    ops = _ops()
+    NU, NI, B, nb, lr = 4096, 8192, 2048, 2, 0.05
+    tune(K1_ITERS=4)
+    rs = np.random.RandomState(D)
+    p, _, _ = make_case(net, D, 0, 8, NU=NU, NI=NI, seed=3)
+    u = np.concatenate([rs.permutation(NU)[:B] for _ in range(nb)])
+    it = [rs.permutation(NI) for _ in range(nb)]
+    i, j = np.concatenate([x[:B] for x in it]), np.concatenate([x[B:2 * B] for x in it])
+    lin = ("user_bias.weight", "item_bias.weight") if net == "linear" else ("linear_user.weight", "linear_item.weight")
+    t = {k: torch.from_numpy(v.copy()).to(DEV) for k, v in p.items()}
+    T, keep = ops.make_tables(t["user.weight"], t["item.weight"], t[lin[0]], t[lin[1]])
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ef = ops.EpochFlags(nb, B, NU, NI, DEV)
+    ef.run(None, None, 0, 0, 0, err, given_ids=[torch.from_numpy(a.astype(np.int32)).to(DEV) for a in (u, i, j)])
+    ids, udup, idup = ef.step_args(0)
+    assert ef.n_flagged.tolist() == [0, 0] and int(udup.sum()) == 0 and int(idup.sum()) == 0
+    for got, want in zip(ids, (u, i, j)):  # nothing to move: the batches are as given
+        assert np.array_equal(got[:nb * B].cpu().numpy(), want)
+    gz, du = torch.empty((2, B), device=DEV), torch.empty((B, D), device=DEV)
+    losses = torch.zeros(nb, device=DEV)
+    sync = (torch.zeros(288, dtype=torch.int32, device=DEV), ctypes.c_uint32(0))
+    ops.train_steps_sgd(net, T, None, None, 0, 0, 0, B, nb, lr, *ids, gz, du, losses, err,
+                        ops.train_scratch(NU, NI, B, D, DEV), 1, None, user_dup=udup, item_dup=idup,
+                        ustage=torch.empty((B, D), device=DEV), sync=sync, n_flagged=ef.n_flagged_from(0))
+    torch.cuda.synchronize()
+    assert sync[1].value > 0 and sync[1].value % nb == 0 and int(sync[0][0].item()) == sync[1].value
+    ref = {k: v.copy() for k, v in p.items()}
+    for b in range(nb):
+        batch = {"user_id": u[b * B:(b + 1) * B], "pos_item_id": i[b * B:(b + 1) * B], "neg_item_id": j[b * B:(b + 1) * B]}
+        _, _, loss, grads = onets.train_forward_backward(net, ref, batch)
+        ooptim.sgd_step(ref, grads, lr)
+        assert abs(losses[b].item() / B - float(loss)) <= TOL * max(abs(float(loss)), 1e-3)
+    for k, v in ref.items():
+        assert rel_err(t[k].cpu().numpy(), v) < TOL, k
+    assert err.item() == 0
+
+
 @pytest.mark.parametrize("net,D,skew", [("fm", 64, False), ("fm", 64, True), ("fm", 16, True), ("linear", 32, True),
                                         ("fm", 80, False), ("fm", 10, True)])
 @pytest.mark.parametrize("inline_user", [False, True, "items", "userflags"])

@@ -40,7 +40,7 @@ e0.record()
 for _ in range(5):
     check = ops._lib.load().trs_epoch_flags(None, None, 0, 0, 0, 0, 16, B, NU, NI, ops.ptr(ef.ids[0]), ops.ptr(ef.ids[1]),
                                             ops.ptr(ef.ids[2]), ops.ptr(ef.user_dup), ops.ptr(ef.item_dup), ops.ptr(err),
-                                            ops._stream())
+                                            None, ops._stream())
 e1.record()
 torch.cuda.synchronize()
 print(f"given ids, 16 batches: {1e3 * e0.elapsed_time(e1) / 5:8.1f} us per slice (bitmap passes only)")

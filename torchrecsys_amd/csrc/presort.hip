@@ -148,6 +148,9 @@ __global__ __launch_bounds__(FLAG_THREADS) void batch_flags_kernel(const FlagArg
   const int lb = a.log2_bits;
   uint16_t* iflags16 = reinterpret_cast<uint16_t*>(a.iflags);  // {pos, neg} of a position as one 16-bit word
   constexpr int STEP = FLAG_THREADS * FLAG_U;
+  uint64_t anyf[NG];  // bit (rd % 8) * FLAG_U + k of word rd / 8: triple (round rd, k) of this thread carries a flag (phase D)
+#pragma unroll
+  for (int g = 0; g < NG; ++g) anyf[g] = 0;
   // ---- item references, then users: phases A / B / C over the same LDS bitmap
   for (int what = a.what_first; what < a.what_end; ++what) {
     const int hashed = what == 0 ? a.item_hash : a.user_hash;
@@ -204,7 +207,11 @@ __global__ __launch_bounds__(FLAG_THREADS) void batch_flags_kernel(const FlagArg
       }
     }
     __syncthreads();
-    for (int t0 = threadIdx.x; t0 < B; t0 += STEP) {  // C: flag = "my row is shared"
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll 1
+    for (int rr = 0; rr < FLAG_ROUNDS && (g * FLAG_ROUNDS + rr) * STEP < B; ++rr) {  // C: flag = "my row is shared"
+      const int t0 = threadIdx.x + (g * FLAG_ROUNDS + rr) * STEP;
       uint32_t b0[FLAG_U], b1[FLAG_U];
 #pragma unroll
       for (int k = 0; k < FLAG_U; ++k) {
@@ -218,10 +225,13 @@ __global__ __launch_bounds__(FLAG_THREADS) void batch_flags_kernel(const FlagArg
         const int t = t0 + k * FLAG_THREADS;
         if (t < B) {
           const uint32_t s0 = (bm[b0[k] >> 5] >> (b0[k] & 31)) & 1u;
-          if (what == 0) iflags16[q0 + t] = (uint16_t)(s0 | (((bm[b1[k] >> 5] >> (b1[k] & 31)) & 1u) << 8));
+          const uint32_t s1 = what == 0 ? (bm[b1[k] >> 5] >> (b1[k] & 31)) & 1u : 0u;
+          if (what == 0) iflags16[q0 + t] = (uint16_t)(s0 | (s1 << 8));
           else a.uflags[q0 + t] = (uint8_t)s0;
+          anyf[g] |= (uint64_t)(s0 | s1) << (rr * FLAG_U + k);
         }
       }
+    }
     }
     __syncthreads();
   }
@@ -243,11 +253,22 @@ __global__ __launch_bounds__(FLAG_THREADS) void batch_flags_kernel(const FlagArg
     __shared__ uint32_t s_nf, s_flnf;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     constexpr int NWV = FLAG_THREADS / 64;
-    auto flagged = [&](int t) -> bool { return t < B && (iflags16[q0 + t] != 0 || a.uflags[q0 + t] != 0); };
-    for (int c = wv; c < cells; c += NWV) {
-      const uint64_t bal = __ballot(flagged(c * 64 + lane));
-      if (lane == 0) F[c] = (uint32_t)__popcll((unsigned long long)bal);
+    // a thread's triples (t = tid + j * 1024, j = rd * FLAG_U + k) are lane `lane` of the cells wv + 16 j, and their flags
+    // sit in its registers (anyf): the three passes below touch no global memory
+#define TRS_FOR_MY_CELLS(BODY)                                                                     \
+    _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                                \
+      _Pragma("unroll 1") for (int rr = 0; rr < FLAG_ROUNDS && (g * FLAG_ROUNDS + rr) * STEP < B; ++rr) { \
+        _Pragma("unroll") for (int k = 0; k < FLAG_U; ++k) {                                        \
+          const int j = (g * FLAG_ROUNDS + rr) * FLAG_U + k;                                       \
+          const int c = wv + NWV * j;                                                              \
+          const int t = c * 64 + lane;                                                             \
+          const bool f = t < B && ((anyf[g] >> (rr * FLAG_U + k)) & 1ull) != 0;                    \
+          const uint64_t bal = __ballot(f);                                                        \
+          if (c < cells) { BODY }                                                                  \
+        }                                                                                          \
+      }                                                                                            \
     }
+    TRS_FOR_MY_CELLS(if (lane == 0) F[c] = (uint32_t)__popcll((unsigned long long)bal);)
     __syncthreads();
     if (wv == 0) {  // exclusive scan over the cells: a lane sums `per` consecutive cells, the wave scans the 64 sums
       const int per = (cells + 63) >> 6;
@@ -275,14 +296,10 @@ __global__ __launch_bounds__(FLAG_THREADS) void batch_flags_kernel(const FlagArg
     }
     __syncthreads();
     const int nf = (int)s_nf;
-    for (int c = wv; c < cells; c += NWV) {
-      const int t = c * 64 + lane;
-      const bool f = flagged(t);
-      const uint64_t bal = __ballot(f);
+    TRS_FOR_MY_CELLS(
       const uint32_t fl = F[c] + (uint32_t)__popcll((unsigned long long)(bal & ((1ull << lane) - 1ull)));
       if (t == nf) s_flnf = fl;
-      if (t < nf && !f && t - fl < (uint32_t)a.ord_cap) holes[t - fl] = (uint32_t)t;
-    }
+      if (t < nf && !f && t - fl < (uint32_t)a.ord_cap) holes[t - fl] = (uint32_t)t;)
     __syncthreads();
     const uint32_t flnf = s_flnf;
     const int m = nf - (int)flnf;  // holes = movers
@@ -290,13 +307,10 @@ __global__ __launch_bounds__(FLAG_THREADS) void batch_flags_kernel(const FlagArg
       if (threadIdx.x == 0) a.nflag[blockIdx.x] = B;
       return;
     }
-    for (int c = wv; c < cells; c += NWV) {
-      const int t = c * 64 + lane;
-      const bool f = flagged(t);
-      const uint64_t bal = __ballot(f);
+    TRS_FOR_MY_CELLS(
       const uint32_t fl = F[c] + (uint32_t)__popcll((unsigned long long)(bal & ((1ull << lane) - 1ull)));
-      if (t >= nf && f) movers[fl - flnf] = (uint32_t)t;
-    }
+      if (t >= nf && f) movers[fl - flnf] = (uint32_t)t;)
+#undef TRS_FOR_MY_CELLS
     __syncthreads();
     for (int k = threadIdx.x; k < m; k += FLAG_THREADS) {
       const int64_t x = q0 + holes[k], y = q0 + movers[k];
