@@ -432,6 +432,22 @@ def main():
         else:
             events = runner.trainer.kernel_events or {}
             runner.trainer.kernel_events = None
+    # One-launch steps: the launch stream holds NOTHING but the step kernel, so the interval between two events that are G
+    # launches apart is G kernel durations (launch gaps included) and only 1/G of an event record — the per-step intervals
+    # above contain a whole record each (~5 us on a ~32 us kernel; rocprofv3's durations in profiles/ say which is right).
+    grouped_us = None
+    if events and getattr(runner.trainer, "one_launch", False):
+        groups, per_group = 16, 8
+        run(per_group)  # (not synchronised: the queue is never empty when a group's first event is recorded)
+        gev = []
+        for _ in range(groups):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            run(per_group)
+            e1.record()
+            gev.append((e0, e1))
+        torch.cuda.synchronize()
+        grouped_us = [1e3 * e0.elapsed_time(e1) / per_group for e0, e1 in gev]
     frac = slice_fractions(runner) if not is_mlp else None
     runner.end_epoch()  # also raises if any id was out of range
 
@@ -479,6 +495,7 @@ def main():
         # write).  On the presorted path the last two events of a step are recorded back to back, so an upper bound of
         # that cost is measured live.  `achieved` is computed from the RAW intervals (conservative: rocprofv3's kernel
         # durations in profiles/ are shorter); the intervals minus the measured record cost are reported beside them.
+        # One-launch steps: from the grouped intervals measured above (G launches per event pair) instead.
         ev_ms = raw_ms.pop("event_overhead", 0.0)
         n_samples.pop("event_overhead", None)
         med_ms.pop("event_overhead", None)
@@ -489,7 +506,10 @@ def main():
         # stream can be 20x a normal one and would decide a mean over 37 samples); `achieved` uses that kernel's MEAN
         dom = max(med_ms, key=med_ms.get)
         per_triple = kernel_algorithmic_bytes(R, row, state_rows, mean_ms, frac)
-        ach = per_triple[dom] * B / (mean_ms[dom] * 1e-3) / 1e9
+        dur_ms = mean_ms[dom]
+        if grouped_us and dom == "fwd_stage_kernel" and frac and frac.get("one_launch"):
+            dur_ms = 1e-3 * sum(grouped_us) / len(grouped_us)
+        ach = per_triple[dom] * B / (dur_ms * 1e-3) / 1e9
         # measured HBM bytes per launch of that kernel: rocprofv3 PMC passes of THIS command committed under profiles/
         # (FETCH_SIZE / WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py).
         # A constant read from that file, not a live measurement: named in traffic_source; null when no profile of the
@@ -505,6 +525,12 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                            "samples": n_samples[dom],
+                           "launch_us": 1e3 * dur_ms,  # what `achieved` divides by
+                           "launch_us_source": ("16 groups of 8 consecutive one-launch steps, one HIP event pair per group "
+                                                "(launch gaps and 1/8 event record per launch included)"
+                                                if dur_ms != mean_ms[dom] else "mean of the per-step event intervals"),
+                           "grouped_launch_us": ({"mean": sum(grouped_us) / len(grouped_us), "min": min(grouped_us),
+                                                  "max": max(grouped_us)} if grouped_us else None),
                            "mean_launch_us": {k: 1e3 * v for k, v in mean_ms.items()},
                            "median_launch_us": {k: 1e3 * v for k, v in med_ms.items()},
                            "mean_launch_us_minus_event_record": {k: 1e3 * max(v - ev_ms, 0.0) for k, v in mean_ms.items()},

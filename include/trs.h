@@ -96,7 +96,7 @@ const char* trs_last_error(void);
 #define TRS_SYNC_WORDS 288
 int trs_abi_version(void);
 /* Tuning / A-B knobs of the launch paths (kernel selection, launch shapes): GRID_CAP, PASS_GRID_CAP, K1_ITERS,
- * PASS_ITERS, PRESORT_GRID_CAP, PASS_NT, K1_NT, GEMM32_NO_GLDS, GEMM16_TN_WIDE, GEMM16_TILE, GEMM16_NO_GLDS, BN_FINAL_TWO_SWEEPS (meanings:
+ * PASS_ITERS, PRESORT_GRID_CAP, PASS_NT, K1_NT, K1_WGS_PER_CU, GEMM32_NO_GLDS, GEMM16_TN_WIDE, GEMM16_TILE, GEMM16_NO_GLDS, BN_FINAL_TWO_SWEEPS (meanings:
  * csrc/trs_common.h TrsTuning).  The library reads TRS_<name> from the environment ONCE, at its first use; this entry
  * point changes a knob afterwards (tests, tools): unset != 0 restores the default.  The defaults are the measured best. */
 int trs_tuning_set(const char* name, int64_t value, int32_t unset);

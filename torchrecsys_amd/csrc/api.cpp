@@ -33,6 +33,7 @@ const Knob KNOBS[] = {
     {"PASS_ITERS", nullptr, &TrsTuning::pass_iters, 0},
     {"PASS_NT", nullptr, &TrsTuning::pass_nt, -1},
     {"K1_NT", nullptr, &TrsTuning::k1_nt, -1},
+    {"K1_WGS_PER_CU", nullptr, &TrsTuning::k1_wgs_per_cu, 2},
     {"GEMM32_NO_GLDS", nullptr, &TrsTuning::gemm32_no_glds, 0},
     {"GEMM16_TN_WIDE", nullptr, &TrsTuning::gemm16_tn_wide, -1},
     {"GEMM16_TILE", nullptr, &TrsTuning::gemm16_tile, 0},

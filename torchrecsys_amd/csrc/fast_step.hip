@@ -1347,7 +1347,8 @@ static int64_t defer_resident_cap(KernelT kernel) {
   if (hipGetDevice(&dev) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
     return 0;
-  const int per_cu = occ - 1 < 2 ? occ - 1 : 2;
+  const int want = trs_tuning().k1_wgs_per_cu;
+  const int per_cu = occ - 1 < want ? occ - 1 : want;
   return per_cu > 0 ? (int64_t)per_cu * cus : 0;
 }
 

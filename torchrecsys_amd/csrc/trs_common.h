@@ -43,6 +43,7 @@ struct TrsTuning {
   int pass_iters;         // TRS_PASS_ITERS      ... of pair_scores_kernel (0: by batch)
   int pass_nt;            // TRS_PASS_NT         nontemporal rows in the scoring pass: bit 0 user, bit 1 item (-1)
   int k1_nt;              // TRS_K1_NT           nontemporal user rows in the one-launch step: 1 loads, 3 loads + stores (-1)
+  int k1_wgs_per_cu;      // TRS_K1_WGS_PER_CU   workgroups per CU the one-launch step may count on being resident (2)
   int gemm32_no_glds;     // TRS_GEMM32_NO_GLDS  1: fp32 NT GEMMs on the register-staged 128 x 128 kernel
   int gemm16_tn_wide;     // TRS_GEMM16_TN_WIDE  0 | 1: weight-gradient GEMMs on 256 x 256 tiles (-1)
   int gemm16_tile;        // TRS_GEMM16_TILE     128 | 256 | 512: force the bf16-resident tile (0)
