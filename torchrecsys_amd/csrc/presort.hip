@@ -1084,7 +1084,9 @@ void sorted_updates_fused_kernel(const SortedArgs ia, const UserDupArgs ua,
 // launches of 280 us beside a 33 us median, every slice).  Two workgroups per CU leave three quarters of the slots to
 // the steps; the slice's ids then take ~4x as long, of the 18 ms the slice's steps run.
 static inline int presort_grid(int64_t n_pos) {
-  const int64_t cap = trs_tuning().presort_grid_cap;
+  // (short slices — up to 2^20 positions — take a thread per triple: the launch is over in ~20 us either way, and with
+  // four dependent stream reads per thread it lasted 54 us beside the steps of a 16-batch slice)
+  const int64_t cap = n_pos <= ((int64_t)1 << 20) ? 4096 : trs_tuning().presort_grid_cap;
   int64_t g = (n_pos + TRS_BLOCK - 1) / TRS_BLOCK;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
