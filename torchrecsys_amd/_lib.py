@@ -195,6 +195,10 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
             f"`make -C torchrecsys_amd/csrc`.  torchrecsys_amd has no CPU fallback.")
+    # PyTorch first: it ships its own HIP runtime, and the process must end up with ONE — the library's libamdhip64
+    # dependency then resolves to the copy torch has loaded.  (Loaded the other way round — this library before the first
+    # `import torch`, e.g. build() followed by smoke() in one process — the library's runtime saw no device on the GPU box.)
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing

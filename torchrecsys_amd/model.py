@@ -538,6 +538,17 @@ class FitRunner:
         self.ep = None
         self._next_ep = None
         self.prep_out = None
+        # MLP (fused embedding update, device RNG): ids AND duplicate flags of 256 batches at a time from the sparse
+        # regime's presort (trs_epoch_flags: the same triples trs_batch_prepare generates) instead of a prepare launch
+        # per step — with the flags, the update's rows that are alone in their batch (94-97 % at c5) take plain
+        # read-modify-writes instead of float atomics.  TRS_MLP_SLICE_FLAGS=0: a prepare launch per step, all atomics.
+        self._mlp_ef, self._mlp_slice = None, None
+        if (model.rng == 'device' and type(self.trainer).__name__ == "MLPTrainer" and
+                getattr(self.trainer, "kind", None) == "sgd" and self.trainer._fused_embed_lr() is not None and
+                batch_size <= ops.EpochFlags.MAX_BATCH and os.environ.get("TRS_MLP_SLICE_FLAGS", "1") != "0" and
+                self.dev.type == "cuda" and self.n_train >= batch_size):
+            self._mlp_ef = ops.EpochFlags(min(256, self.n_train // batch_size), batch_size, model.n_users,
+                                          model.n_items, self.dev, ordered=False)
 
     def begin_epoch(self):
         m = self.m
@@ -631,6 +642,8 @@ class FitRunner:
             s, e = b * B, min((b + 1) * B, self.n_train)
             if m.rng == 'reference':
                 ids = {key: v[s:e] for key, v in self.ep.items()}
+            elif self._mlp_ef is not None and e - s == B:
+                ids = self._mlp_slice_ids(b)
             else:
                 st = self.st
                 out = self.prep_out if (self.prep_out is not None and e - s == B) else None
@@ -642,6 +655,35 @@ class FitRunner:
             self.next_batch += 1
             done += 1
         return done
+
+    def _mlp_slice_ids(self, b):
+        """ids + duplicate flags of whole batch b as views of the current 256-batch slice (generated on the launch
+        stream when the epoch enters the slice: 0.8 ms per 256 steps of >= 1.5 ms each)."""
+        ef, B, st = self._mlp_ef, self.batch_size, self.st
+        cur = self._mlp_slice
+        if cur is None or cur[0] != self._epoch_no or not (cur[1] <= b < cur[1] + cur[2]):
+            s0 = (b // ef.n_batches) * ef.n_batches
+            nb = min(ef.n_batches, self.n_train // B - s0)
+            if "ui" not in st:
+                st["ui"] = ops.interleave_stream(st["user"], st["pos"])
+            run = ef if nb == ef.n_batches else None
+            if run is None:  # the epoch's last, shorter slice: the same buffers, fewer batches
+                run = ops.EpochFlags.__new__(ops.EpochFlags)
+                run.__dict__.update(ef.__dict__)
+                run.n_batches = nb
+            run.run(st["ui"], st["neg"], self.shuffle_key, self.sample_seed, s0 * B, self.trainer.err,
+                    sampler=self.sampler)
+            meta = None
+            if st.get("item_meta") is not None:
+                n = nb * B
+                meta = (st["item_meta"][ef.ids[1][:n].long()], st["item_meta"][ef.ids[2][:n].long()])
+            cur = self._mlp_slice = (self._epoch_no, s0, nb, meta)
+        o = (b - cur[1]) * B
+        ids = {"user": ef.ids[0][o:o + B], "pos": ef.ids[1][o:o + B], "neg": ef.ids[2][o:o + B],
+               "user_dup": ef.user_dup[o:o + B], "item_dup": ef.item_dup[o:o + B]}
+        if cur[3] is not None:
+            ids["pos_meta"], ids["neg_meta"] = cur[3][0][o:o + B], cur[3][1][o:o + B]
+        return ids
 
     def touch_host_path(self):
         """Walk the host side of the next run_steps() call with ZERO steps: the same Python code and the same C entry
