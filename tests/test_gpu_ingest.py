@@ -129,3 +129,49 @@ def test_remap_ids_with_metadata_rows_follow_the_items_present():
     assert np.array_equal(m.data_processor.item_meta_table[:, 0], meta_raw.cpu().numpy()[present, 0])
     top = m.predict(int(users[5]), top_k=7)
     assert set(top.tolist()) <= set(present.tolist()) and top.numel() == 7
+
+
+@pytest.mark.parametrize("meta", [False, True])
+def test_mlp_fit_takes_ids_and_flags_from_presort_slices(meta, monkeypatch):
+    """The MLP's device-RNG fit() draws its batches and their duplicate flags per slice from trs_epoch_flags (lone
+    embedding rows: plain read-modify-writes) — the same triples trs_batch_prepare generates step by step
+    (TRS_MLP_SLICE_FLAGS=0: that path, float atomics for every row): same losses, same tables up to the order of the
+    float atomics on duplicated rows, flags exact for these table sizes, metadata ids looked up per slice."""
+    from torchrecsys_amd.model import TorchRecSys
+    df = _frame(n_u=3000, n_i=1500, n=40_000, seed=5)
+    u, i = torch.from_numpy(df["user_id"].values).to(DEV), torch.from_numpy(df["item_id"].values).to(DEV)
+    rs = np.random.RandomState(1)
+    item_meta = torch.from_numpy(rs.randint(0, 9, (1500, 2))).to(DEV) if meta else None
+
+    def run(slices):
+        monkeypatch.setenv("TRS_MLP_SLICE_FLAGS", "1" if slices else "0")
+        np.random.seed(4)
+        torch.manual_seed(4)
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = TorchRecSys.from_tensors(u, i, item_metadata=item_meta, n_factors=32, net_type="mlp",
+                                         hidden_layers=[64, 32], dynamic_neg_sampling=True, rng="device", seed=11)
+            opt = torch.optim.SGD(m.parameters(), lr=0.05)
+            r = m.make_runner(opt, 1024)
+            assert (r._mlp_ef is not None) == slices
+            m.net.train()
+            losses = []
+            for _ in range(2):
+                r.begin_epoch()
+                while r.run_steps(7):
+                    pass
+                losses.append(r.end_epoch())
+        if slices:  # the slice in use: flags == "the row occurs again in this batch" (tables fit the bitmap: exact)
+            ef, (_, s0, nb, _m) = r._mlp_ef, r._mlp_slice
+            for b in range(nb):
+                sl = slice(b * 1024, (b + 1) * 1024)
+                uu, pp, nn = (t[sl].long() for t in ef.ids)
+                assert torch.equal(ef.user_dup[sl].bool(), torch.bincount(uu, minlength=3000)[uu] > 1)
+                cnt = torch.bincount(torch.cat([pp, nn]), minlength=1500)
+                assert torch.equal(ef.item_dup[sl].bool(), torch.stack([cnt[pp] > 1, cnt[nn] > 1], 1))
+        return m, losses
+    a, la = run(True)
+    b, lb = run(False)
+    for x, y in zip(la, lb):
+        assert abs(x - y) <= 5e-3 * max(abs(y), 1e-3), (la, lb)
+    for (k, va), (_, vb) in zip(sorted(a.state_dict().items()), sorted(b.state_dict().items())):
+        assert torch.allclose(va.float(), vb.float(), rtol=0, atol=5e-3), k
