@@ -153,6 +153,9 @@ def test_mlp_fit_takes_ids_and_flags_from_presort_slices(meta, monkeypatch):
             opt = torch.optim.SGD(m.parameters(), lr=0.05)
             r = m.make_runner(opt, 1024)
             assert (r._mlp_ef is not None) == slices
+            if slices and meta:  # slices of 8 batches: 31 whole batches = 3 slices + a shorter last one
+                from torchrecsys_amd import ops
+                r._mlp_ef = ops.EpochFlags(8, 1024, 3000, 1500, DEV, ordered=False)
             m.net.train()
             losses = []
             for _ in range(2):

@@ -666,13 +666,8 @@ class FitRunner:
             nb = min(ef.n_batches, self.n_train // B - s0)
             if "ui" not in st:
                 st["ui"] = ops.interleave_stream(st["user"], st["pos"])
-            run = ef if nb == ef.n_batches else None
-            if run is None:  # the epoch's last, shorter slice: the same buffers, fewer batches
-                run = ops.EpochFlags.__new__(ops.EpochFlags)
-                run.__dict__.update(ef.__dict__)
-                run.n_batches = nb
-            run.run(st["ui"], st["neg"], self.shuffle_key, self.sample_seed, s0 * B, self.trainer.err,
-                    sampler=self.sampler)
+            ef.run(st["ui"], st["neg"], self.shuffle_key, self.sample_seed, s0 * B, self.trainer.err,
+                   sampler=self.sampler, n_batches=nb)  # (the epoch's last slice may be shorter)
             meta = None
             if st.get("item_meta") is not None:
                 n = nb * B

@@ -321,14 +321,18 @@ class EpochFlags:
     def bytes_needed(n_batches, batch):
         return 15 * n_batches * batch
 
-    def run(self, stream_ui, neg_static, shuffle_key, sample_seed, first_pos, err_flag, given_ids=None, sampler=None):
+    def run(self, stream_ui, neg_static, shuffle_key, sample_seed, first_pos, err_flag, given_ids=None, sampler=None,
+            n_batches=None):
+        """n_batches: fewer batches than the buffers hold (an epoch's last, shorter slice)."""
+        nb = self.n_batches if n_batches is None else int(n_batches)
+        assert 0 < nb <= self.n_batches
         if given_ids is not None:
-            n_pos = self.n_batches * self.batch
+            n_pos = nb * self.batch
             for dst, src in zip(self.ids, given_ids):
                 dst[:n_pos].copy_(src[:n_pos])
         N = 0 if stream_ui is None else stream_ui.shape[0]
         check(_lib.load().trs_epoch_flags_ordered(ptr(stream_ui), ptr(neg_static), N, int(shuffle_key), int(sample_seed),
-                                                  int(first_pos), self.n_batches, self.batch, self.n_users,
+                                                  int(first_pos), nb, self.batch, self.n_users,
                                                   self.n_items, ptr(self.ids[0]), ptr(self.ids[1]), ptr(self.ids[2]),
                                                   ptr(self.user_dup), ptr(self.item_dup), ptr(self.n_flagged),
                                                   ptr(err_flag), _samp(sampler), _stream()),
