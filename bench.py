@@ -416,8 +416,18 @@ def main():
 
     # ---- instrumented window (untimed): the same steps with HIP events around the kernels, on the launch stream ----
     events, gemm_events = {}, None
+    inst_slice = None
     if not args.no_kernel_events:
         n_inst = 64 if is_mlp else 256
+        if not is_mlp and "TRS_SLICE_BATCHES" not in os.environ:
+            # The kernel-level measurements describe the step kernel as a fit() runs it: with the production presort
+            # slices (512 batches).  The timed region above keeps slices no longer than the run (so that it carries its
+            # share of the presort), and a 16-batch slice puts the presort's fixed latency beside a quarter of the
+            # steps — a property of the short window, not of the kernel (profiles/EXPERIMENTS.md, slice length).
+            from torchrecsys_amd.engine import SparseScorerTrainer
+            inst_slice = SparseScorerTrainer.SLICE_BATCHES = 512
+            run(16)  # enter the first long slice (its presort runs here) before anything is recorded
+            torch.cuda.synchronize()
         if is_mlp:
             model.net.compute.gemm_events = []
             model.net.compute.gemm_steps_seen = model.net.compute.gemm_steps_timed = 0
@@ -538,8 +548,11 @@ def main():
                            "algorithmic_bytes_per_triple": per_triple[dom],
                            "algorithmic_bytes_per_triple_all": {k: per_triple[k] for k in mean_ms if k in per_triple},
                            "row_reference_fractions": frac,
+                           "presort_slice_batches": {"timed_region": sl if not is_mlp and "TRS_SLICE_BATCHES" not in os.environ else None,
+                                                     "instrumented_window": inst_slice},
                            "note": "HIP events on the launch stream, one step in 7 of a 256-step instrumented window "
-                                   "that follows the timed region (the timed region itself records no events)"}
+                                   "that follows the timed region (the timed region itself records no events); the "
+                                   "instrumented window runs with the production presort slices (512 batches)"}
     # ---- the north-star pass alone: fused pos+neg gather + pairwise score (trs_score_forward), read-only ----
     if not is_mlp and not args.no_pass and M == 0:
         out["roofline_pass"] = time_pass(model, runner, B, D, R, dev)
