@@ -185,13 +185,16 @@ __device__ __forceinline__ void load_rows(TripleRows<VEC, K>& r, const trs_table
 // once): INL 2, and the flagged references are applied by this same launch instead of flagged_update_kernel.  The
 // workgroup lists its flagged references in LDS — (triple, which) | table row | coefficient | coefficient of the 1-wide
 // term; a wave takes its slots with ONE LDS atomic per iteration, positions inside come from ballots — and stages their
-// rows in global memory as in INL 2.  After its last triple a
+// rows in global memory as in INL 2.  Batches in arbitrary order (a.nflag NULL): after its last triple a
 // workgroup waits for its loads and stores (s_waitcnt vmcnt(0) + barrier), counts itself in on the step's arrival
 // counter and waits until ALL workgroups of the launch have done so: from then on no row of the tables is read any more
 // by this step, so the float atomics of the flagged references — each workgroup re-reads the rows IT staged (same CU:
-// its own stores are visible to it) — may land.  What this replaces: a kernel boundary, a ramp, and the second launch's
-// detection pass over all 3B ids and flags for the 6 % of references that are flagged.  The wait is bounded (50 ms of
-// s_memrealtime): a grid that cannot become resident (another process on the same GPU) raises err bit 2 instead of hanging.
+// its own stores are visible to it) — may land.  Flagged-first batches (a.nflag, the product path): the workgroups count
+// themselves in right behind the flagged triples, mid-loop, and every wave applies its own references after its last
+// iteration without waiting for anybody (see `early` below).  What this replaces: a kernel boundary, a ramp, and the
+// second launch's detection pass over all 3B ids and flags for the 6 % of references that are flagged.  Every wait is
+// bounded (50 ms of s_memrealtime): a grid that cannot become resident (another process on the same GPU) raises err bit
+// 2 instead of hanging.
 constexpr int DEFER_ITERS = 8;  // iterations per lane group the per-wave list is sized for (launch_fwd_stage keeps to it)
 struct DeferEntry {
   uint32_t tw;   // (t << 2) | which      which: 0 user (row staged in du), 1 positive, 2 negative (row staged in ustage)
