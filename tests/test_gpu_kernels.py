@@ -1068,6 +1068,36 @@ def test_flag_mode_matches_oracle(net, D, skew, n_users, one_launch, tune):
     assert err.item() == 0
 
 
+@pytest.mark.parametrize("B", [1, 2, 63, 64, 65, 1000, 4097, 20000])
+@pytest.mark.parametrize("dense", [False, True])
+def test_flagged_first_order_any_batch_length(B, dense):
+    """trs_epoch_flags_ordered on batches whose length is no multiple of anything (the partition works on 64-position
+    cells and 1024-thread rounds): per batch the same multiset of triples as given, every triple with its own flags,
+    the flagged ones first and counted.  dense: nearly every triple flagged; sparse: a few."""
+    ops = _ops()
+    rs = np.random.RandomState(B + dense)
+    nb = 3
+    NU, NI = (max(B // 2, 2), max(B // 3, 3)) if dense else (min(40 * B + 7, 1 << 20), min(60 * B + 11, 1 << 20))
+    u, i, j = rs.randint(0, NU, nb * B), rs.randint(0, NI, nb * B), rs.randint(0, NI, nb * B)
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ef = ops.EpochFlags(nb, B, NU, NI, DEV)
+    ef.run(None, None, 0, 0, 0, err, given_ids=[torch.from_numpy(a.astype(np.int32)).to(DEV) for a in (u, i, j)])
+    torch.cuda.synchronize()
+    uo, io, jo = (t_[:nb * B].cpu().numpy().astype(np.int64) for t_ in ef.ids)
+    ud, idp = ef.user_dup[:nb * B].cpu().numpy().astype(bool), ef.item_dup[:nb * B].cpu().numpy().astype(bool)
+    for b in range(nb):
+        sl = slice(b * B, (b + 1) * B)
+        a_, b_ = np.stack([u[sl], i[sl], j[sl]], 1), np.stack([uo[sl], io[sl], jo[sl]], 1)
+        assert np.array_equal(a_[np.lexsort(a_.T)], b_[np.lexsort(b_.T)])
+        assert np.array_equal(ud[sl], np.bincount(uo[sl], minlength=NU)[uo[sl]] > 1)  # (tables fit the bitmap: exact)
+        cnt = np.bincount(np.concatenate([io[sl], jo[sl]]), minlength=NI)
+        assert np.array_equal(idp[sl], np.stack([cnt[io[sl]] > 1, cnt[jo[sl]] > 1], 1))
+        anyf = ud[sl] | idp[sl].any(axis=1)
+        nf = int(ef.n_flagged[b].item())
+        assert nf == int(anyf.sum()) and anyf[:nf].all() and not anyf[nf:].any(), (b, nf, int(anyf.sum()))
+    assert err.item() == 0
+
+
 @pytest.mark.parametrize("net,D", [("fm", 64), ("linear", 32), ("fm", 128)])
 def test_flag_mode_ordered_batches_without_any_shared_row(net, D, tune):
     """Flagged-first order, edge: no row is named twice in a batch — n_flagged = 0, the one-launch step counts its
