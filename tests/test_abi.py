@@ -110,3 +110,43 @@ def test_ctypes_structs_follow_the_header_member_by_member():
     src = open(os.path.join(ROOT, "include", "trs.h")).read()
     assert int(re.search(r"#define TRS_ABI_VERSION (\d+)", src).group(1)) == _lib.ABI_VERSION
     assert _lib.load().trs_train_steps_sgd(None, None) == -1  # validated on the host, no launch
+
+
+def test_one_launch_step_kernels_keep_four_waves_per_simd(tmp_path):
+    """Register guard on the shipped code objects (no GPU, no recompilation): the one-launch step kernels of the c4 /
+    c2 row shapes (FM, 16-byte lanes, whole rows: 32 or 16 lanes per triple) need at most 128 VGPRs — four waves per
+    SIMD; at 133-135 the same kernel ran 2 us per step slower (profiles/EXPERIMENTS.md) — and no scratch."""
+    import re
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
+    if not all(os.path.exists(t) for t in tools):
+        pytest.skip("ROCm LLVM tools not found")
+    from torchrecsys_amd import _lib
+    fat = tmp_path / "fat.bin"
+    subprocess.run([tools[0], "-O", "binary", "--only-section=.hip_fatbin", _lib.LIB_PATH, str(fat)], check=True)
+    data = fat.read_bytes()
+    offs = [m.start() for m in re.finditer(re.escape(b"__CLANG_OFFLOAD_BUNDLE__"), data)]
+    assert offs, "no offload bundle in libtrs_hip.so"
+    found = {}
+    for k, o in enumerate(offs):  # one bundle per translation unit
+        part, co = tmp_path / "b.bin", tmp_path / "co.o"
+        part.write_bytes(data[o:offs[k + 1] if k + 1 < len(offs) else len(data)])
+        r = subprocess.run([tools[1], "--type=o", "--unbundle", f"--input={part}",
+                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], capture_output=True)
+        if r.returncode:
+            continue
+        notes = subprocess.run([tools[2], "--notes", str(co)], capture_output=True, text=True).stdout
+        for blk in notes.split("- .agpr_count:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk)
+            vg = re.search(r"\.vgpr_count:\s+(\d+)", blk)
+            sc = re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk)
+            if name and vg and sc:
+                found[name.group(1)] = (int(vg.group(1)), int(sc.group(1)))
+    shutil.rmtree(tmp_path, ignore_errors=True)
+    hot = {n: v for n, v in found.items()
+           if re.search(r"fwd_stage_kernelILi1ELi4ELi(32|16)ELi1ELi0ELb1ELi3ELi0ELi[013]E", n)}
+    assert len(hot) == 6, sorted(hot)
+    for n, (vgpr, scratch) in hot.items():
+        assert vgpr <= 128 and scratch == 0, (n, vgpr, scratch)
