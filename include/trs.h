@@ -321,7 +321,8 @@ typedef struct trs_train_args {
   const int32_t* n_flagged_dev; /* NULL, or (n_steps) int32 from trs_epoch_flags_ordered (the id and flag arrays above
                                 then are the ones it ordered): batch st's first n_flagged_dev[st] triples are the ones
                                 that carry a flagged reference.  The one-launch step then counts a workgroup in as soon
-                                as it is past those triples and never waits for the slowest workgroup. */
+                                as it is past those triples and never waits for the slowest workgroup.  err bit 3: a
+                                flagged reference was met behind those triples (arrays of another origin). */
 } trs_train_args;
 int trs_train_steps_sgd(const trs_train_args* args, void* stream);
 

@@ -1068,6 +1068,37 @@ def test_flag_mode_matches_oracle(net, D, skew, n_users, one_launch, tune):
     assert err.item() == 0
 
 
+def test_one_launch_step_reports_flag_counts_of_another_origin(tune):
+    """n_flagged_dev that does not describe the arrays it comes with (here: zeroed counts for batches that do hold
+    flagged triples) is detected by the step — err bit 3 — instead of silently racing."""
+    import ctypes
+    ops = _ops()
+    rs = np.random.RandomState(5)
+    NU, NI, B, D = 4000, 5000, 2048, 64
+    tune(K1_ITERS=4)
+    p, _, _ = make_case("fm", D, 0, 8, NU=NU, NI=NI, seed=1)
+    t = {k: torch.from_numpy(v.copy()).to(DEV) for k, v in p.items()}
+    T, keep = ops.make_tables(t["user.weight"], t["item.weight"], t["linear_user.weight"], t["linear_item.weight"])
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ef = ops.EpochFlags(1, B, NU, NI, DEV)
+    ef.run(None, None, 0, 0, 0, err,
+           given_ids=[torch.from_numpy(rs.randint(0, n, B).astype(np.int32)).to(DEV) for n in (NU, NI, NI)])
+    assert 0 < int(ef.n_flagged[0].item()) < B
+    ef.n_flagged.zero_()
+    ids, udup, idup = ef.step_args(0)
+    sync = (torch.zeros(288, dtype=torch.int32, device=DEV), ctypes.c_uint32(0))
+    ops.train_steps_sgd("fm", T, None, None, 0, 0, 0, B, 1, 0.05, *ids, torch.empty((2, B), device=DEV),
+                        torch.empty((B, D), device=DEV), torch.zeros(1, device=DEV), err,
+                        ops.train_scratch(NU, NI, B, D, DEV), 1, None, user_dup=udup, item_dup=idup,
+                        ustage=torch.empty((B, D), device=DEV), sync=sync, n_flagged=ef.n_flagged_from(0))
+    torch.cuda.synchronize()
+    assert sync[1].value > 0  # (the one-launch form ran)
+    assert int(err.item()) & 8
+    from torchrecsys_amd.collaborative._scorer import check_err_flag
+    with pytest.raises(RuntimeError, match="n_flagged_dev"):
+        check_err_flag(err, "step")
+
+
 @pytest.mark.parametrize("B", [1, 2, 63, 64, 65, 1000, 4097, 20000])
 @pytest.mark.parametrize("dense", [False, True])
 def test_flagged_first_order_any_batch_length(B, dense):

@@ -128,6 +128,10 @@ def check_err_flag(err, what):
                            "at once within 50 ms (another process is computing on the same device?); the step that "
                            "timed out is not exact.  Set TRS_FLAG_ONE_LAUNCH=0 to run the step as two launches when "
                            "several processes share one GPU.")
+    if code & 8:  # bit 3: the one-launch step met a flagged reference behind the batch's first n_flagged triples
+        err.zero_()
+        raise RuntimeError(f"{what}: n_flagged_dev does not describe the id / flag arrays of this step (they must be the "
+                           "ones trs_epoch_flags_ordered wrote); the step is not exact.")
     if code != 0:
         raise IndexError(f"index out of range in self ({what}: an id is outside its embedding table; ids must be "
                          f"dense 0..n-1 as in the reference, dataset/dataset.py:30-31,268-269)")

@@ -352,6 +352,10 @@ __global__ __launch_bounds__(TRS_BLOCK) void fwd_stage_kernel(const FastArgs a) 
       if (early) {  // the wave's own part of the list
         bu = wv * CAPW + my_cnt;
         my_cnt += cu + cp + cn;
+        // a flagged reference BEHIND the first nf triples: n_flagged_dev does not describe these id / flag arrays (they
+        // are not the ones trs_epoch_flags_ordered wrote) — the workgroup has counted itself in already, so this step is
+        // not exact: err bit 3
+        if (arrived && (cu + cp + cn) && lane == 0 && a.err) atomicOr(a.err, 8);
       } else if (cu + cp + cn) {  // (wave-uniform) this wave's slots of the workgroup's list: one LDS atomic per iteration
         if (lane == 0) bu = atomicAdd(&s_total, cu + cp + cn);
         bu = __builtin_amdgcn_readfirstlane(bu);
